@@ -1,0 +1,253 @@
+"""ctypes binding of libadrates_hip.so (C-ABI: include/adrates.h).
+
+There is deliberately no CPU fallback: if the shared library has not been built
+or no HIP device is usable, every pricing entry point raises.  Build the library
+with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C adrates_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .utils.error import LibError
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadrates_hip.so")
+_lib = None
+
+REQ_VALUE, REQ_DELTA, REQ_GAMMA = 1, 2, 4
+MAX_PILLARS = 32
+
+_dp = C.POINTER(C.c_double)
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+_SIGNATURES = {
+    "adr_version": (C.c_int, []),
+    "adr_last_error": (C.c_char_p, []),
+    "adr_device_count": (C.c_int, []),
+    "adr_init": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "adr_free_ctx": (None, [_vp]),
+    "adr_sync": (C.c_int, [_vp]),
+    "adr_curve_upload": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
+    "adr_free_curve": (None, [_vp]),
+    "adr_curve_pillars": (C.c_int, [_vp]),
+    "adr_curve_tables_host": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, _dp, _i32p, _dp, _dp, _dp]),
+    "adr_trades_upload": (C.c_int, [_vp, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, _dp, _dp, _dp,
+                                    _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
+    "adr_free_trades": (None, [_vp]),
+    "adr_trades_count": (C.c_int64, [_vp]),
+    "adr_trades_input_bytes": (C.c_int64, [_vp]),
+    "adr_price": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _dp, _dp, _dp, _dp]),
+    "adr_price_dev": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
+    "adr_allreduce_agg": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library (no GPU needed for this step) and declare the
+    argument types of every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise LibError(f"HIP extension not built: {_LIB_PATH} is missing "
+                       "(run __graft_entry__.build() or make -C adrates_amd/csrc); "
+                       "there is no CPU fallback for the pricing path")
+    lib = C.CDLL(_LIB_PATH)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc < 0:
+        msg = load().adr_last_error().decode("utf-8", "replace")
+        raise LibError(f"{what} failed ({rc}): {msg}")
+    return rc
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a, typ=_dp):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+class Context:
+    """One per GPU/process: owns the device selection, a stream and scratch."""
+
+    def __init__(self, device: int = 0):
+        lib = load()
+        h = _vp()
+        _check(lib.adr_init(int(device), C.byref(h)), "adr_init")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().adr_free_ctx(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(load().adr_sync(self._h), "adr_sync")
+
+
+class DeviceCurve:
+    """Curve tables resident on the GPU (adr_curve_upload)."""
+
+    def __init__(self, ctx: Context, interp_method: int, times, dfs, jac, hess=None):
+        times, dfs, jac = _f64(times), _f64(dfs), _f64(jac)
+        K, P = jac.shape
+        if times.shape != (K,) or dfs.shape != (K,):
+            raise LibError("curve arrays have inconsistent shapes")
+        hess_c = None
+        if hess is not None:
+            hess_c = _f64(hess)
+            if hess_c.shape != (K, P, P):
+                raise LibError("hess must have shape [K, P, P]")
+        h = _vp()
+        _check(load().adr_curve_upload(ctx._h, int(interp_method), K, P, _ptr(times), _ptr(dfs), _ptr(jac),
+                                       _ptr(hess_c), C.byref(h)), "adr_curve_upload")
+        self._h, self._ctx = h, ctx
+        self.n_pillars, self.n_knots = P, K
+        self.has_hess = hess is not None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().adr_free_curve(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceTrades:
+    """A batch of OIS trades resident on the GPU (adr_trades_upload)."""
+
+    def __init__(self, ctx: Context, batch):
+        b = batch
+        n = int(b.n_trades)
+        arrs = dict(fix_off=np.ascontiguousarray(b.fix_off, dtype=np.int64),
+                    flt_off=np.ascontiguousarray(b.flt_off, dtype=np.int64))
+        for name in ("fix_tp", "fix_pay", "flt_tp", "flt_ts", "flt_te", "flt_alpha",
+                     "notional", "spread", "fix_sign", "flt_sign"):
+            arrs[name] = _f64(getattr(b, name))
+        if arrs["fix_off"].shape != (n + 1,) or arrs["flt_off"].shape != (n + 1,):
+            raise LibError("offset arrays must have n_trades + 1 entries")
+        h = _vp()
+        _check(load().adr_trades_upload(
+            ctx._h, n, _ptr(arrs["fix_off"], _i64p), _ptr(arrs["flt_off"], _i64p),
+            _ptr(arrs["fix_tp"]), _ptr(arrs["fix_pay"]), _ptr(arrs["flt_tp"]), _ptr(arrs["flt_ts"]),
+            _ptr(arrs["flt_te"]), _ptr(arrs["flt_alpha"]), _ptr(arrs["notional"]), _ptr(arrs["spread"]),
+            _ptr(arrs["fix_sign"]), _ptr(arrs["flt_sign"]), C.byref(h)), "adr_trades_upload")
+        self._h, self._ctx = h, ctx
+        self.n_trades = n
+
+    @property
+    def input_bytes(self) -> int:
+        return int(load().adr_trades_input_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().adr_free_trades(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def price(ctx: Context, curve: DeviceCurve, trades: DeviceTrades, want_value=True, want_delta=True,
+          want_gamma=True, per_trade=True, aggregate=False):
+    """Blocking pricing call returning numpy arrays (adr_price).
+
+    Returns a dict with ``pv [n]``, ``delta [n, P]``, ``gamma [n, P, P]`` (when
+    ``per_trade``) and ``agg_pv``, ``agg_delta [P]``, ``agg_gamma [P, P]`` (when
+    ``aggregate``)."""
+    n, P = trades.n_trades, curve.n_pillars
+    mask = (REQ_VALUE if want_value else 0) | (REQ_DELTA if want_delta else 0) | (REQ_GAMMA if want_gamma else 0)
+    pv = np.empty(n) if (per_trade and want_value) else None
+    delta = np.empty((n, P)) if (per_trade and want_delta) else None
+    gamma = np.empty((n, P, P)) if (per_trade and want_gamma) else None
+    agg = np.empty(1 + P + P * P) if aggregate else None
+    _check(load().adr_price(ctx._h, curve._h, trades._h, mask, _ptr(pv), _ptr(delta), _ptr(gamma), _ptr(agg)),
+           "adr_price")
+    out = {}
+    if pv is not None:
+        out["pv"] = pv
+    if delta is not None:
+        out["delta"] = delta
+    if gamma is not None:
+        out["gamma"] = gamma
+    if agg is not None:
+        out["agg_pv"] = float(agg[0])
+        out["agg_delta"] = agg[1:1 + P].copy()
+        out["agg_gamma"] = agg[1 + P:].reshape(P, P).copy()
+    return out
+
+
+def price_dev(ctx: Context, curve: DeviceCurve, trades: DeviceTrades, mask: int, pv_ptr=0, delta_ptr=0,
+              gamma_ptr=0, agg_ptr=0, stream=0):
+    """Non-blocking pricing into caller-owned device buffers (adr_price_dev);
+    pointers are integers (e.g. ``tensor.data_ptr()``), ``stream`` a hipStream_t
+    handle (0 = the context's own stream)."""
+    _check(load().adr_price_dev(ctx._h, curve._h, trades._h, int(mask), _vp(pv_ptr or None), _vp(delta_ptr or None),
+                                _vp(gamma_ptr or None), _vp(agg_ptr or None), _vp(stream or None)), "adr_price_dev")
+
+
+def curve_tables_host(times, dfs, jac, hess=None):
+    """Log-space tables of the reachable knots, computed by the library's host
+    code (no GPU needed) - used by the CPU tests."""
+    times, dfs, jac = _f64(times), _f64(dfs), _f64(jac)
+    K, P = jac.shape
+    hess_c = None if hess is None else _f64(hess)
+    lib = load()
+    kc = _check(lib.adr_curve_tables_host(K, P, _ptr(times), _ptr(dfs), _ptr(jac), _ptr(hess_c),
+                                          None, None, None, None), "adr_curve_tables_host")
+    idx = np.empty(kc, dtype=np.int32)
+    log_df = np.empty(kc)
+    lj = np.empty((kc, P))
+    lc = np.empty((kc, P, P)) if hess is not None else None
+    _check(lib.adr_curve_tables_host(K, P, _ptr(times), _ptr(dfs), _ptr(jac), _ptr(hess_c),
+                                     _ptr(idx, _i32p), _ptr(log_df), _ptr(lj), _ptr(lc)), "adr_curve_tables_host")
+    return dict(knot_index=idx, log_df=log_df, lj=lj, lc=lc)
+
+
+_default_ctx = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    """Process-wide context for ``device`` (default: LOCAL_RANK or 0)."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+        n = load().adr_device_count()
+        if n > 0:
+            device %= n
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

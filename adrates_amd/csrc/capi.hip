@@ -1,0 +1,347 @@
+// C-ABI of libadrates_hip.so (declarations and reference citations: include/adrates.h).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/adrates.h"
+#include "curve_tables.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+int fail_hip(hipError_t e, const char* what) {
+    return fail(ADR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define ADR_HIP(call)                                      \
+    do {                                                   \
+        hipError_t e__ = (call);                           \
+        if (e__ != hipSuccess) return fail_hip(e__, #call); \
+    } while (0)
+
+template <typename T>
+hipError_t upload(const std::vector<T>& host, T** dev) {
+    *dev = nullptr;
+    if (host.empty()) return hipSuccess;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(dev), host.size() * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+}  // namespace
+
+struct adr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cu = 0;
+    size_t lds_limit = 0;
+    double* partials = nullptr;     // [max_blocks][kAggStride] scratch for the aggregate
+    int max_blocks = 0;
+};
+
+struct adr_curve {
+    adr_ctx* ctx = nullptr;
+    adr::CurveDev dev{};
+    std::vector<void*> allocations;
+};
+
+struct adr_trades {
+    adr_ctx* ctx = nullptr;
+    adr::TradesDev dev{};
+    int64_t n_fix_flows = 0, n_flt_flows = 0;
+    std::vector<void*> allocations;
+};
+
+extern "C" {
+
+int adr_version(void) { return 100; }
+
+const char* adr_last_error(void) { return g_last_error.c_str(); }
+
+int adr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int adr_init(int device_ordinal, adr_ctx** out) {
+    if (!out) return fail(ADR_ERR_INVALID, "adr_init: out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(ADR_ERR_HIP, "adr_init: no HIP device available (this library has no CPU fallback)");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(ADR_ERR_INVALID, "adr_init: bad device ordinal");
+    ADR_HIP(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    ADR_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+    adr_ctx* ctx = new (std::nothrow) adr_ctx();
+    if (!ctx) return fail(ADR_ERR_NOMEM, "adr_init: out of memory");
+    ctx->device = device_ordinal;
+    ctx->n_cu = prop.multiProcessorCount;
+    ctx->lds_limit = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor
+                                                           : prop.sharedMemPerBlock;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return fail_hip(e, "hipStreamCreate"); }
+    ctx->max_blocks = std::max(1, ctx->n_cu) * 8;
+    e = hipMalloc(reinterpret_cast<void**>(&ctx->partials),
+                  sizeof(double) * static_cast<size_t>(ctx->max_blocks) * adr::kAggStride);
+    if (e != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return fail_hip(e, "hipMalloc(partials)"); }
+    *out = ctx;
+    return ADR_OK;
+}
+
+void adr_free_ctx(adr_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->partials) hipFree(ctx->partials);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int adr_sync(adr_ctx* ctx) {
+    if (!ctx) return fail(ADR_ERR_INVALID, "adr_sync: ctx is null");
+    ADR_HIP(hipStreamSynchronize(ctx->stream));
+    return ADR_OK;
+}
+
+// ------------------------------------------------------------------------------------------- curve
+int adr_curve_tables_host(int K, int P, const double* times, const double* dfs, const double* jac,
+                          const double* hess, int32_t* knot_index, double* log_df, double* lj, double* lc) {
+    adr::CurveTables t;
+    const std::string err = adr::build_curve_tables(K, P, times, dfs, jac, hess, t);
+    if (!err.empty()) return fail(ADR_ERR_INVALID, "adr_curve_tables_host: " + err);
+    if (knot_index) std::copy(t.knot_index.begin(), t.knot_index.end(), knot_index);
+    if (log_df) std::copy(t.log_df.begin(), t.log_df.end(), log_df);
+    if (lj)
+        for (int c = 0; c < t.Kc; ++c)
+            for (int p = 0; p < P; ++p) lj[static_cast<size_t>(c) * P + p] = t.lj[static_cast<size_t>(c) * adr::kPillarPad + p];
+    if (lc && t.has_hess) std::copy(t.lc.begin(), t.lc.end(), lc);
+    return t.Kc;
+}
+
+void adr_free_curve(adr_curve* curve) {
+    if (!curve) return;
+    if (curve->ctx) hipSetDevice(curve->ctx->device);
+    for (void* p : curve->allocations) hipFree(p);
+    delete curve;
+}
+
+int adr_curve_pillars(const adr_curve* curve) { return curve ? curve->dev.P : 0; }
+
+int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double* times, const double* dfs,
+                     const double* jac, const double* hess, adr_curve** out) {
+    if (!ctx || !out) return fail(ADR_ERR_INVALID, "adr_curve_upload: null ctx/out");
+    *out = nullptr;
+    if (interp_method != ADR_INTERP_FLAT_FWD_RATES && interp_method != ADR_INTERP_LINEAR_ZERO_RATES)
+        return fail(ADR_ERR_UNSUPPORTED,
+                    "adr_curve_upload: only FLAT_FWD_RATES (1) and LINEAR_ZERO_RATES (4) are implemented");
+    if (P > ADR_MAX_PILLARS)
+        return fail(ADR_ERR_UNSUPPORTED, "adr_curve_upload: more than ADR_MAX_PILLARS pillars");
+    adr::CurveTables t;
+    const std::string err = adr::build_curve_tables(K, P, times, dfs, jac, hess, t);
+    if (!err.empty()) return fail(ADR_ERR_INVALID, "adr_curve_upload: " + err);
+
+    const size_t lds = adr::price_kernel_lds_bytes(t.K, t.Kc);
+    if (lds > 160 * 1024)
+        return fail(ADR_ERR_UNSUPPORTED, "adr_curve_upload: curve tables exceed the 160 KiB LDS of a CU");
+
+    ADR_HIP(hipSetDevice(ctx->device));
+    adr_curve* c = new (std::nothrow) adr_curve();
+    if (!c) return fail(ADR_ERR_NOMEM, "adr_curve_upload: out of memory");
+    c->ctx = ctx;
+    std::vector<int16_t> first16(t.first_of.begin(), t.first_of.end());
+    std::vector<int16_t> comp16(t.compact_of.begin(), t.compact_of.end());
+    double *d_x = nullptr, *d_log = nullptr, *d_invx = nullptr, *d_lj = nullptr, *d_lc = nullptr;
+    int16_t *d_first = nullptr, *d_comp = nullptr;
+    hipError_t e = hipSuccess;
+    auto track = [&](hipError_t r, void* p) { if (p) c->allocations.push_back(p); if (e == hipSuccess) e = r; };
+    track(upload(t.x, &d_x), d_x);
+    track(upload(t.log_df, &d_log), d_log);
+    track(upload(t.inv_x, &d_invx), d_invx);
+    track(upload(t.lj, &d_lj), d_lj);
+    track(upload(t.lc_lanes, &d_lc), d_lc);
+    track(upload(first16, &d_first), d_first);
+    track(upload(comp16, &d_comp), d_comp);
+    if (e != hipSuccess) { adr_free_curve(c); return fail_hip(e, "adr_curve_upload: copying tables"); }
+    c->dev.K = t.K; c->dev.Kc = t.Kc; c->dev.P = t.P; c->dev.method = interp_method;
+    c->dev.x = d_x; c->dev.log_df = d_log; c->dev.inv_x = d_invx; c->dev.lj = d_lj; c->dev.lc_lanes = d_lc;
+    c->dev.first_of = d_first; c->dev.compact_of = d_comp;
+    if (lds > 48 * 1024) {
+        e = adr::set_price_kernel_lds_limit(lds);
+        if (e != hipSuccess) { adr_free_curve(c); return fail_hip(e, "hipFuncSetAttribute(LDS)"); }
+    }
+    *out = c;
+    return ADR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ trades
+void adr_free_trades(adr_trades* t) {
+    if (!t) return;
+    if (t->ctx) hipSetDevice(t->ctx->device);
+    for (void* p : t->allocations) hipFree(p);
+    delete t;
+}
+
+int64_t adr_trades_count(const adr_trades* t) { return t ? t->dev.n : 0; }
+
+int64_t adr_trades_input_bytes(const adr_trades* t) {
+    if (!t) return 0;
+    return 16 * t->n_fix_flows + 32 * t->n_flt_flows + 40 * t->dev.n;
+}
+
+int adr_trades_upload(adr_ctx* ctx, int64_t n, const int64_t* fix_off, const int64_t* flt_off, const double* fix_tp,
+                      const double* fix_pay, const double* flt_tp, const double* flt_ts, const double* flt_te,
+                      const double* flt_alpha, const double* notional, const double* spread, const double* fix_sign,
+                      const double* flt_sign, adr_trades** out) {
+    if (!ctx || !out) return fail(ADR_ERR_INVALID, "adr_trades_upload: null ctx/out");
+    *out = nullptr;
+    if (n < 0) return fail(ADR_ERR_INVALID, "adr_trades_upload: negative trade count");
+    if (n > 0 && (!fix_off || !flt_off || !notional || !spread || !fix_sign || !flt_sign))
+        return fail(ADR_ERR_INVALID, "adr_trades_upload: null per-trade array");
+    const int64_t n_fix = n ? fix_off[n] : 0, n_flt = n ? flt_off[n] : 0;
+    if (n > 0 && (fix_off[0] != 0 || flt_off[0] != 0))
+        return fail(ADR_ERR_INVALID, "adr_trades_upload: offsets must start at 0");
+    if (n_fix > INT32_MAX || n_flt > INT32_MAX)
+        return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^31 cash flows in one batch; shard the portfolio");
+    if ((n_fix > 0 && (!fix_tp || !fix_pay)) || (n_flt > 0 && (!flt_tp || !flt_ts || !flt_te || !flt_alpha)))
+        return fail(ADR_ERR_INVALID, "adr_trades_upload: null cash-flow array");
+
+    std::vector<adr::TradeHeader> hdr(static_cast<size_t>(n));
+    for (int64_t t = 0; t < n; ++t) {
+        const int64_t mf = fix_off[t + 1] - fix_off[t], ml = flt_off[t + 1] - flt_off[t];
+        if (mf < 0 || ml < 0 || mf > INT16_MAX || ml > INT16_MAX)
+            return fail(ADR_ERR_INVALID, "adr_trades_upload: offsets must be non-decreasing, <= 32767 flows per leg");
+        if (!(fix_sign[t] == 1.0 || fix_sign[t] == -1.0) || !(flt_sign[t] == 1.0 || flt_sign[t] == -1.0))
+            return fail(ADR_ERR_INVALID, "adr_trades_upload: leg signs must be +1 or -1");
+        adr::TradeHeader& h = hdr[static_cast<size_t>(t)];
+        h.notional = notional[t];
+        h.spread = spread[t];
+        h.flt_begin = static_cast<int32_t>(flt_off[t]);
+        h.fix_begin = static_cast<int32_t>(fix_off[t]);
+        h.n_flt = static_cast<int16_t>(ml);
+        h.n_fix = static_cast<int16_t>(mf);
+        h.fix_sign = static_cast<int8_t>(fix_sign[t]);
+        h.flt_sign = static_cast<int8_t>(flt_sign[t]);
+        h.pad = 0;
+    }
+
+    ADR_HIP(hipSetDevice(ctx->device));
+    adr_trades* tr = new (std::nothrow) adr_trades();
+    if (!tr) return fail(ADR_ERR_NOMEM, "adr_trades_upload: out of memory");
+    tr->ctx = ctx;
+    tr->n_fix_flows = n_fix;
+    tr->n_flt_flows = n_flt;
+    hipError_t e = hipSuccess;
+    auto put = [&](const void* src, size_t bytes) -> void* {
+        if (bytes == 0 || e != hipSuccess) return nullptr;
+        // over-allocate one header's worth so that the kernels' neighbour reads never leave the buffer
+        void* p = nullptr;
+        e = hipMalloc(&p, bytes + 64);
+        if (e != hipSuccess) return nullptr;
+        tr->allocations.push_back(p);
+        e = hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+        return p;
+    };
+    tr->dev.n = n;
+    tr->dev.header = static_cast<const adr::TradeHeader*>(put(hdr.data(), hdr.size() * sizeof(adr::TradeHeader)));
+    tr->dev.fix_tp = static_cast<const double*>(put(fix_tp, n_fix * sizeof(double)));
+    tr->dev.fix_pay = static_cast<const double*>(put(fix_pay, n_fix * sizeof(double)));
+    tr->dev.flt_tp = static_cast<const double*>(put(flt_tp, n_flt * sizeof(double)));
+    tr->dev.flt_ts = static_cast<const double*>(put(flt_ts, n_flt * sizeof(double)));
+    tr->dev.flt_te = static_cast<const double*>(put(flt_te, n_flt * sizeof(double)));
+    tr->dev.flt_alpha = static_cast<const double*>(put(flt_alpha, n_flt * sizeof(double)));
+    if (e != hipSuccess) { adr_free_trades(tr); return fail_hip(e, "adr_trades_upload: copying trades"); }
+    *out = tr;
+    return ADR_OK;
+}
+
+// ------------------------------------------------------------------------------------------- price
+int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades, uint32_t req_mask, double* pv_dev,
+                  double* delta_dev, double* gamma_dev, double* agg_dev, void* stream_v) {
+    if (!ctx || !curve || !trades) return fail(ADR_ERR_INVALID, "adr_price: null ctx/curve/trades");
+    if (curve->ctx != ctx || trades->ctx != ctx)
+        return fail(ADR_ERR_INVALID, "adr_price: curve/trades were uploaded through another ctx");
+    const bool want_gamma = (req_mask & ADR_REQ_GAMMA) != 0;
+    const bool want_delta = want_gamma || (req_mask & ADR_REQ_DELTA) != 0;
+    if (want_gamma && !curve->dev.lc_lanes)
+        return fail(ADR_ERR_INVALID, "adr_price: GAMMA requested but the curve was uploaded without hess");
+    hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
+    const int P = curve->dev.P;
+    const int64_t n = trades->dev.n;
+
+    ADR_HIP(hipSetDevice(ctx->device));
+    if (n == 0) {   // empty portfolio: the aggregate is all zeros, nothing else to write
+        if (agg_dev) ADR_HIP(hipMemsetAsync(agg_dev, 0, sizeof(double) * (1 + P + static_cast<size_t>(P) * P), stream));
+        return ADR_OK;
+    }
+
+    // one wavefront per trade, 4 per block; enough blocks to fill the chip, grid-stride over the rest
+    const int64_t blocks_needed = (n + (adr::kBlockThreads / 64) - 1) / (adr::kBlockThreads / 64);
+    const int per_cu = want_gamma ? 4 : 8;
+    const int n_blocks = static_cast<int>(std::min<int64_t>(blocks_needed,
+                                                            std::min(ctx->max_blocks, ctx->n_cu * per_cu)));
+    adr::OutputsDev o;
+    o.pv = (req_mask & ADR_REQ_VALUE) ? pv_dev : nullptr;
+    o.delta = (req_mask & ADR_REQ_DELTA) ? delta_dev : nullptr;
+    o.gamma = want_gamma ? gamma_dev : nullptr;
+    o.block_partials = agg_dev ? ctx->partials : nullptr;
+    ADR_HIP(adr::launch_price(curve->dev, trades->dev, o, want_delta, want_gamma, n_blocks, stream));
+    if (agg_dev) ADR_HIP(adr::launch_reduce_partials(ctx->partials, n_blocks, P, agg_dev, stream));
+    return ADR_OK;
+}
+
+int adr_price(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades, uint32_t req_mask, double* pv,
+              double* delta, double* gamma, double* agg) {
+    if (!ctx || !curve || !trades) return fail(ADR_ERR_INVALID, "adr_price: null ctx/curve/trades");
+    const int P = curve->dev.P;
+    const size_t n = static_cast<size_t>(trades->dev.n);
+    const size_t n_agg = 1 + P + static_cast<size_t>(P) * P;
+    ADR_HIP(hipSetDevice(ctx->device));
+    double *d_pv = nullptr, *d_delta = nullptr, *d_gamma = nullptr, *d_agg = nullptr;
+    int rc = ADR_OK;
+    hipError_t e = hipSuccess;
+    auto cleanup = [&]() { hipFree(d_pv); hipFree(d_delta); hipFree(d_gamma); hipFree(d_agg); };
+    if (pv && (req_mask & ADR_REQ_VALUE) && n) e = hipMalloc(reinterpret_cast<void**>(&d_pv), n * sizeof(double));
+    if (e == hipSuccess && delta && (req_mask & ADR_REQ_DELTA) && n)
+        e = hipMalloc(reinterpret_cast<void**>(&d_delta), n * P * sizeof(double));
+    if (e == hipSuccess && gamma && (req_mask & ADR_REQ_GAMMA) && n)
+        e = hipMalloc(reinterpret_cast<void**>(&d_gamma), n * P * P * sizeof(double));
+    if (e == hipSuccess && agg) e = hipMalloc(reinterpret_cast<void**>(&d_agg), n_agg * sizeof(double));
+    if (e != hipSuccess) { cleanup(); return fail_hip(e, "adr_price: allocating outputs"); }
+    rc = adr_price_dev(ctx, curve, trades, req_mask, d_pv, d_delta, d_gamma, d_agg, nullptr);
+    if (rc != ADR_OK) { cleanup(); return rc; }
+    e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && d_pv) e = hipMemcpy(pv, d_pv, n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && d_delta) e = hipMemcpy(delta, d_delta, n * P * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && d_gamma) e = hipMemcpy(gamma, d_gamma, n * P * P * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && d_agg) e = hipMemcpy(agg, d_agg, n_agg * sizeof(double), hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail_hip(e, "adr_price: running kernels / copying results");
+    return ADR_OK;
+}
+
+// ---------------------------------------------------------------------------------------- multi-GPU
+int adr_allreduce_agg(adr_ctx* ctx, void* rccl_comm, double* agg_dev, int count, void* stream_v) {
+    if (!ctx || !rccl_comm || !agg_dev || count <= 0) return fail(ADR_ERR_INVALID, "adr_allreduce_agg: bad argument");
+    hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
+    ncclResult_t r = ncclAllReduce(agg_dev, agg_dev, static_cast<size_t>(count), ncclDouble, ncclSum,
+                                   static_cast<ncclComm_t>(rccl_comm), stream);
+    if (r != ncclSuccess) return fail(ADR_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    return ADR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,452 @@
+// CDNA4 (gfx950) kernels: PV, pillar delta ladder and pillar x pillar gamma of OIS trades.
+//
+// What is computed (reference: cavour/market/position/engine.py:2414-2448 fixed leg, :2639-2728 float
+// leg, :2541-2576 / :2899-2934 Greeks assembly; curve lookups: cavour/market/curves/
+// interpolator_ad.py:186-249):
+//
+//   PV      = s_f * sum_j pay_j D(tp_j) [tp_j > 0]
+//           + s_l * sum_j N ((D(ts_j)/D(te_j) - 1)/a_j + spread) a_j D(tp_j) [tp_j >= 0]
+//   delta_p = 1e-4 dPV/dr_p,   gamma_pq = 1e-8 d2PV/dr_p dr_q
+//
+// Every discount factor is D(t) = exp(ba*L[ka] + bb*L[kb]) with L = ln(knot DF) and (ka, kb) the knots
+// bracketing t (or a single snapped knot), so every PV term is w = c*exp(sum_i b_i L[k_i]) and
+//   dPV/dr   = sum_terms w * v,              v = sum_i b_i LJ[k_i]
+//   d2PV/dr2 = sum_terms w * (v v^T + sum_i b_i LC[k_i])
+// (hand-rolled reverse sweep for v / delta, forward-over-reverse for gamma).
+//
+// Terms that share a time share D and v, so before any exponential is taken the cash flows of a trade
+// are folded into "nodes" (time, coefficient): with no payment lag (te == tp) a float coupon is
+// N*(D(ts) - (1 - spread*a) D(tp)), its start node coincides with the previous coupon's payment node,
+// and the fixed coupon on the same date adds to the same node.  A standard OIS with M coupons becomes
+// M + 1 nodes instead of 4M discount factors.  Coupons with te != tp stay ratio terms (3 times, 6 knots).
+//
+// Mapping: one 64-lane wavefront per trade.  Lanes = cash flows while nodes are built (coalesced loads
+// of the trade's arrays, binary search of the knot times in LDS, exp); then lanes = pillars for delta
+// and lane = one 4x4 block of the 32x32 gamma; node data is broadcast with v_readlane.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace adr {
+
+namespace {
+
+constexpr int kWavesPerBlock = kBlockThreads / 64;
+
+__device__ __forceinline__ int readlane_i(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
+
+__device__ __forceinline__ double readlane_d(double x, int lane) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+// Curve tables staged in LDS, shared by the block's waves.
+struct CurveLds {
+    const double* x;        // [K]
+    const double* log_df;   // [Kc]
+    const double* inv_x;    // [Kc]
+    const double* lj;       // [Kc][32]
+    const int16_t* first_of;    // [K]
+    const int16_t* compact_of;  // [K]
+    int K;
+    int method;
+};
+
+// One discount-factor lookup: D(t) = exp(ba*L[ka] + bb*L[kb]); ka/kb are rows of the compact tables.
+struct Lookup {
+    int ka, kb;
+    double ba, bb;
+};
+
+// InterpolatorAd.simple_interpolate for one time (interpolator_ad.py:210-243) in weight form.
+__device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
+    const int K = c.K;
+    // j = first knot with x > t
+    int lo = 0, hi = K;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c.x[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    const int j = lo;
+    // nearest knot; the first of equal candidates wins, the lower one on a distance tie (argmin)
+    double best_dist = 1e300;
+    int best = 0;
+    if (j > 0) { best = c.first_of[j - 1]; best_dist = fabs(t - c.x[j - 1]); }
+    if (j < K) {
+        const double dh = fabs(t - c.x[j]);
+        if (dh < best_dist) { best_dist = dh; best = j; }
+    }
+    Lookup r;
+    if (best_dist < 1e-10) {            // exact grid point: that knot's DF, gradient to that knot only
+        r.ka = c.compact_of[best]; r.kb = 0; r.ba = 1.0; r.bb = 0.0;
+        return r;
+    }
+    const double tau = t + 1e-12;
+    const bool lzr = c.method == 4;
+    if (tau < c.x[0] || tau > c.x[K - 1]) {   // jnp.interp is constant outside the knot range
+        const int k = tau < c.x[0] ? 0 : K - 1;
+        r.ka = c.compact_of[k]; r.kb = 0; r.bb = 0.0;
+        r.ba = lzr ? t * c.inv_x[r.ka] : 1.0;
+        return r;
+    }
+    // no knot lies in (t, t + 1e-12] (it would have snapped), so searchsorted(tau, 'right') == j
+    const int i = min(max(j, 1), K - 1);
+    const double xa = c.x[i - 1], xb = c.x[i];
+    const double dx = xb - xa;
+    // jnp.interp returns fp[i-1] when |dx| <= spacing(eps) = 2^-104
+    const double w = (fabs(dx) <= 0x1p-104) ? 0.0 : (tau - xa) / dx;
+    r.ka = c.compact_of[i - 1];
+    r.kb = c.compact_of[i];
+    if (lzr) {
+        r.ba = t * (1.0 - w) * c.inv_x[r.ka];
+        r.bb = t * w * c.inv_x[r.kb];
+    } else {
+        r.ba = 1.0 - w;
+        r.bb = w;
+    }
+    return r;
+}
+
+// Per-wave accumulators of one trade (and, separately, of the wave's running portfolio sums).
+template <bool GAMMA>
+struct Ladders {
+    double pv;                 // lane-partial, reduced at the end of the trade
+    double delta;              // lane p (and p + 32, duplicated) holds pillar p
+    double gamma[GAMMA ? kGammaPerLane : 1];
+    __device__ void clear() {
+        pv = 0.0; delta = 0.0;
+#pragma unroll
+        for (int e = 0; e < (GAMMA ? kGammaPerLane : 1); ++e) gamma[e] = 0.0;
+    }
+};
+
+// Add the nodes held by the lanes in `mask` to the trade's ladders.  A node is NK (knot, weight) pairs
+// and a coefficient*exp() value `omega`; NK is 2 for plain nodes and 6 for ratio nodes.
+template <int NK, bool DELTA, bool GAMMA>
+__device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k)[NK], const double (&b)[NK],
+                                          double omega, const CurveLds& c, const double* __restrict__ lc_lanes,
+                                          double* vbuf, int lane, Ladders<GAMMA>& acc) {
+    const int p = lane & 31;
+    const int bi = lane >> 3, bj = lane & 7;
+    while (mask) {
+        const int n = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const double om = readlane_d(omega, n);
+        int kk[NK];
+        double bb[NK];
+#pragma unroll
+        for (int i = 0; i < NK; ++i) { kk[i] = readlane_i(k[i], n); bb[i] = readlane_d(b[i], n); }
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) v = fma(bb[i], c.lj[kk[i] * kPillarPad + p], v);
+        if (DELTA) acc.delta = fma(om, v, acc.delta);
+        if (GAMMA) {
+            // hand v[0..31] to every lane through the wave's LDS slot (same-wave LDS ops are ordered)
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 32) vbuf[lane] = v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double vr[4], vc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { vr[i] = om * vbuf[4 * bi + i]; vc[i] = vbuf[4 * bj + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) acc.gamma[i * 4 + jx] = fma(vr[i], vc[jx], acc.gamma[i * 4 + jx]);
+            // curve-convexity part: sum_i om*b_i * LC[k_i]
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const double coef = om * bb[i];
+                if (coef != 0.0) {
+                    const double2* tile = reinterpret_cast<const double2*>(
+                        lc_lanes + (static_cast<size_t>(kk[i]) * 64 + lane) * kGammaPerLane);
+#pragma unroll
+                    for (int e = 0; e < kGammaPerLane / 2; ++e) {
+                        const double2 tv = tile[e];
+                        acc.gamma[2 * e] = fma(coef, tv.x, acc.gamma[2 * e]);
+                        acc.gamma[2 * e + 1] = fma(coef, tv.y, acc.gamma[2 * e + 1]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <bool DELTA, bool GAMMA>
+__global__ __launch_bounds__(kBlockThreads) void price_trades_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    // LDS carve-up: doubles first (16-byte aligned base), then the int16 index tables
+    double* s_x = reinterpret_cast<double*>(smem_raw);
+    double* s_log = s_x + cv.K;
+    double* s_invx = s_log + cv.Kc;
+    double* s_lj = s_invx + cv.Kc;
+    double* s_vbuf = s_lj + static_cast<size_t>(cv.Kc) * kPillarPad;
+    int16_t* s_first = reinterpret_cast<int16_t*>(s_vbuf + kWavesPerBlock * kPillarPad);
+    int16_t* s_comp = s_first + cv.K;
+
+    for (int i = threadIdx.x; i < cv.K; i += kBlockThreads) {
+        s_x[i] = cv.x[i];
+        s_first[i] = cv.first_of[i];
+        s_comp[i] = cv.compact_of[i];
+    }
+    for (int i = threadIdx.x; i < cv.Kc; i += kBlockThreads) {
+        s_log[i] = cv.log_df[i];
+        s_invx[i] = cv.inv_x[i];
+    }
+    for (int i = threadIdx.x; i < cv.Kc * kPillarPad; i += kBlockThreads) s_lj[i] = cv.lj[i];
+    __syncthreads();
+
+    CurveLds c;
+    c.x = s_x; c.log_df = s_log; c.inv_x = s_invx; c.lj = s_lj;
+    c.first_of = s_first; c.compact_of = s_comp; c.K = cv.K; c.method = cv.method;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar loads of the header
+    double* vbuf = s_vbuf + wave * kPillarPad;
+    const int P = cv.P;
+    const double* __restrict__ lc_lanes = cv.lc_lanes;
+
+    Ladders<GAMMA> total;   // this wave's share of the portfolio aggregate
+    total.clear();
+
+    const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+    for (int64_t t = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; t < tr.n; t += wave_stride) {
+        const TradeHeader h = tr.header[t];
+        const double N = h.notional, spread = h.spread;
+        const double sl = static_cast<double>(h.flt_sign), sf = static_cast<double>(h.fix_sign);
+        const int n_flt = h.n_flt, n_fix = h.n_fix;
+        const double* f_tp = tr.flt_tp + h.flt_begin;
+        const double* f_ts = tr.flt_ts + h.flt_begin;
+        const double* f_te = tr.flt_te + h.flt_begin;
+        const double* f_al = tr.flt_alpha + h.flt_begin;
+        const double* x_tp = tr.fix_tp + h.fix_begin;
+        const double* x_pay = tr.fix_pay + h.fix_begin;
+
+        Ladders<GAMMA> acc;
+        acc.clear();
+
+        // ---------------------------------------------------------------- float coupons (+ merged fixed)
+        for (int base = 0; base < n_flt; base += 64) {
+            const int j = base + lane;
+            const bool in = j < n_flt;
+            double tp = 0.0, ts = 0.0, te = 0.0, al = 0.0;
+            if (in) { tp = f_tp[j]; ts = f_ts[j]; te = f_te[j]; al = f_al[j]; }
+            const bool valid = in && tp >= 0.0;
+            const bool accrues = al > 0.0;
+            const bool linear = accrues && te == tp;      // D(ts)/D(te)*D(tp) collapses to D(ts)
+            const bool ratio = accrues && te != tp;
+
+            // payment node P_j: -N(1 - spread*a) D(tp) (or N*spread*a*D(tp) when nothing accrues)
+            double a_pay = valid ? sl * N * (spread * al - (accrues ? 1.0 : 0.0)) : 0.0;
+            // next coupon's start node lands here when its accrual starts on this payment time
+            if (in && j + 1 < n_flt) {
+                const double ntp = f_tp[j + 1], nts = f_ts[j + 1], nte = f_te[j + 1], nal = f_al[j + 1];
+                if (nal > 0.0 && nte == ntp && ntp >= 0.0 && nts == tp) a_pay += sl * N;
+            }
+            // the fixed coupon paid at the same time joins the node
+            if (in && j < n_fix) {
+                const double xtp = x_tp[j];
+                if (xtp == tp && xtp > 0.0) a_pay = fma(sf, x_pay[j], a_pay);
+            }
+            // own start node S_j unless it coincides with the previous payment node
+            bool own_start = valid && linear;
+            if (own_start && j > 0 && f_tp[j - 1] == ts) own_start = false;
+
+            {   // payment nodes
+                int k[2]; double b[2]; double omega = 0.0;
+                const bool on = in && a_pay != 0.0;
+                k[0] = k[1] = 0; b[0] = b[1] = 0.0;
+                if (on) {
+                    const Lookup q = curve_lookup(c, tp);
+                    k[0] = q.ka; k[1] = q.kb; b[0] = q.ba; b[1] = q.bb;
+                    omega = a_pay * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
+                    acc.pv += omega;
+                }
+                add_nodes<2, DELTA, GAMMA>(__ballot(on), k, b, omega, c, lc_lanes, vbuf, lane, acc);
+            }
+            {   // unmerged start nodes
+                int k[2]; double b[2]; double omega = 0.0;
+                k[0] = k[1] = 0; b[0] = b[1] = 0.0;
+                if (own_start) {
+                    const Lookup q = curve_lookup(c, ts);
+                    k[0] = q.ka; k[1] = q.kb; b[0] = q.ba; b[1] = q.bb;
+                    omega = sl * N * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
+                    acc.pv += omega;
+                }
+                add_nodes<2, DELTA, GAMMA>(__ballot(own_start), k, b, omega, c, lc_lanes, vbuf, lane, acc);
+            }
+            const bool own_ratio = valid && ratio;
+            if (__ballot(own_ratio)) {   // payment lag: N D(ts) D(tp) / D(te) keeps all three lookups
+                int k[6]; double b[6]; double omega = 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { k[i] = 0; b[i] = 0.0; }
+                if (own_ratio) {
+                    const Lookup qs = curve_lookup(c, ts), qe = curve_lookup(c, te), qp = curve_lookup(c, tp);
+                    k[0] = qs.ka; k[1] = qs.kb; b[0] = qs.ba; b[1] = qs.bb;
+                    k[2] = qe.ka; k[3] = qe.kb; b[2] = -qe.ba; b[3] = -qe.bb;
+                    k[4] = qp.ka; k[5] = qp.kb; b[4] = qp.ba; b[5] = qp.bb;
+                    double l = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) l = fma(b[i], c.log_df[k[i]], l);
+                    omega = sl * N * exp(l);
+                    acc.pv += omega;
+                }
+                add_nodes<6, DELTA, GAMMA>(__ballot(own_ratio), k, b, omega, c, lc_lanes, vbuf, lane, acc);
+            }
+        }
+        // ---------------------------------------------------------------- fixed coupons not merged above
+        for (int base = 0; base < n_fix; base += 64) {
+            const int j = base + lane;
+            bool on = false;
+            double tp = 0.0, a = 0.0;
+            if (j < n_fix) {
+                tp = x_tp[j];
+                const bool merged = j < n_flt && f_tp[j] == tp;
+                on = !merged && tp > 0.0;
+                if (on) a = sf * x_pay[j];
+                on = on && a != 0.0;
+            }
+            int k[2]; double b[2]; double omega = 0.0;
+            k[0] = k[1] = 0; b[0] = b[1] = 0.0;
+            if (on) {
+                const Lookup q = curve_lookup(c, tp);
+                k[0] = q.ka; k[1] = q.kb; b[0] = q.ba; b[1] = q.bb;
+                omega = a * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
+                acc.pv += omega;
+            }
+            add_nodes<2, DELTA, GAMMA>(__ballot(on), k, b, omega, c, lc_lanes, vbuf, lane, acc);
+        }
+
+        // ---------------------------------------------------------------- results of this trade
+        const double pv = wave_sum(acc.pv);
+        if (lane == 0) {
+            if (out.pv) out.pv[t] = pv;
+            total.pv += pv;
+        }
+        if (DELTA) {
+            const double d = acc.delta * 1e-4;
+            if (lane < P && out.delta) out.delta[t * P + lane] = d;
+            total.delta += d;
+        }
+        if (GAMMA) {
+            const int bi = lane >> 3, bj = lane & 7;
+            double* g = out.gamma ? out.gamma + t * static_cast<int64_t>(P) * P : nullptr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * bi + i;
+                double gv[4];
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    gv[jx] = acc.gamma[i * 4 + jx] * 1e-8;
+                    total.gamma[i * 4 + jx] += gv[jx];
+                }
+                if (g && r < P) {
+                    if (P == kPillarPad) {
+                        double2* dst = reinterpret_cast<double2*>(g + r * kPillarPad + 4 * bj);
+                        dst[0] = make_double2(gv[0], gv[1]);
+                        dst[1] = make_double2(gv[2], gv[3]);
+                    } else {
+#pragma unroll
+                        for (int jx = 0; jx < 4; ++jx)
+                            if (4 * bj + jx < P) g[r * P + 4 * bj + jx] = gv[jx];
+                    }
+                }
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------------ block partial of the aggregate
+    if (out.block_partials) {
+        __syncthreads();   // every wave is done with the curve tables; reuse the LDS for the reduction
+        double* red = reinterpret_cast<double*>(smem_raw);   // [waves][kAggStride]
+        double* mine = red + wave * kAggStride;
+        if (lane == 0) mine[0] = total.pv;
+        if (lane < kPillarPad) mine[1 + lane] = DELTA ? total.delta : 0.0;
+        {
+            const int bi = lane >> 3, bj = lane & 7;
+#pragma unroll
+            for (int e = 0; e < kGammaPerLane; ++e) {
+                const int r = 4 * bi + (e >> 2), q = 4 * bj + (e & 3);
+                mine[1 + kPillarPad + r * kPillarPad + q] = GAMMA ? total.gamma[GAMMA ? e : 0] : 0.0;
+            }
+        }
+        __syncthreads();
+        double* dst = out.block_partials + static_cast<size_t>(blockIdx.x) * kAggStride;
+        for (int i = threadIdx.x; i < kAggStride; i += kBlockThreads) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; ++w) s += red[w * kAggStride + i];
+            dst[i] = s;
+        }
+    }
+}
+
+// Fixed-order sum of the block partials -> agg[1 + P + P*P]; one thread per output, blocks summed in
+// index order so the aggregate does not depend on scheduling.
+__global__ void reduce_partials_kernel(const double* partials, int n_blocks, int P, double* agg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_out = 1 + P + P * P;
+    if (i >= n_out) return;
+    int src;
+    if (i == 0) src = 0;
+    else if (i < 1 + P) src = i;
+    else { const int r = (i - 1 - P) / P, q = (i - 1 - P) % P; src = 1 + kPillarPad + r * kPillarPad + q; }
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; ++b) s += partials[static_cast<size_t>(b) * kAggStride + src];
+    agg[i] = s;
+}
+
+}  // namespace
+
+size_t price_kernel_lds_bytes(int K, int Kc) {
+    size_t tables = sizeof(double) * (static_cast<size_t>(K) + 2 * Kc + static_cast<size_t>(Kc) * kPillarPad +
+                                      kWavesPerBlock * kPillarPad) + sizeof(int16_t) * 2 * static_cast<size_t>(K);
+    size_t reduce = sizeof(double) * kWavesPerBlock * kAggStride;
+    size_t need = tables > reduce ? tables : reduce;
+    return (need + 15) & ~static_cast<size_t>(15);
+}
+
+hipError_t launch_price(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
+                        bool want_gamma, int n_blocks, hipStream_t stream) {
+    const size_t lds = price_kernel_lds_bytes(cv.K, cv.Kc);
+    dim3 grid(n_blocks), block(kBlockThreads);
+    if (want_gamma) {
+        hipLaunchKernelGGL((price_trades_kernel<true, true>), grid, block, lds, stream, cv, tr, out);
+    } else if (want_delta) {
+        hipLaunchKernelGGL((price_trades_kernel<true, false>), grid, block, lds, stream, cv, tr, out);
+    } else {
+        hipLaunchKernelGGL((price_trades_kernel<false, false>), grid, block, lds, stream, cv, tr, out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_partials(const double* partials, int n_blocks, int P, double* agg, hipStream_t stream) {
+    const int n_out = 1 + P + P * P;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, partials, n_blocks,
+                       P, agg);
+    return hipGetLastError();
+}
+
+hipError_t set_price_kernel_lds_limit(size_t bytes) {
+    hipError_t e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&price_trades_kernel<true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&price_trades_kernel<true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&price_trades_kernel<false, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+}
+
+}  // namespace adr

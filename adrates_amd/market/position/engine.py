@@ -1,0 +1,116 @@
+"""Valuation engine: dispatch + the GPU pricing call.
+
+Mirrors the OIS branch of cavour/market/position/engine.py
+(`Engine.compute` :89-124, `_compute_ois` :126-151, `_compute_ois_natural`
+:153-215): fetch the index curve from the model, price fixed + float legs and
+return ``AnalyticsResult(value, risk=Delta, gamma=Gamma)``.  Where the
+reference runs JAX per leg on the CPU, this engine
+
+1. builds the engine knot grid with closed-form derivative recurrences once per
+   curve (market/curves/curve_tables.py) and uploads it (adr_curve_upload);
+2. compiles the trade(s) to arrays (trades/compiler.py, adr_trades_upload);
+3. runs the hand-written HIP kernels (adr_price).
+
+There is no CPU pricing path: without the HIP library and a GPU ``compute``
+raises `LibError`.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict
+
+import numpy as np
+
+from ... import _native
+from ...requests.results import AnalyticsResult, Delta, Gamma, Valuation
+from ...trades.compiler import compile_ois
+from ...utils.error import LibError
+from ...utils.global_types import InstrumentTypes, InterpTypes, RequestTypes, collateral_to_currency
+from ...utils.helpers import to_tenor
+from ..curves.curve_tables import build_engine_curve
+
+_SUPPORTED_INTERP = (InterpTypes.FLAT_FWD_RATES.value, InterpTypes.LINEAR_ZERO_RATES.value)
+
+
+class Engine:
+    def __init__(self, model):
+        self.model = model
+        # keyed by tuple(swap_times) like the reference (engine.py:2510); the
+        # device tables themselves are cached on the curve object, so Positions
+        # sharing a model do not re-bootstrap (position.py:55 creates one Engine
+        # per Position).
+        self._curve_cache: Dict[Any, Dict[str, Any]] = {}
+
+    # ------------------------------------------------------------------ curves
+    def _device_curve(self, ir_model):
+        key = tuple(ir_model.swap_times)
+        hit = self._curve_cache.get(key)
+        if hit is not None:
+            return hit
+        shared = getattr(ir_model, "_adr_device_curve", None)
+        if shared is None:
+            method = ir_model._interp_type.value
+            if method not in _SUPPORTED_INTERP:
+                raise LibError("Invalid interpolation scheme.")   # interpolator_ad.py:237
+            host = build_engine_curve(ir_model.swap_rates, ir_model.swap_times, ir_model.year_fracs)
+            ctx = _native.default_context()
+            dev = _native.DeviceCurve(ctx, method, host.times, host.dfs, host.jac, host.hess)
+            shared = dict(ctx=ctx, host=host, dev=dev, tenors=to_tenor(list(ir_model.swap_times)))
+            ir_model._adr_device_curve = shared
+        self._curve_cache[key] = shared
+        return shared
+
+    # ---------------------------------------------------------------- dispatch
+    def compute(self, derivative, request_list, collateral_type=None):
+        reqs = set(request_list)
+        dtype = derivative.derivative_type
+        if dtype == InstrumentTypes.OIS_SWAP:
+            return self._compute_ois(derivative, reqs, collateral_type)
+        raise LibError(f"{dtype} not yet implemented")
+
+    def _compute_ois(self, derivative, reqs, collateral_type=None):
+        collateral_ccy = (derivative._currency if collateral_type is None
+                          else collateral_to_currency(collateral_type))
+        if collateral_ccy == derivative._currency:
+            return self._compute_ois_natural(derivative, reqs)
+        raise NotImplementedError("OIS with cross-currency collateral needs the XCCY curve path "
+                                  "(SURVEY.md section 8(f) rank 1), which is not built yet")
+
+    def _compute_ois_natural(self, derivative, reqs):
+        ir_model = getattr(self.model.curves, derivative._floating_index.name)
+        res = price_batch(self, ir_model, [derivative], reqs, per_trade=True, aggregate=False)
+        return wrap_result(res, 0, reqs, ir_model_tenors=res["tenors"], currency=derivative._currency,
+                           curve_type=derivative._floating_index)
+
+
+def price_batch(engine: Engine, ir_model, derivatives, reqs, per_trade=True, aggregate=False):
+    """Compile, upload and price a list of OIS trades on ``ir_model``'s curve."""
+    cur = engine._device_curve(ir_model)
+    batch = compile_ois(derivatives, ir_model._value_dt)
+    dev_trades = _native.DeviceTrades(cur["ctx"], batch)
+    try:
+        out = _native.price(cur["ctx"], cur["dev"], dev_trades,
+                            want_value=RequestTypes.VALUE in reqs,
+                            want_delta=RequestTypes.DELTA in reqs,
+                            want_gamma=RequestTypes.GAMMA in reqs,
+                            per_trade=per_trade, aggregate=aggregate)
+    finally:
+        dev_trades.close()
+    out["tenors"] = cur["tenors"]
+    return out
+
+
+def wrap_result(res, idx, reqs, ir_model_tenors, currency, curve_type, aggregate=False):
+    """numpy outputs -> Valuation / Delta / Gamma (engine.py:2546, 2556-2561, 2569-2574)."""
+    value = delta = gamma = None
+    if RequestTypes.VALUE in reqs:
+        amount = res["agg_pv"] if aggregate else res["pv"][idx]
+        value = Valuation(amount=float(amount), currency=currency)
+    if RequestTypes.DELTA in reqs:
+        ladder = res["agg_delta"] if aggregate else res["delta"][idx]
+        delta = Delta(risk_ladder=np.array(ladder, dtype=np.float64), tenors=ir_model_tenors,
+                      currency=currency, curve_type=curve_type)
+    if RequestTypes.GAMMA in reqs:
+        mat = res["agg_gamma"] if aggregate else res["gamma"][idx]
+        gamma = Gamma(risk_ladder=np.array(mat, dtype=np.float64), tenors=ir_model_tenors,
+                      currency=currency, curve_type=curve_type)
+    return AnalyticsResult(value=value, risk=delta, gamma=gamma)

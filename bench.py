@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the OIS PV + delta + gamma path on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.
+For N > 1 it is launched under ``torch.distributed.run`` (one rank per GPU, RCCL).
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): per GPU a synthetic
+portfolio of 1,000,000 spot-starting OIS on the README 32-pillar GBP SONIA curve (SURVEY.md section 8(d):
+maturity U{1..360} months, annual ACT/365F legs with a front stub, coupon U(1%,7%), notional
+round(U(1e6,5e7),-5), pay/receive 50/50, seed 20240430 + rank); one step = PV, 32-pillar delta ladder and
+full 32x32 gamma of every trade written to HBM, plus the portfolio aggregate, all-reduced over the ranks.
+Inputs are resident in HBM before the timed region; weak scaling (per-GPU work fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--trades", type=int, default=1_000_000, help="trades per GPU")
+    ap.add_argument("--kind", default="offgrid", choices=["offgrid", "ongrid"])
+    ap.add_argument("--interp", default="LINEAR_ZERO_RATES", choices=["LINEAR_ZERO_RATES", "FLAT_FWD_RATES"])
+    ap.add_argument("--requests", default="value,delta,gamma")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0,
+                    help="approximate CPU time budget of the baseline leg (0 disables it)")
+    return ap.parse_args()
+
+
+def cpu_baseline(curve, value_dt, interp_value, want_gamma, budget_s):
+    """Time the CPU oracle (oracle/ - the build's restatement of the reference algorithm) on a bounded
+    sample of the same synthetic workload.  Reported beside the GPU number; never the target."""
+    try:
+        from oracle import port as cpu_port
+    except Exception as exc:  # the C restatement is optional test infrastructure
+        return {"value": None, "unit": "trades/s", "cores": 0, "kind": "port", "sample": f"unavailable: {exc}"}
+    return cpu_port.timed_baseline(curve, value_dt, interp_value, want_gamma, budget_s)
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from adrates_amd import _native
+    from adrates_amd.market.curves.curve_tables import build_engine_curve
+    from adrates_amd.trades import synthetic
+    from adrates_amd.utils import InterpTypes
+    from tests._fixtures import README_VALUE_DT, gbp_model
+
+    reqs = {r.strip().lower() for r in args.requests.split(",")}
+    want_gamma = "gamma" in reqs
+    want_delta = want_gamma or "delta" in reqs
+    mask = 1 | (2 if want_delta else 0) | (4 if want_gamma else 0)
+
+    interp = InterpTypes[args.interp]
+    model = gbp_model(README_VALUE_DT, interp)
+    curve = model.curves.GBP_OIS_SONIA
+    host_curve = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    P = host_curve.n_pillars
+
+    ctx = _native.Context(local_rank)
+    dev_curve = _native.DeviceCurve(ctx, interp.value, host_curve.times, host_curve.dfs, host_curve.jac,
+                                    host_curve.hess)
+    n = args.trades
+    batch = synthetic.synthesize(README_VALUE_DT, n, kind=args.kind, seed=synthetic.DEFAULT_SEED + rank)
+    dev_trades = _native.DeviceTrades(ctx, batch)
+    in_bytes = dev_trades.input_bytes
+    out_bytes = 8 * n * (1 + (P if want_delta else 0) + (P * P if want_gamma else 0))
+    curve_bytes = 16 * host_curve.n_knots + 8 * host_curve.n_knots * P * (1 + (P if want_gamma else 0))
+    algo_bytes = in_bytes + out_bytes + curve_bytes
+
+    dev = torch.device("cuda", local_rank)
+    pv = torch.empty(n, dtype=torch.float64, device=dev)
+    delta = torch.empty((n, P), dtype=torch.float64, device=dev) if want_delta else None
+    gamma = torch.empty((n, P, P), dtype=torch.float64, device=dev) if want_gamma else None
+    agg = torch.zeros(1 + P + P * P, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        _native.price_dev(ctx, dev_curve, dev_trades, mask, pv.data_ptr(),
+                          delta.data_ptr() if delta is not None else 0,
+                          gamma.data_ptr() if gamma is not None else 0, agg.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.all_reduce(agg)   # the one exchange step: 1 + P + P*P doubles over RCCL/xGMI
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+
+    # kernel-only time from HIP events on the launch stream (one pair per step, around the pricing call)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        _native.price_dev(ctx, dev_curve, dev_trades, mask, pv.data_ptr(),
+                          delta.data_ptr() if delta is not None else 0,
+                          gamma.data_ptr() if gamma is not None else 0, agg.data_ptr(), stream.cuda_stream)
+        b.record(stream)
+        if world > 1:
+            dist.all_reduce(agg)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * n * args.steps / elapsed
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "OIS trades/sec PV+delta+gamma, 32-pillar curve; achieved HBM GB/s",
+            "value": value, "unit": "trades/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n} random-tenor OIS per GPU ({args.kind}), PV + {P}-pillar delta"
+                                   + (f" + full {P}x{P} gamma" if want_gamma else "")
+                                   + f", {args.interp}, README GBP SONIA curve (BASELINE configs[2])",
+                       "trades_per_gpu": n, "pillars": P, "knots": host_curve.n_knots,
+                       "requests": sorted(reqs), "parallelism": f"trade-axis shard x{world}, RCCL all-reduce of "
+                                                               f"{1 + P + P * P} doubles"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                         "algorithmic_bytes_per_trade": algo_bytes / n},
+        }
+        if args.cpu_baseline_seconds > 0 and world == 1:
+            line["cpu_baseline"] = cpu_baseline(curve, README_VALUE_DT, interp.value, want_gamma,
+                                                args.cpu_baseline_seconds)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

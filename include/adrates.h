@@ -1,0 +1,160 @@
+/*
+ * adrates.h - C-ABI of the MI355X-native OIS PV / delta / gamma path.
+ *
+ * The reference (ludcode/ADRates, "Cavour") is pure Python + JAX and has no FFI
+ * of its own; the boundary this library replaces is the internal pure-function
+ * seam of its valuation engine:
+ *
+ *   curve cache dict {times, dfs, jac, hess}   cavour/market/position/engine.py:2362-2412
+ *   _price_fixed_leg_jax(dfs, times, interp, payment_times, payments, ...)     :2414-2448
+ *   _float_leg_jax(dfs, times, interp, payment_times, start_times, end_times,
+ *                  pay_alphas, spreads, notionals, ...)                         :2639-2728
+ *   grad / hessian + chain rule to the pillar ladders                 :2541-2576, 2899-2934
+ *   Portfolio.compute's running sums            cavour/market/portfolio/portfolio.py:39-66
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative adr_status; the message
+ *     for the calling thread's last failure is adr_last_error();
+ *   - all arithmetic is IEEE float64; indices are int32/int64;
+ *   - plain pointers and sizes only; "host" pointers are ordinary process memory,
+ *     "_dev" pointers are HIP device memory of the ctx's GPU (e.g. a torch tensor's
+ *     data_ptr);
+ *   - a ctx is bound to one GPU and is not thread-safe; use one ctx per GPU/process;
+ *   - there is no CPU fallback: adr_init fails when no HIP device is usable.
+ */
+#ifndef ADRATES_H
+#define ADRATES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct adr_ctx adr_ctx;
+typedef struct adr_curve adr_curve;
+typedef struct adr_trades adr_trades;
+
+typedef enum adr_status {
+    ADR_OK = 0,
+    ADR_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, unsorted times ...) */
+    ADR_ERR_UNSUPPORTED = -2, /* interpolation method / pillar count outside what the kernels implement */
+    ADR_ERR_HIP = -3,         /* a HIP runtime call failed; text has hipGetErrorString */
+    ADR_ERR_NOMEM = -4,
+    ADR_ERR_RCCL = -5
+} adr_status;
+
+/* Interpolation methods: values of the reference's InterpTypes enum
+ * (cavour/utils/global_types.py:76-84) accepted by simple_interpolate
+ * (cavour/market/curves/interpolator_ad.py:227-235). */
+#define ADR_INTERP_FLAT_FWD_RATES 1
+#define ADR_INTERP_LINEAR_ZERO_RATES 4
+
+/* Request mask bits: RequestTypes.VALUE / DELTA / GAMMA (cavour/utils/global_types.py:69-74). */
+#define ADR_REQ_VALUE 1u
+#define ADR_REQ_DELTA 2u
+#define ADR_REQ_GAMMA 4u
+
+/* Largest pillar count the kernels are built for (the ladders are padded to it on chip). */
+#define ADR_MAX_PILLARS 32
+
+int adr_version(void);
+const char* adr_last_error(void);
+
+/* One context per GPU: selects the device, creates the library's own stream and scratch. */
+int adr_init(int device_ordinal, adr_ctx** out);
+void adr_free_ctx(adr_ctx* ctx);
+/* Number of HIP devices visible to the process (0 when none; never fails). */
+int adr_device_count(void);
+
+/*
+ * Curve tables, replacing the reference's per-Engine cache dict
+ * (engine.py:2405-2411): knot times [K] (non-decreasing, duplicates allowed and
+ * meaningful), knot discount factors [K], jac = d dfs / d par-rates [K*P]
+ * row-major, hess = d2 dfs / d par-rates2 [K*P*P] row-major (may be NULL when
+ * gamma will never be requested).  The library converts them to log space,
+ * keeps only the knots a query can reference and uploads them.
+ */
+int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P,
+                     const double* times, const double* dfs,
+                     const double* jac, const double* hess,
+                     adr_curve** out);
+void adr_free_curve(adr_curve* curve);
+int adr_curve_pillars(const adr_curve* curve);
+
+/*
+ * Host-side half of adr_curve_upload, exposed so the table construction can be
+ * checked without a GPU: writes, for the Kc knots a query can reach,
+ *   knot_index[Kc]  index into the caller's K knots,
+ *   log_df[Kc]      ln dfs,
+ *   lj[Kc*P]        d ln df_k / d r_p,
+ *   lc[Kc*P*P]      d2 ln df_k / d r_p d r_q   (skipped when hess or lc is NULL).
+ * Call with all outputs NULL to get Kc.  Returns Kc (>= 0) or a negative status.
+ */
+int adr_curve_tables_host(int K, int P, const double* times, const double* dfs,
+                          const double* jac, const double* hess,
+                          int32_t* knot_index, double* log_df, double* lj, double* lc);
+
+/*
+ * A batch of OIS trades in CSR form - the per-trade arrays the reference engine
+ * extracts from the leg objects (engine.py:2519-2527 fixed, :2858-2877 float):
+ *   fix_off/flt_off [n+1]  offsets into the cash-flow arrays (fix_off[0] = flt_off[0] = 0)
+ *   fix_tp, fix_pay        fixed payment times (years from the value date) and amounts
+ *   flt_tp/ts/te/alpha     float payment, accrual-start, accrual-end times and accrual fractions
+ *   notional, spread       per trade (float-leg notional and spread)
+ *   fix_sign, flt_sign     +1 receive / -1 pay, per trade
+ * Value time is 0 and both principals are 0, as for every OIS the reference builds
+ * (cavour/trades/rates/ois.py:149, swap_float_leg.py:106).
+ */
+int adr_trades_upload(adr_ctx* ctx, int64_t n_trades,
+                      const int64_t* fix_off, const int64_t* flt_off,
+                      const double* fix_tp, const double* fix_pay,
+                      const double* flt_tp, const double* flt_ts,
+                      const double* flt_te, const double* flt_alpha,
+                      const double* notional, const double* spread,
+                      const double* fix_sign, const double* flt_sign,
+                      adr_trades** out);
+void adr_free_trades(adr_trades* trades);
+int64_t adr_trades_count(const adr_trades* trades);
+/* Bytes of trade input one pricing pass has to read (SURVEY.md section 8(d):
+ * 16 per fixed flow + 32 per float flow + 40 per trade). */
+int64_t adr_trades_input_bytes(const adr_trades* trades);
+
+/*
+ * Price the batch: per-trade PV [n], delta ladder [n*P] and gamma [n*P*P]
+ * (row-major, full symmetric matrix), units as the reference: delta per 1 bp
+ * (x1e-4), gamma per bp^2 (x1e-8).  Any output may be NULL; req_mask says what
+ * to compute.  agg (optional) receives the portfolio sums laid out as
+ * [pv, delta[P], gamma[P*P]] = 1 + P + P*P doubles - what Portfolio.compute
+ * returns.  Blocks until the results are in the (host) buffers.
+ */
+int adr_price(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades,
+              uint32_t req_mask,
+              double* pv, double* delta, double* gamma, double* agg);
+
+/*
+ * Same, with device-resident outputs and no host synchronisation: the kernels
+ * are enqueued on `stream` (a hipStream_t; NULL = the ctx's own stream) and the
+ * call returns immediately.  Output pointers are device memory owned by the
+ * caller.  This is the entry the throughput benchmark times.
+ */
+int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades,
+                  uint32_t req_mask,
+                  double* pv_dev, double* delta_dev, double* gamma_dev, double* agg_dev,
+                  void* stream);
+
+/* Wait for everything enqueued on the ctx's own stream. */
+int adr_sync(adr_ctx* ctx);
+
+/*
+ * Sum the aggregate ladder over the ranks of an RCCL communicator (one rank per
+ * GPU): in-place ncclAllReduce(sum, double) of `count` doubles at agg_dev on
+ * `stream`.  `rccl_comm` is an ncclComm_t.  This is the only exchange step of
+ * the multi-GPU path; per-trade results never leave their GPU.
+ */
+int adr_allreduce_agg(adr_ctx* ctx, void* rccl_comm, double* agg_dev, int count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADRATES_H */
