@@ -1,0 +1,55 @@
+"""Multi-GPU layout of the pricing path: shard the trade axis, reduce the aggregate once.
+
+Trades are independent given the (tiny, replicated) curve tables, so each rank prices a contiguous
+block of the trade axis chosen to balance *cash flows* (work is proportional to coupons, not trades;
+SURVEY.md section 8(e)).  The only exchange is the aggregate ladder
+``[pv, delta[P], gamma[P*P]]`` - one all-reduce of 1 + P + P*P doubles per curve over RCCL/xGMI
+(`torch.distributed` backend "nccl" on ROCm; "gloo" in the CPU tests).  Per-trade results never move.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_bounds(flt_off: np.ndarray, fix_off: np.ndarray, world_size: int):
+    """Contiguous trade ranges ``[(lo, hi)] * world_size`` with near-equal cash-flow counts."""
+    n = int(flt_off.shape[0]) - 1
+    work = (np.asarray(flt_off, dtype=np.int64) + np.asarray(fix_off, dtype=np.int64))   # cumulative flows
+    total = int(work[-1])
+    cuts = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        cuts.append(int(np.searchsorted(work, target, side="left")))
+    cuts.append(n)
+    cuts = np.maximum.accumulate(np.clip(cuts, 0, n))
+    return [(int(cuts[r]), int(cuts[r + 1])) for r in range(world_size)]
+
+
+def shard_batch(batch, rank: int, world_size: int):
+    """This rank's slice of a `TradeBatch`."""
+    lo, hi = shard_bounds(batch.flt_off, batch.fix_off, world_size)[rank]
+    return batch.slice(lo, hi), (lo, hi)
+
+
+def allreduce_aggregate(agg, group=None):
+    """In-place sum of the aggregate ladder tensor over the ranks (the single collective of the path)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM, group=group)
+    return agg
+
+
+def allgather_sum_fixed_order(agg, group=None):
+    """Bit-stable alternative: gather every rank's partial and add them in rank order, so the result
+    does not depend on the collective's internal reduction order."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return agg
+    parts = [torch.empty_like(agg) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, agg, group=group)
+    total = parts[0].clone()
+    for p in parts[1:]:
+        total += p
+    agg.copy_(total)
+    return agg

@@ -95,7 +95,10 @@ def main():
     delta = torch.empty((n, P), dtype=torch.float64, device=dev) if want_delta else None
     gamma = torch.empty((n, P, P), dtype=torch.float64, device=dev) if want_gamma else None
     agg = torch.zeros(1 + P + P * P, dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream(dev)
+    # a non-default torch stream: the kernels, the HIP events that time them and the RCCL all-reduce all
+    # go to this one stream (torch.cuda.Event only sees the stream it is recorded on)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
 
     def step():
         _native.price_dev(ctx, dev_curve, dev_trades, mask, pv.data_ptr(),

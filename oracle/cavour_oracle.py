@@ -12,7 +12,7 @@ this path.  The oracle is therefore pinned by (i) the notebook outputs of the
 reference (`notebooks/intro.ipynb` cells 36-44: 1W swap PV, delta ladder, total
 gamma), (ii) the reference tests' properties (calibration swaps reprice through
 the engine to <= 1e-5, AD delta vs bump-and-reprice, gamma symmetry, pay/receive
-antisymmetry) - see tests/test_oracle_reference_properties.py.
+antisymmetry) - see tests/test_oracle_pins.py.
 
 Where the reference differentiates with `jax.grad / jax.hessian / jax.jacrev`,
 the oracle differentiates the same restated function with `torch.func` in
@@ -105,10 +105,11 @@ def _bootstrap_dfs(rates, acc, rate_idx, prev_idx):
     return torch.stack(dfs)
 
 
-def cached_curve(swap_rates, swap_times, year_fracs):
+def cached_curve(swap_rates, swap_times, year_fracs, derivatives=True):
     """times, dfs, d(dfs)/d(rates) and d2(dfs)/d(rates)2 - the cache dict of
     engine.py:2362-2412 (the `times[0] > 1e-7` prepend never triggers because
-    the grid already starts at t = 0)."""
+    the grid already starts at t = 0).  ``derivatives=False`` skips the two AD
+    passes (bump-and-reprice checks only need values)."""
     times, acc, rate_idx, prev_idx, collisions = expand_points(swap_rates, swap_times, year_fracs)
     rates = torch.tensor([float(r) for r in swap_rates], dtype=_F64)
 
@@ -116,12 +117,13 @@ def cached_curve(swap_rates, swap_times, year_fracs):
         return _bootstrap_dfs(r, acc, rate_idx, prev_idx)
 
     dfs = f(rates)
-    jac = jacrev(f)(rates)
-    hess = hessian(f)(rates)
     assert times[0] <= 1e-7
-    return dict(times=times, dfs=dfs.numpy().copy(), jac=jac.numpy().copy(),
-                hess=hess.numpy().copy(), acc=acc, rate_idx=rate_idx, prev_idx=prev_idx,
-                collisions=collisions)
+    out = dict(times=times, dfs=dfs.numpy().copy(), acc=acc, rate_idx=rate_idx, prev_idx=prev_idx,
+               collisions=collisions)
+    if derivatives:
+        out["jac"] = jacrev(f)(rates).numpy().copy()
+        out["hess"] = hessian(f)(rates).numpy().copy()
+    return out
 
 
 # ------------------------------------------------------------------- interpolation
@@ -228,6 +230,18 @@ def _leg_analytics(pv_fn, cache, want_gamma=True):
         term2 = torch.sum(grad_dfs[:, None, None] * hess_curve, dim=0)
         out["gamma"] = np.array((term1 + term2).numpy(), dtype=np.float64) * 1e-8
     return out
+
+
+def ois_value(cache, method, fixed, floating):
+    """PV only (no AD), for bump-and-reprice checks."""
+    dfs = torch.as_tensor(cache["dfs"], dtype=_F64)
+    m = len(floating["payment_times"])
+    v = price_fixed_leg(dfs, cache["times"], method, fixed["payment_times"], fixed["payments"],
+                        fixed.get("principal", 0.0), fixed["leg_sign"])
+    v = v + float_leg(dfs, cache["times"], method, floating["payment_times"], floating["start_times"],
+                      floating["end_times"], floating["pay_alphas"], np.full(m, floating["spread"]),
+                      np.full(m, floating["notional"]), floating.get("principal", 0.0), floating["leg_sign"])
+    return float(v)
 
 
 def ois_analytics(cache, method, fixed, floating, want_gamma=True):

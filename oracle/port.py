@@ -1,0 +1,89 @@
+"""ctypes wrapper of oracle/port.c (batched C restatement).  TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/ and by the ``cpu_baseline`` leg of bench.py - never by the
+product package.  ``price`` takes the reference's curve cache arrays
+(times, dfs, jac, hess) and a CSR trade batch and returns PV / delta / gamma.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libadr_port.so")
+_lib = None
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            subprocess.check_call(["make", "-C", _HERE])
+        _lib = C.CDLL(_SO)
+        _lib.adr_port_price.restype = C.c_int
+        _lib.adr_port_price.argtypes = ([C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, _ip, _ip]
+                                        + [_dp] * 10 + [_dp, _dp, _dp, C.c_int])
+        _lib.adr_port_max_threads.restype = C.c_int
+    return _lib
+
+
+def max_threads() -> int:
+    return int(_load().adr_port_max_threads())
+
+
+def _p(a, t=_dp):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def price(method, times, dfs, jac, hess, batch, want_delta=True, want_gamma=True, n_threads=0):
+    lib = _load()
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    times, dfs, jac = f(times), f(dfs), f(jac)
+    hess = None if hess is None else f(hess)
+    K, P = jac.shape
+    n = batch.n_trades
+    arr = {k: f(getattr(batch, k)) for k in ("fix_tp", "fix_pay", "flt_tp", "flt_ts", "flt_te", "flt_alpha",
+                                              "notional", "spread", "fix_sign", "flt_sign")}
+    fo = np.ascontiguousarray(batch.fix_off, dtype=np.int64)
+    lo = np.ascontiguousarray(batch.flt_off, dtype=np.int64)
+    pv = np.empty(n)
+    delta = np.empty((n, P)) if (want_delta or want_gamma) else None
+    gamma = np.empty((n, P, P)) if want_gamma else None
+    rc = lib.adr_port_price(K, P, int(method), _p(times), _p(dfs), _p(jac), _p(hess), n, _p(fo, _ip), _p(lo, _ip),
+                            _p(arr["fix_tp"]), _p(arr["fix_pay"]), _p(arr["flt_tp"]), _p(arr["flt_ts"]),
+                            _p(arr["flt_te"]), _p(arr["flt_alpha"]), _p(arr["notional"]), _p(arr["spread"]),
+                            _p(arr["fix_sign"]), _p(arr["flt_sign"]), _p(pv), _p(delta), _p(gamma), int(n_threads))
+    if rc != 0:
+        raise RuntimeError("adr_port_price rejected its arguments")
+    return dict(pv=pv, delta=delta, gamma=gamma)
+
+
+def timed_baseline(curve, value_dt, method, want_gamma, budget_s, kind="offgrid"):
+    """CPU baseline for bench.py: the same synthetic workload, a bounded sample, all host cores.
+
+    The curve derivatives come from the torch.func oracle (one-off, untimed, like the GPU's table
+    upload); the timed region is the batched pricing only."""
+    from adrates_amd.trades import synthetic   # workload generator (inputs only)
+    from . import cavour_oracle as O
+
+    cache = O.cached_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    threads = max_threads()
+    probe = synthetic.synthesize(value_dt, 2000, kind=kind)
+    t0 = time.perf_counter()
+    price(method, cache["times"], cache["dfs"], cache["jac"], cache["hess"], probe, want_gamma=want_gamma)
+    rate = 2000 / (time.perf_counter() - t0)
+    n = int(max(2000, min(2_000_000, rate * budget_s)))
+    sample = synthetic.synthesize(value_dt, n, kind=kind)
+    t0 = time.perf_counter()
+    price(method, cache["times"], cache["dfs"], cache["jac"], cache["hess"], sample, want_gamma=want_gamma)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "trades/s", "cores": threads, "kind": "port",
+            "sample": f"{n} trades of the same synthetic portfolio ({kind}), PV+delta"
+                      + ("+gamma" if want_gamma else "") + f", {dt:.1f} s wall on {threads} OpenMP threads "
+                      "(oracle/port.c: C restatement of the reference algorithm; the JAX reference cannot run here)"}

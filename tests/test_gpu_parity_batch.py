@@ -1,0 +1,204 @@
+"""HIP path at scale: against oracle/port.c on seeded synthetic portfolios, against the committed golden
+vectors, through the public Position / Portfolio API, and through size-independent properties at the
+BASELINE sizes (1e5 and 1e6 trades)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from adrates_amd import _native
+from adrates_amd.market.curves.curve_tables import build_engine_curve
+from adrates_amd.market.portfolio.portfolio import Portfolio
+from adrates_amd.trades import synthetic
+from adrates_amd.trades.compiler import TradeBatch, compile_ois
+from adrates_amd.utils import InterpTypes, RequestTypes
+from oracle import port
+
+from . import _fixtures as F
+from ._parity import REL_TOL, assert_batch_parity, assert_parity, gpu_price
+from .golden import make_golden
+
+pytestmark = pytest.mark.gpu
+ALL = [RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA]
+
+
+def _device_curve(ctx, curve):
+    host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    return host, _native.DeviceCurve(ctx, curve._interp_type.value, host.times, host.dfs, host.jac, host.hess)
+
+
+@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES])
+@pytest.mark.parametrize("kind", ["offgrid", "ongrid"])
+def test_synthetic_portfolio_vs_c_oracle(gpu_ctx, interp, kind):
+    vd = F.README_VALUE_DT
+    curve = F.gbp_model(vd, interp).curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    batch = synthetic.synthesize(vd, 20000, kind=kind, seed=77)
+    dt = _native.DeviceTrades(gpu_ctx, batch)
+    got = _native.price(gpu_ctx, dc, dt, aggregate=True)
+    ref = port.price(interp.value, host.times, host.dfs, host.jac, host.hess, batch)
+    worst = assert_batch_parity(got, ref, batch.notional)
+    assert np.allclose(got["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+    assert np.allclose(got["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
+    print(f"{interp.name}/{kind}: worst error {worst:.2e}")
+
+
+def test_usd_act360_curve_vs_c_oracle(gpu_ctx):
+    from adrates_amd.utils import CurrencyTypes, CurveTypes, DayCountTypes
+    vd = F.TEST_VALUE_DT
+    curve = F.usd_model().curves.USD_OIS_SOFR
+    host, dc = _device_curve(gpu_ctx, curve)
+    batch = synthetic.synthesize(vd, 5000, seed=4, dc_type=DayCountTypes.ACT_360,
+                                 curve_type=CurveTypes.USD_OIS_SOFR, currency=CurrencyTypes.USD)
+    got = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch))
+    ref = port.price(4, host.times, host.dfs, host.jac, host.hess, batch)
+    assert_batch_parity(got, ref, batch.notional)
+
+
+def test_golden_vectors(gpu_ctx):
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ois_golden.json")) as f:
+        golden = json.load(f)
+    for case, want in zip(make_golden.CASES, golden["cases"]):
+        vd, curve, swaps = make_golden.build(case)
+        got = gpu_price(gpu_ctx, curve, swaps, vd)
+        refs = [dict(value=r["pv"], delta=np.array(r["delta"]), gamma=np.array(r["gamma"])) for r in want["trades"]]
+        assert_parity(got, refs, [r["notional"] for r in want["trades"]])
+
+
+def test_request_subsets_and_small_pillar_curve(gpu_ctx):
+    vd = F.README_VALUE_DT
+    curve = F.gbp_model(px=[5.19, 5.13, 5.04, 4.75, 4.24], tenors=["1M", "3M", "6M", "1Y", "5Y"]).curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    assert dc.n_pillars == 5
+    swaps = [F.make_swap(vd, t, 0.045, 1e6) for t in ("2M", "9M", "3Y", "5Y", "7Y")]
+    batch = compile_ois(swaps, vd)
+    dt = _native.DeviceTrades(gpu_ctx, batch)
+    ref = port.price(4, host.times, host.dfs, host.jac, host.hess, batch)
+    full = _native.price(gpu_ctx, dc, dt)
+    assert full["delta"].shape == (5, 5) and full["gamma"].shape == (5, 5, 5)
+    assert_batch_parity(full, ref, batch.notional)
+    only_v = _native.price(gpu_ctx, dc, dt, want_delta=False, want_gamma=False)
+    only_d = _native.price(gpu_ctx, dc, dt, want_gamma=False)
+    assert set(only_v) == {"pv"} and set(only_d) == {"pv", "delta"}
+    assert np.array_equal(only_v["pv"], full["pv"]) and np.array_equal(only_d["delta"], full["delta"])
+    # a curve uploaded without the Hessian cannot serve GAMMA
+    no_h = _native.DeviceCurve(gpu_ctx, 4, host.times, host.dfs, host.jac, None)
+    from adrates_amd.utils import LibError
+    with pytest.raises(LibError):
+        _native.price(gpu_ctx, no_h, dt)
+    assert np.array_equal(_native.price(gpu_ctx, no_h, dt, want_gamma=False)["delta"], full["delta"])
+
+
+def test_edge_cases_empty_single_long(gpu_ctx):
+    vd = F.README_VALUE_DT
+    curve = F.readme_model().curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    z = np.zeros(0)
+    empty = TradeBatch(np.zeros(1, np.int64), np.zeros(1, np.int64), z, z, z, z, z, z, z, z, z, z)
+    r = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, empty), aggregate=True)
+    assert r["pv"].shape == (0,) and r["agg_pv"] == 0.0 and not r["agg_gamma"].any()
+    # one single-coupon trade, one 120-coupon quarterly 30Y (more than one 64-lane chunk), a trade with no
+    # fixed flows and one with no float flows (ragged CSR rows)
+    from adrates_amd.utils import FrequencyTypes
+    swaps = [F.make_swap(vd, "1D", 0.05), F.make_swap(vd, "30Y", 0.04, 2e6, fixed_freq=FrequencyTypes.QUARTERLY,
+                                                      float_freq=FrequencyTypes.QUARTERLY)]
+    b = compile_ois(swaps, vd)
+    assert np.diff(b.flt_off).tolist() == [1, 120]
+    no_fix = TradeBatch(np.array([0, 0]), np.array([0, 3]), z, z, b.flt_tp[1:4], b.flt_ts[1:4], b.flt_te[1:4],
+                        b.flt_alpha[1:4], np.array([1e6]), np.array([0.001]), np.array([1.0]), np.array([-1.0]))
+    no_flt = TradeBatch(np.array([0, 2]), np.array([0, 0]), b.fix_tp[1:3], b.fix_pay[1:3], z, z, z, z,
+                        np.array([1e6]), np.array([0.0]), np.array([1.0]), np.array([-1.0]))
+    for batch in (b, no_fix, no_flt):
+        got = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch))
+        ref = port.price(4, host.times, host.dfs, host.jac, host.hess, batch)
+        assert_batch_parity(got, ref, batch.notional)
+
+
+def test_position_and_portfolio_api(gpu_ctx):
+    """README section 2 call sequence through the drop-in API."""
+    vd = F.README_VALUE_DT
+    model = F.readme_model()
+    swap = F.make_swap(vd, "10Y", 0.045, 10_000_000)
+    res = swap.position(model).compute(ALL)
+    assert res.value.amount == pytest.approx(-339137.9944015499, rel=1e-12)      # oracle value (golden)
+    assert res.risk.value.amount == pytest.approx(8204.149481268581, rel=1e-12)
+    assert res.gamma.value.amount == pytest.approx(-8.072481784896766, rel=1e-11)
+    assert res.gamma.risk_ladder.shape == (32, 32) and len(res.risk.tenors) == 32
+    assert len(res.risk.ladder.data) == 31 and res.risk.curve_type.name == "GBP_OIS_SONIA"
+    assert np.allclose(res.gamma.risk_ladder, res.gamma.risk_ladder.T, rtol=1e-10, atol=1e-14)
+    only = swap.position(model).compute([RequestTypes.DELTA])
+    assert only.value is None and only.gamma is None and only.risk.value.amount == res.risk.value.amount
+    # portfolio = sum of positions (cavour/market/portfolio/portfolio.py:39-66)
+    others = [F.make_swap(vd, "87M", 0.04, 1e7, pay=False), F.make_swap(vd, "3M", 0.05, 2e6)]
+    positions = [s.position(model) for s in [swap] + others]
+    tot = Portfolio(positions).compute(ALL)
+    parts = [p.compute(ALL) for p in positions]
+    assert tot.value.amount == pytest.approx(sum(p.value.amount for p in parts), rel=1e-13)
+    assert np.allclose(tot.risk.risk_ladder, sum(p.risk.risk_ladder for p in parts), rtol=1e-12, atol=1e-9)
+    assert np.allclose(tot.gamma.risk_ladder, sum(p.gamma.risk_ladder for p in parts), rtol=1e-12, atol=1e-13)
+    # AD delta vs bump-and-reprice through Model.scenario, all on the GPU path
+    up = swap.position(model.scenario("GBP_OIS_SONIA", 0.01)).compute([RequestTypes.VALUE]).value.amount
+    dn = swap.position(model.scenario("GBP_OIS_SONIA", -0.01)).compute([RequestTypes.VALUE]).value.amount
+    assert abs(res.risk.value.amount - (up - dn) / 2.0) / abs(res.risk.value.amount) < 1e-4
+
+
+@pytest.mark.parametrize("n", [100_000, 1_000_000])
+def test_full_size_properties(gpu_ctx, n):
+    """BASELINE configs[1]/[2] sizes: properties that need no oracle.  (a) a spot check of 2000 random
+    trades against the C oracle, (b) pay/receive antisymmetry, (c) linearity in notional,
+    (d) aggregate == sum of per-trade ladders, (e) gamma symmetric."""
+    import torch
+    vd = F.README_VALUE_DT
+    curve = F.readme_model().curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    batch = synthetic.synthesize(vd, n, seed=synthetic.DEFAULT_SEED)
+    P = dc.n_pillars
+    dev = torch.device("cuda", 0)
+
+    def run(b):
+        dt = _native.DeviceTrades(gpu_ctx, b)
+        pv = torch.empty(b.n_trades, dtype=torch.float64, device=dev)
+        de = torch.empty((b.n_trades, P), dtype=torch.float64, device=dev)
+        ga = torch.empty((b.n_trades, P, P), dtype=torch.float64, device=dev)
+        ag = torch.empty(1 + P + P * P, dtype=torch.float64, device=dev)
+        _native.price_dev(gpu_ctx, dc, dt, 7, pv.data_ptr(), de.data_ptr(), ga.data_ptr(), ag.data_ptr())
+        gpu_ctx.sync()
+        dt.close()
+        return pv, de, ga, ag
+
+    pv, de, ga, ag = run(batch)
+    # (a)
+    pick = np.sort(np.random.default_rng(1).choice(n, 2000, replace=False))
+    sub = TradeBatch(*[None] * 12)
+    lens_f, lens_l = np.diff(batch.fix_off)[pick], np.diff(batch.flt_off)[pick]
+    gidx = lambda off, lens: np.concatenate([np.arange(off[i], off[i] + m) for i, m in zip(pick, lens)])
+    fi, li = gidx(batch.fix_off, lens_f), gidx(batch.flt_off, lens_l)
+    sub = TradeBatch(np.r_[0, np.cumsum(lens_f)], np.r_[0, np.cumsum(lens_l)], batch.fix_tp[fi], batch.fix_pay[fi],
+                     batch.flt_tp[li], batch.flt_ts[li], batch.flt_te[li], batch.flt_alpha[li],
+                     batch.notional[pick], batch.spread[pick], batch.fix_sign[pick], batch.flt_sign[pick])
+    ref = port.price(4, host.times, host.dfs, host.jac, host.hess, sub)
+    tp = torch.as_tensor(pick, device=dev)
+    got = dict(pv=pv[tp].cpu().numpy(), delta=de[tp].cpu().numpy(), gamma=ga[tp].cpu().numpy())
+    assert_batch_parity(got, ref, sub.notional)
+    # (e)
+    asym = (ga - ga.transpose(1, 2)).abs().amax(dim=(1, 2)) / ga.abs().amax(dim=(1, 2)).clamp_min(1e-300)
+    assert float(asym.max()) <= REL_TOL
+    # (d)
+    scale = float(ga.abs().sum(0).max())
+    assert float((ag[1 + P:].view(P, P) - ga.sum(0)).abs().max()) <= 1e-10 * scale
+    assert float((ag[1:1 + P] - de.sum(0)).abs().max()) <= 1e-10 * float(de.abs().sum(0).max())
+    assert abs(float(ag[0] - pv.sum())) <= 1e-10 * float(pv.abs().sum())
+    # (b): flip both legs
+    flipped = TradeBatch(batch.fix_off, batch.flt_off, batch.fix_tp, batch.fix_pay, batch.flt_tp, batch.flt_ts,
+                         batch.flt_te, batch.flt_alpha, batch.notional, batch.spread, -batch.fix_sign, -batch.flt_sign)
+    pv2, de2, ga2, _ = run(flipped)
+    assert float((pv + pv2).abs().max()) == 0.0 and float((de + de2).abs().max()) == 0.0
+    assert float((ga + ga2).abs().max()) == 0.0
+    del pv2, de2, ga2
+    # (c): doubling notional and payments doubles everything exactly (power-of-two scaling)
+    doubled = TradeBatch(batch.fix_off, batch.flt_off, batch.fix_tp, 2.0 * batch.fix_pay, batch.flt_tp, batch.flt_ts,
+                         batch.flt_te, batch.flt_alpha, 2.0 * batch.notional, batch.spread, batch.fix_sign,
+                         batch.flt_sign)
+    pv3, de3, ga3, _ = run(doubled)
+    assert torch.equal(pv3, 2.0 * pv) and torch.equal(de3, 2.0 * de) and torch.equal(ga3, 2.0 * ga)
