@@ -36,6 +36,7 @@ _SIGNATURES = {
     "adr_free_curve": (None, [_vp]),
     "adr_curve_pillars": (C.c_int, [_vp]),
     "adr_curve_tables_host": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, _dp, _i32p, _dp, _dp, _dp]),
+    "adr_curve_layout_host": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, _dp, _i64p]),
     "adr_trades_upload": (C.c_int, [_vp, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, _dp, _dp, _dp,
                                     _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
     "adr_free_trades": (None, [_vp]),
@@ -236,6 +237,19 @@ def curve_tables_host(times, dfs, jac, hess=None):
     _check(lib.adr_curve_tables_host(K, P, _ptr(times), _ptr(dfs), _ptr(jac), _ptr(hess_c),
                                      _ptr(idx, _i32p), _ptr(log_df), _ptr(lj), _ptr(lc)), "adr_curve_tables_host")
     return dict(knot_index=idx, log_df=log_df, lj=lj, lc=lc)
+
+
+def curve_layout_host(times, dfs, jac, hess=None):
+    """LDS layout the fast kernels would use for this curve (diagnostic; no GPU needed)."""
+    times, dfs, jac = _f64(times), _f64(dfs), _f64(jac)
+    K, P = jac.shape
+    hess_c = None if hess is None else _f64(hess)
+    info = np.zeros(8, dtype=np.int64)
+    _check(load().adr_curve_layout_host(K, P, _ptr(times), _ptr(dfs), _ptr(jac), _ptr(hess_c), _ptr(info, _i64p)),
+           "adr_curve_layout_host")
+    keys = ("packed_ok", "core_pillars", "core_pairs", "packed_entries", "entries_per_lane", "core_rows",
+            "mini_knots", "lds_bytes")
+    return dict(zip(keys, (int(v) for v in info)))
 
 
 _default_ctx = {}

@@ -17,6 +17,8 @@ namespace {
 
 thread_local std::string g_last_error;
 
+constexpr size_t kLdsBudget = 160 * 1024;
+
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
@@ -62,6 +64,11 @@ struct adr_trades {
     adr_ctx* ctx = nullptr;
     adr::TradesDev dev{};
     int64_t n_fix_flows = 0, n_flt_flows = 0;
+    // trades with a coupon whose accrual end differs from its payment time (payment lag) need the
+    // general kernel; when there are none both lists stay null and the fast kernel walks 0..n-1
+    int64_t n_fast = 0, n_general = 0;
+    const int32_t* list_fast = nullptr;
+    const int32_t* list_general = nullptr;
     std::vector<void*> allocations;
 };
 
@@ -133,6 +140,20 @@ int adr_curve_tables_host(int K, int P, const double* times, const double* dfs, 
     return t.Kc;
 }
 
+int adr_curve_layout_host(int K, int P, const double* times, const double* dfs, const double* jac,
+                          const double* hess, int64_t* info) {
+    if (!info) return fail(ADR_ERR_INVALID, "adr_curve_layout_host: info is null");
+    adr::CurveTables t;
+    const std::string err = adr::build_curve_tables(K, P, times, dfs, jac, hess, t);
+    if (!err.empty()) return fail(ADR_ERR_INVALID, "adr_curve_layout_host: " + err);
+    adr::CurveDev d{};
+    d.K = t.K; d.Kc = t.Kc; d.Kcore = t.Kcore; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Eu = t.Eu; d.n_mini = t.n_mini;
+    info[0] = t.packed_ok ? 1 : 0; info[1] = t.Pc; info[2] = t.Ec; info[3] = t.Eu; info[4] = t.epl;
+    info[5] = t.Kcore; info[6] = t.n_mini;
+    info[7] = t.packed_ok ? static_cast<int64_t>(adr::fast_kernel_lds_bytes(d, t.has_hess)) : 0;
+    return ADR_OK;
+}
+
 void adr_free_curve(adr_curve* curve) {
     if (!curve) return;
     if (curve->ctx) hipSetDevice(curve->ctx->device);
@@ -155,8 +176,8 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     const std::string err = adr::build_curve_tables(K, P, times, dfs, jac, hess, t);
     if (!err.empty()) return fail(ADR_ERR_INVALID, "adr_curve_upload: " + err);
 
-    const size_t lds = adr::price_kernel_lds_bytes(t.K, t.Kc);
-    if (lds > 160 * 1024)
+    const size_t lds = adr::general_kernel_lds_bytes(t.K, t.Kc);
+    if (lds > kLdsBudget)
         return fail(ADR_ERR_UNSUPPORTED, "adr_curve_upload: curve tables exceed the 160 KiB LDS of a CU");
 
     ADR_HIP(hipSetDevice(ctx->device));
@@ -166,7 +187,10 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     std::vector<int16_t> first16(t.first_of.begin(), t.first_of.end());
     std::vector<int16_t> comp16(t.compact_of.begin(), t.compact_of.end());
     double *d_x = nullptr, *d_log = nullptr, *d_invx = nullptr, *d_lj = nullptr, *d_lc = nullptr;
-    int16_t *d_first = nullptr, *d_comp = nullptr;
+    double *d_ljc = nullptr, *d_lcc = nullptr;
+    int16_t *d_first = nullptr, *d_comp = nullptr, *d_class = nullptr, *d_p2c = nullptr, *d_omap = nullptr;
+    uint8_t* d_pq = nullptr;
+    adr::MiniKnot* d_mini = nullptr;
     hipError_t e = hipSuccess;
     auto track = [&](hipError_t r, void* p) { if (p) c->allocations.push_back(p); if (e == hipSuccess) e = r; };
     track(upload(t.x, &d_x), d_x);
@@ -176,14 +200,32 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     track(upload(t.lc_lanes, &d_lc), d_lc);
     track(upload(first16, &d_first), d_first);
     track(upload(comp16, &d_comp), d_comp);
+    if (t.packed_ok) {
+        track(upload(t.ljc, &d_ljc), d_ljc);
+        track(upload(t.lcc, &d_lcc), d_lcc);
+        track(upload(t.knot_class, &d_class), d_class);
+        track(upload(t.pillar_to_core, &d_p2c), d_p2c);
+        track(upload(t.out_map, &d_omap), d_omap);
+        track(upload(t.ent_pq, &d_pq), d_pq);
+        track(upload(t.mini, &d_mini), d_mini);
+    }
     if (e != hipSuccess) { adr_free_curve(c); return fail_hip(e, "adr_curve_upload: copying tables"); }
     c->dev.K = t.K; c->dev.Kc = t.Kc; c->dev.P = t.P; c->dev.method = interp_method;
     c->dev.x = d_x; c->dev.log_df = d_log; c->dev.inv_x = d_invx; c->dev.lj = d_lj; c->dev.lc_lanes = d_lc;
     c->dev.first_of = d_first; c->dev.compact_of = d_comp;
-    if (lds > 48 * 1024) {
-        e = adr::set_price_kernel_lds_limit(lds);
-        if (e != hipSuccess) { adr_free_curve(c); return fail_hip(e, "hipFuncSetAttribute(LDS)"); }
+    c->dev.packed_ok = t.packed_ok ? 1 : 0;
+    c->dev.Pc = t.Pc; c->dev.pc_pad = t.pc_pad; c->dev.Ec = t.Ec; c->dev.Eu = t.Eu; c->dev.epl = t.epl;
+    c->dev.Kcore = t.Kcore; c->dev.n_mini = t.n_mini;
+    c->dev.ljc = d_ljc; c->dev.lcc = d_lcc; c->dev.mini = d_mini; c->dev.knot_class = d_class;
+    c->dev.pillar_to_core = d_p2c; c->dev.out_map = d_omap; c->dev.ent_pq = d_pq;
+    // the packed tables must fit the LDS of a CU next to the search arrays, else the general kernel serves all
+    size_t fast_lds = 0;
+    if (c->dev.packed_ok) {
+        fast_lds = adr::fast_kernel_lds_bytes(c->dev, t.has_hess);
+        if (fast_lds > kLdsBudget) { c->dev.packed_ok = 0; fast_lds = 0; }
     }
+    e = adr::set_kernel_lds_limits(lds, std::max(fast_lds, lds));
+    if (e != hipSuccess) { adr_free_curve(c); return fail_hip(e, "hipFuncSetAttribute(LDS)"); }
     *out = c;
     return ADR_OK;
 }
@@ -221,6 +263,14 @@ int adr_trades_upload(adr_ctx* ctx, int64_t n, const int64_t* fix_off, const int
         return fail(ADR_ERR_INVALID, "adr_trades_upload: null cash-flow array");
 
     std::vector<adr::TradeHeader> hdr(static_cast<size_t>(n));
+    std::vector<int32_t> list_fast, list_general;
+    if (n > INT32_MAX) return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^31 trades in one batch");
+    for (int64_t t = 0; t < n; ++t) {
+        bool lagged = false;
+        for (int64_t j = flt_off[t]; j < flt_off[t + 1] && !lagged; ++j)
+            lagged = flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j];
+        (lagged ? list_general : list_fast).push_back(static_cast<int32_t>(t));
+    }
     for (int64_t t = 0; t < n; ++t) {
         const int64_t mf = fix_off[t + 1] - fix_off[t], ml = flt_off[t + 1] - flt_off[t];
         if (mf < 0 || ml < 0 || mf > INT16_MAX || ml > INT16_MAX)
@@ -264,6 +314,14 @@ int adr_trades_upload(adr_ctx* ctx, int64_t n, const int64_t* fix_off, const int
     tr->dev.flt_ts = static_cast<const double*>(put(flt_ts, n_flt * sizeof(double)));
     tr->dev.flt_te = static_cast<const double*>(put(flt_te, n_flt * sizeof(double)));
     tr->dev.flt_alpha = static_cast<const double*>(put(flt_alpha, n_flt * sizeof(double)));
+    tr->dev.list = nullptr;
+    tr->dev.n_list = n;
+    tr->n_fast = static_cast<int64_t>(list_fast.size());
+    tr->n_general = static_cast<int64_t>(list_general.size());
+    if (tr->n_general > 0) {
+        tr->list_fast = static_cast<const int32_t*>(put(list_fast.data(), list_fast.size() * sizeof(int32_t)));
+        tr->list_general = static_cast<const int32_t*>(put(list_general.data(), list_general.size() * sizeof(int32_t)));
+    }
     if (e != hipSuccess) { adr_free_trades(tr); return fail_hip(e, "adr_trades_upload: copying trades"); }
     *out = tr;
     return ADR_OK;
@@ -289,18 +347,43 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         return ADR_OK;
     }
 
-    // one wavefront per trade, 4 per block; enough blocks to fill the chip, grid-stride over the rest
-    const int64_t blocks_needed = (n + (adr::kBlockThreads / 64) - 1) / (adr::kBlockThreads / 64);
-    const int per_cu = want_gamma ? 4 : 8;
-    const int n_blocks = static_cast<int>(std::min<int64_t>(blocks_needed,
-                                                            std::min(ctx->max_blocks, ctx->n_cu * per_cu)));
     adr::OutputsDev o;
     o.pv = (req_mask & ADR_REQ_VALUE) ? pv_dev : nullptr;
     o.delta = (req_mask & ADR_REQ_DELTA) ? delta_dev : nullptr;
     o.gamma = want_gamma ? gamma_dev : nullptr;
-    o.block_partials = agg_dev ? ctx->partials : nullptr;
-    ADR_HIP(adr::launch_price(curve->dev, trades->dev, o, want_delta, want_gamma, n_blocks, stream));
-    if (agg_dev) ADR_HIP(adr::launch_reduce_partials(ctx->partials, n_blocks, P, agg_dev, stream));
+
+    // One wavefront per trade, grid-stride.  Trades without payment lag go to the fast kernel when the
+    // curve has the packed layout; everything else to the general kernel.
+    const bool use_fast = curve->dev.packed_ok != 0;
+    adr::TradesDev fast = trades->dev, general = trades->dev;
+    if (use_fast) {
+        fast.list = trades->list_fast;       fast.n_list = trades->n_fast;
+        general.list = trades->list_general; general.n_list = trades->n_general;
+    } else {
+        fast.n_list = 0;                     // general walks all n trades through the identity list
+    }
+    int blocks_fast = 0, blocks_general = 0;
+    if (fast.n_list > 0) {
+        const size_t lds = adr::fast_kernel_lds_bytes(curve->dev, want_gamma);
+        const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
+        const int64_t need = (fast.n_list + adr::kFastThreads / 64 - 1) / (adr::kFastThreads / 64);
+        blocks_fast = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * per_cu));
+    }
+    if (general.n_list > 0) {
+        const int64_t need = (general.n_list + adr::kGeneralThreads / 64 - 1) / (adr::kGeneralThreads / 64);
+        blocks_general = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * 4));
+    }
+    if (blocks_fast + blocks_general > ctx->max_blocks) return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
+    if (blocks_fast > 0) {
+        o.block_partials = agg_dev ? ctx->partials : nullptr;
+        ADR_HIP(adr::launch_price_fast(curve->dev, fast, o, want_delta, want_gamma, blocks_fast, stream));
+    }
+    if (blocks_general > 0) {
+        o.block_partials = agg_dev ? ctx->partials + static_cast<size_t>(blocks_fast) * adr::kAggStride : nullptr;
+        ADR_HIP(adr::launch_price_general(curve->dev, general, o, want_delta, want_gamma, blocks_general, stream));
+    }
+    if (agg_dev)
+        ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_fast + blocks_general, P, agg_dev, stream));
     return ADR_OK;
 }
 

@@ -66,7 +66,129 @@ std::string build_curve_tables(int K, int P, const double* times, const double* 
                 lanes[lane * kGammaPerLane + e] = (r < P && q < P) ? lck[r * P + q] : 0.0;
             }
     }
+    out.packed_ok = build_packed_layout(out);
     return std::string();
+}
+
+// Pillar-support analysis for the fast kernels.
+//
+// A bootstrapped knot DF depends only on the par rates of the swaps in its bootstrap chain, so most of
+// LJ and of every LC matrix is structurally zero (README curve: at most 17 of 32 pillars per knot, always
+// from the same 17 "long" pillars, while the 15 short pillars only touch their own single-period knots).
+//   core set C   = union of all supports with at least three pillars;
+//   core knot    = support inside C: a row of ljc (LJ on C) and of lcc (LC on the packed pairs of C x C);
+//   mini knot    = any other knot - by construction its support has at most two pillars: a MiniKnot record;
+//   null knot    = empty support (t = 0).
+// A node (one or two knots) only creates gamma entries inside S x S with S the union of its knots'
+// supports.  The packed entry list is all core pairs followed by every non-core pair some *possible* node
+// can create - possible nodes are the adjacent (last-of-run, first-of-run) knot pairs and the single
+// knots, which the curve alone determines.  Trades with ratio terms (payment lag) can couple three
+// intervals and are not covered; they go to the general kernel.
+bool build_packed_layout(CurveTables& t) {
+    const int P = t.P, Kc = t.Kc;
+    std::vector<uint32_t> support(Kc, 0u);
+    for (int c = 0; c < Kc; ++c) {
+        uint32_t m = 0;
+        for (int p = 0; p < P; ++p) {
+            bool nz = t.lj[static_cast<size_t>(c) * kPillarPad + p] != 0.0;
+            if (!nz && t.has_hess)
+                for (int q = 0; q < P && !nz; ++q) nz = t.lc[(static_cast<size_t>(c) * P + p) * P + q] != 0.0;
+            if (nz) m |= 1u << p;
+        }
+        support[c] = m;
+    }
+    uint32_t core = 0;
+    for (int c = 0; c < Kc; ++c)
+        if (__builtin_popcount(support[c]) >= 3) core |= support[c];
+
+    const int Pc = t.Pc = __builtin_popcount(core);
+    t.pc_pad = (Pc + 2) & ~1;
+    t.pillar_to_core.assign(kPillarPad, static_cast<int16_t>(Pc));
+    std::vector<int> core_pillars;
+    for (int p = 0; p < P; ++p)
+        if (core & (1u << p)) {
+            t.pillar_to_core[p] = static_cast<int16_t>(core_pillars.size());
+            core_pillars.push_back(p);
+        }
+    const int Ec = t.Ec = Pc * (Pc + 1) / 2;
+
+    // packed entries: core pairs first (in packed_index order), then fringe pairs as discovered
+    std::vector<int> entry_of(kPillarPad * kPillarPad, -1);   // [p*32+q], p <= q
+    t.ent_pq.clear();
+    for (int i = 0; i < Pc; ++i)
+        for (int j = i; j < Pc; ++j) {
+            entry_of[core_pillars[i] * kPillarPad + core_pillars[j]] = static_cast<int>(t.ent_pq.size() / 2);
+            t.ent_pq.push_back(static_cast<uint8_t>(core_pillars[i]));
+            t.ent_pq.push_back(static_cast<uint8_t>(core_pillars[j]));
+        }
+    auto add_pairs = [&](uint32_t S) {
+        for (int p = 0; p < P; ++p) {
+            if (!(S & (1u << p))) continue;
+            for (int q = p; q < P; ++q) {
+                if (!(S & (1u << q)) || entry_of[p * kPillarPad + q] >= 0) continue;
+                entry_of[p * kPillarPad + q] = static_cast<int>(t.ent_pq.size() / 2);
+                t.ent_pq.push_back(static_cast<uint8_t>(p));
+                t.ent_pq.push_back(static_cast<uint8_t>(q));
+            }
+        }
+    };
+    for (int c = 0; c < Kc; ++c) {
+        add_pairs(support[c]);                                  // snapped / extrapolated single knots
+        if (c + 1 < Kc && t.x[t.knot_index[c]] != t.x[t.knot_index[c + 1]])
+            add_pairs(support[c] | support[c + 1]);             // (last of a run, first of the next run)
+    }
+    const int Eu = t.Eu = static_cast<int>(t.ent_pq.size() / 2);
+    if (Eu > 64 * 9) return false;
+    t.epl = Eu <= 64 * 3 ? 3 : Eu <= 64 * 4 ? 4 : Eu <= 64 * 6 ? 6 : 9;
+
+    t.out_map.assign(kPillarPad * kPillarPad, -1);
+    for (int r = 0; r < P; ++r)
+        for (int q = 0; q < P; ++q)
+            t.out_map[r * kPillarPad + q] = static_cast<int16_t>(entry_of[std::min(r, q) * kPillarPad + std::max(r, q)]);
+
+    t.knot_class.assign(Kc, -2);
+    t.Kcore = 0;
+    t.mini.clear();
+    for (int c = 0; c < Kc; ++c) {
+        if (support[c] == 0) continue;
+        if ((support[c] & ~core) == 0) { t.knot_class[c] = static_cast<int16_t>(t.Kcore++); continue; }
+        if (__builtin_popcount(support[c]) > 2) return false;   // cannot happen: such a support is in the core
+        MiniKnot m{};
+        m.p[0] = m.p[1] = -1;
+        m.e[0] = m.e[1] = m.e[2] = -1;
+        int n = 0;
+        for (int p = 0; p < P; ++p)
+            if (support[c] & (1u << p)) { m.p[n] = p; m.lj[n] = t.lj[static_cast<size_t>(c) * kPillarPad + p]; ++n; }
+        if (t.has_hess) {
+            const double* lck = &t.lc[static_cast<size_t>(c) * P * P];
+            m.e[0] = entry_of[m.p[0] * kPillarPad + m.p[0]];
+            m.lc[0] = lck[m.p[0] * P + m.p[0]];
+            if (n == 2) {
+                m.e[1] = entry_of[m.p[0] * kPillarPad + m.p[1]];
+                m.lc[1] = lck[m.p[0] * P + m.p[1]];
+                m.e[2] = entry_of[m.p[1] * kPillarPad + m.p[1]];
+                m.lc[2] = lck[m.p[1] * P + m.p[1]];
+            }
+        }
+        t.knot_class[c] = static_cast<int16_t>(-3 - static_cast<int>(t.mini.size()));
+        t.mini.push_back(m);
+    }
+    t.n_mini = static_cast<int>(t.mini.size());
+
+    t.ljc.assign(static_cast<size_t>(t.Kcore) * t.pc_pad, 0.0);
+    t.lcc.assign(t.has_hess ? static_cast<size_t>(t.Kcore) * (Ec + 1) : 0, 0.0);   // trailing 0 per row
+    for (int c = 0; c < Kc; ++c) {
+        const int row = t.knot_class[c];
+        if (row < 0) continue;
+        for (int i = 0; i < Pc; ++i)
+            t.ljc[static_cast<size_t>(row) * t.pc_pad + i] = t.lj[static_cast<size_t>(c) * kPillarPad + core_pillars[i]];
+        if (!t.has_hess) continue;
+        for (int i = 0; i < Pc; ++i)
+            for (int j = i; j < Pc; ++j)
+                t.lcc[static_cast<size_t>(row) * (Ec + 1) + packed_index(i, j, Pc)] =
+                    t.lc[(static_cast<size_t>(c) * P + core_pillars[i]) * P + core_pillars[j]];
+    }
+    return true;
 }
 
 }  // namespace adr

@@ -23,11 +23,23 @@ namespace adr {
 constexpr int kPillarPad = 32;                                  // ladders are padded to this on chip
 constexpr int kGammaPerLane = kPillarPad * kPillarPad / 64;     // 16 gamma entries per lane (4x4 block)
 
+// A knot whose log-DF depends on at most two par rates (single-period calibration swaps of the short
+// end): its whole first/second-derivative information is 2 + 3 numbers.
+struct MiniKnot {
+    int32_t p[2];      // pillars, -1 when unused
+    int32_t e[3];      // packed entries of (p0,p0), (p0,p1), (p1,p1), -1 when unused
+    int32_t pad;
+    double lj[2];
+    double lc[3];
+};
+static_assert(sizeof(MiniKnot) == 64, "MiniKnot is read as 64-byte records");
+
 struct CurveTables {
     int K = 0;    // knots of the caller's grid
     int P = 0;    // pillars
     int Kc = 0;   // knots kept
     bool has_hess = false;
+    bool packed_ok = false;            // packed layout below is usable
     std::vector<double> x;             // [K]   knot times (full grid, for the search)
     std::vector<int32_t> first_of;     // [K]   first index of the run of equal times containing k
     std::vector<int32_t> compact_of;   // [K]   row of knot k in the compact tables, -1 if unreachable
@@ -36,12 +48,35 @@ struct CurveTables {
     std::vector<double> inv_x;         // [Kc]  1 / max(x_k, 1e-15)   (linear-zero-rate weights)
     std::vector<double> lj;            // [Kc][kPillarPad], zero padded
     std::vector<double> lc;            // [Kc][P][P] row-major (plain layout, for checking)
-    std::vector<double> lc_lanes;      // [Kc][64][16] lane-major layout read by the gamma kernel
+    std::vector<double> lc_lanes;      // [Kc][64][16] lane-major layout read by the general gamma kernel
+
+    // ---- packed layout of the fast kernels (see build_packed_layout) ----
+    int Pc = 0;                        // pillars in the core set
+    int pc_pad = 0;                    // row stride of ljc: >= Pc + 1 (column Pc is all zero), even
+    int Ec = 0;                        // Pc*(Pc+1)/2 core x core pairs = the first Ec packed entries
+    int Eu = 0;                        // all packed entries: core pairs, then the fringe pairs
+    int epl = 0;                       // packed entries per lane the kernel is instantiated for (Eu <= 64*epl)
+    int Kcore = 0;                     // rows of ljc / lcc
+    int n_mini = 0;                    // knots with at most two pillars outside the core
+    std::vector<int16_t> pillar_to_core;   // [32]   core column of pillar p; Pc (the zero column) outside the core
+    std::vector<int16_t> knot_class;       // [Kc]   >= 0: core row; -2: all-zero knot; <= -3: mini record -3 - m
+    std::vector<double> ljc;               // [Kcore][pc_pad]  LJ on the core pillars
+    std::vector<double> lcc;               // [Kcore][Ec + 1]  LC on the packed core x core pairs, then a 0
+    std::vector<uint8_t> ent_pq;           // [Eu][2]          pillars (p <= q) of packed entry e
+    std::vector<int16_t> out_map;          // [32*32]          packed entry feeding gamma[r][c], -1 if none
+    std::vector<MiniKnot> mini;            // [n_mini]
 };
 
 // Row/column of gamma entry e (0..15) held by lane l (0..63): a 4x4 block at (4*(l/8), 4*(l%8)).
 inline int gamma_row(int lane, int e) { return 4 * (lane >> 3) + (e >> 2); }
 inline int gamma_col(int lane, int e) { return 4 * (lane & 7) + (e & 3); }
+
+// Packed index of core pair (i <= j) among Pc core pillars, row-major upper triangle.
+inline int packed_index(int i, int j, int Pc) { return i * Pc - i * (i - 1) / 2 + (j - i); }
+
+// Returns false when the curve does not have the sparse structure the packed layout needs (the fast
+// kernels are then not used for it).
+bool build_packed_layout(CurveTables& t);
 
 // Returns an empty string on success, otherwise the reason the inputs were rejected.
 std::string build_curve_tables(int K, int P, const double* times, const double* dfs, const double* jac,

@@ -1,4 +1,4 @@
-// Device-side data layout and kernel launchers shared by kernels.hip and capi.hip.
+// Device-side data layout and kernel launchers shared by the .hip files.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -7,8 +7,9 @@
 
 namespace adr {
 
-constexpr int kBlockThreads = 256;                                   // 4 wavefronts, one trade each
 constexpr int kAggStride = 1 + kPillarPad + kPillarPad * kPillarPad; // padded [pv, delta, gamma] record
+constexpr int kGeneralThreads = 256;                                 // general kernel: 4 wavefronts per block
+constexpr int kFastThreads = 512;                                    // fast kernel: 8 wavefronts per block
 
 // Per-trade header, 32 bytes, read once per trade with scalar loads.
 struct TradeHeader {
@@ -27,7 +28,7 @@ static_assert(sizeof(TradeHeader) == 32, "TradeHeader must stay 32 bytes");
 // Trade arrays in HBM: struct-of-arrays over the flattened (trade x cash flow) axis, so that the
 // lanes of a wavefront read consecutive doubles.
 struct TradesDev {
-    int64_t n;
+    int64_t n;                   // trades in the batch
     const TradeHeader* header;   // [n]
     const double* fix_tp;        // [sum n_fix]
     const double* fix_pay;
@@ -35,18 +36,31 @@ struct TradesDev {
     const double* flt_ts;
     const double* flt_te;
     const double* flt_alpha;
+    // The launch covers n_list trades: list[i] when list != null, else trade i.
+    const int32_t* list;
+    int64_t n_list;
 };
 
-// Curve tables in HBM (copied to LDS by every block, except lc_lanes which streams from L2).
+// Curve tables in HBM.
 struct CurveDev {
     int K, Kc, P, method;
     const double* x;             // [K]
     const double* log_df;        // [Kc]
     const double* inv_x;         // [Kc]
-    const double* lj;            // [Kc][32]
-    const double* lc_lanes;      // [Kc][64][16], null without gamma
     const int16_t* first_of;     // [K]
     const int16_t* compact_of;   // [K]
+    // general kernel: dense 32-wide tables
+    const double* lj;            // [Kc][32]
+    const double* lc_lanes;      // [Kc][64][16], null without gamma
+    // fast kernels: packed layout (curve_tables.hpp), valid when packed_ok
+    int packed_ok, Pc, pc_pad, Ec, Eu, epl, Kcore, n_mini;
+    const double* ljc;           // [Kcore][pc_pad]
+    const double* lcc;           // [Kcore][Ec + 1] (last entry of every row is 0), null without gamma
+    const MiniKnot* mini;        // [n_mini]
+    const int16_t* knot_class;   // [Kc]
+    const int16_t* pillar_to_core;  // [32]
+    const int16_t* out_map;      // [32*32]
+    const uint8_t* ent_pq;       // [Eu][2]
 };
 
 struct OutputsDev {
@@ -56,10 +70,13 @@ struct OutputsDev {
     double* block_partials;  // [grid][kAggStride] or null
 };
 
-size_t price_kernel_lds_bytes(int K, int Kc);
-hipError_t set_price_kernel_lds_limit(size_t bytes);
-hipError_t launch_price(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
-                        bool want_gamma, int n_blocks, hipStream_t stream);
+size_t general_kernel_lds_bytes(int K, int Kc);
+size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma);
+hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes);
+hipError_t launch_price_general(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
+                                bool want_gamma, int n_blocks, hipStream_t stream);
+hipError_t launch_price_fast(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
+                             bool want_gamma, int n_blocks, hipStream_t stream);
 hipError_t launch_reduce_partials(const double* partials, int n_blocks, int P, double* agg, hipStream_t stream);
 
 }  // namespace adr

@@ -1,4 +1,7 @@
-// CDNA4 (gfx950) kernels: PV, pillar delta ladder and pillar x pillar gamma of OIS trades.
+// CDNA4 (gfx950) GENERAL kernel: PV, pillar delta ladder and pillar x pillar gamma of OIS trades with no
+// assumption on the curve's structure or the trade's cash flows.  It serves the trades the fast kernel
+// (kernels_fast.hip) does not take: coupons with a payment lag (ratio terms) and curves without the sparse
+// pillar-support structure.  Dense 32-wide tables: LJ in LDS, LC tiles streamed from L2.
 //
 // What is computed (reference: cavour/market/position/engine.py:2414-2448 fixed leg, :2639-2728 float
 // leg, :2541-2576 / :2899-2934 Greeks assembly; curve lookups: cavour/market/curves/
@@ -32,6 +35,7 @@ namespace adr {
 
 namespace {
 
+constexpr int kBlockThreads = kGeneralThreads;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 
 __device__ __forceinline__ int readlane_i(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
@@ -183,7 +187,7 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
 }
 
 template <bool DELTA, bool GAMMA>
-__global__ __launch_bounds__(kBlockThreads) void price_trades_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
+__global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS carve-up: doubles first (16-byte aligned base), then the int16 index tables
     double* s_x = reinterpret_cast<double*>(smem_raw);
@@ -220,7 +224,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_trades_kernel(CurveDev cv
     total.clear();
 
     const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-    for (int64_t t = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; t < tr.n; t += wave_stride) {
+    for (int64_t it = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; it < tr.n_list; it += wave_stride) {
+        const int64_t t = tr.list ? static_cast<int64_t>(tr.list[it]) : it;
         const TradeHeader h = tr.header[t];
         const double N = h.notional, spread = h.spread;
         const double sl = static_cast<double>(h.flt_sign), sf = static_cast<double>(h.fix_sign);
@@ -391,24 +396,9 @@ __global__ __launch_bounds__(kBlockThreads) void price_trades_kernel(CurveDev cv
     }
 }
 
-// Fixed-order sum of the block partials -> agg[1 + P + P*P]; one thread per output, blocks summed in
-// index order so the aggregate does not depend on scheduling.
-__global__ void reduce_partials_kernel(const double* partials, int n_blocks, int P, double* agg) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_out = 1 + P + P * P;
-    if (i >= n_out) return;
-    int src;
-    if (i == 0) src = 0;
-    else if (i < 1 + P) src = i;
-    else { const int r = (i - 1 - P) / P, q = (i - 1 - P) % P; src = 1 + kPillarPad + r * kPillarPad + q; }
-    double s = 0.0;
-    for (int b = 0; b < n_blocks; ++b) s += partials[static_cast<size_t>(b) * kAggStride + src];
-    agg[i] = s;
-}
-
 }  // namespace
 
-size_t price_kernel_lds_bytes(int K, int Kc) {
+size_t general_kernel_lds_bytes(int K, int Kc) {
     size_t tables = sizeof(double) * (static_cast<size_t>(K) + 2 * Kc + static_cast<size_t>(Kc) * kPillarPad +
                                       kWavesPerBlock * kPillarPad) + sizeof(int16_t) * 2 * static_cast<size_t>(K);
     size_t reduce = sizeof(double) * kWavesPerBlock * kAggStride;
@@ -416,37 +406,29 @@ size_t price_kernel_lds_bytes(int K, int Kc) {
     return (need + 15) & ~static_cast<size_t>(15);
 }
 
-hipError_t launch_price(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
-                        bool want_gamma, int n_blocks, hipStream_t stream) {
-    const size_t lds = price_kernel_lds_bytes(cv.K, cv.Kc);
+hipError_t launch_price_general(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
+                                bool want_gamma, int n_blocks, hipStream_t stream) {
+    const size_t lds = general_kernel_lds_bytes(cv.K, cv.Kc);
     dim3 grid(n_blocks), block(kBlockThreads);
     if (want_gamma) {
-        hipLaunchKernelGGL((price_trades_kernel<true, true>), grid, block, lds, stream, cv, tr, out);
+        hipLaunchKernelGGL((price_general_kernel<true, true>), grid, block, lds, stream, cv, tr, out);
     } else if (want_delta) {
-        hipLaunchKernelGGL((price_trades_kernel<true, false>), grid, block, lds, stream, cv, tr, out);
+        hipLaunchKernelGGL((price_general_kernel<true, false>), grid, block, lds, stream, cv, tr, out);
     } else {
-        hipLaunchKernelGGL((price_trades_kernel<false, false>), grid, block, lds, stream, cv, tr, out);
+        hipLaunchKernelGGL((price_general_kernel<false, false>), grid, block, lds, stream, cv, tr, out);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_partials(const double* partials, int n_blocks, int P, double* agg, hipStream_t stream) {
-    const int n_out = 1 + P + P * P;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, partials, n_blocks,
-                       P, agg);
-    return hipGetLastError();
-}
-
-hipError_t set_price_kernel_lds_limit(size_t bytes) {
-    hipError_t e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&price_trades_kernel<true, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&price_trades_kernel<true, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&price_trades_kernel<false, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+hipError_t set_general_kernel_lds_limit(size_t bytes) {
+    const void* fns[] = {reinterpret_cast<const void*>(&price_general_kernel<true, true>),
+                         reinterpret_cast<const void*>(&price_general_kernel<true, false>),
+                         reinterpret_cast<const void*>(&price_general_kernel<false, false>)};
+    for (const void* f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace adr

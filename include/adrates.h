@@ -96,6 +96,15 @@ int adr_curve_tables_host(int K, int P, const double* times, const double* dfs,
                           int32_t* knot_index, double* log_df, double* lj, double* lc);
 
 /*
+ * Diagnostic twin of adr_curve_tables_host: how the fast kernels would lay this curve out in LDS.
+ * info[8] = { packed layout usable (0/1), core pillars Pc, core pairs Ec, packed entries Eu,
+ *             entries per lane, core-table rows, short-end (mini) knots, LDS bytes of the gamma kernel }.
+ * Returns 0 or a negative status.  No GPU needed.
+ */
+int adr_curve_layout_host(int K, int P, const double* times, const double* dfs,
+                          const double* jac, const double* hess, int64_t* info);
+
+/*
  * A batch of OIS trades in CSR form - the per-trade arrays the reference engine
  * extracts from the leg objects (engine.py:2519-2527 fixed, :2858-2877 float):
  *   fix_off/flt_off [n+1]  offsets into the cash-flow arrays (fix_off[0] = flt_off[0] = 0)
