@@ -142,46 +142,43 @@ struct Ladders {
 // Per-lane constants of the packed layout.
 template <int EPL>
 struct PackedLane {
-    int pil;          // pillar this lane accumulates delta for
-    int col;          // its column in ljc (the zero column outside the core)
-    int p[EPL], q[EPL];      // pillars of packed entry lane + 64 s (255: no entry)
-    int cp[EPL], cq[EPL];    // their ljc columns
-    int ec[EPL];             // index into an lcc row (the trailing zero for non core-pair entries)
+    int pil;                 // pillar this lane builds v for (lanes 32..63 duplicate 0..31)
+    int col;                 // its column in ljc (the zero column outside the core)
+    int up[EPL];             // p and q of packed entry lane + 64 s (entry 0's when there is none)
+    int vq[EPL];
 };
 
-// One knot's share of a node: v (delta lane), vp/vq (the two pillars of each packed entry), lc.
-template <bool GAMMA, int EPL>
-__device__ __forceinline__ void knot_terms(int cls, double b, const CurveLds& c, const PackedLane<EPL>& pl, int lane,
-                                           double& v, double (&vp)[EPL], double (&vq)[EPL], double (&lc)[EPL]) {
-    if (cls >= 0) {                     // core knot: rows of the LDS tables
-        const double* lj = c.ljc + cls * c.pc_pad;
-        v = fma(b, lj[pl.col], v);
-        if (GAMMA) {
-            const double* lcr = c.lcc + cls * c.ec_stride;
-#pragma unroll
-            for (int s = 0; s < EPL; ++s) {
-                vp[s] = fma(b, lj[pl.cp[s]], vp[s]);
-                vq[s] = fma(b, lj[pl.cq[s]], vq[s]);
-                lc[s] = fma(b, lcr[pl.ec[s]], lc[s]);
-            }
-        }
-    } else if (cls <= -3) {             // short-end knot: at most two pillars, three second derivatives
+// v_p = d lnD / d r_p share of one knot for this lane's pillar.
+__device__ __forceinline__ double knot_v(int cls, double b, const CurveLds& c, int col, int pil, double v) {
+    if (cls >= 0) return fma(b, c.ljc[cls * c.pc_pad + col], v);
+    if (cls <= -3) {
         const MiniKnot& m = c.mini[-3 - cls];
-        const int p0 = m.p[0], p1 = m.p[1];
-        const double j0 = m.lj[0], j1 = m.lj[1];
-        v = fma(b, pl.pil == p0 ? j0 : (pl.pil == p1 ? j1 : 0.0), v);
-        if (GAMMA) {
-            const int e0 = m.e[0], e1 = m.e[1], e2 = m.e[2];
-            const double c0 = m.lc[0], c1 = m.lc[1], c2 = m.lc[2];
+        return fma(b, pil == m.p[0] ? m.lj[0] : (pil == m.p[1] ? m.lj[1] : 0.0), v);
+    }
+    return v;
+}
+
+// Second-derivative share of one knot: coef * LC[knot] added to the packed entries.
+// Core knots stream a contiguous row (entry lane + 64 s sits at row[lane + 64 s]); lanes whose entry is
+// not a core pair pick up whatever follows the row - those lanes' `lc` sums are discarded at the end.
+template <int EPL>
+__device__ __forceinline__ void knot_lc(int cls, double coef, const CurveLds& c, int lane, double (&lc)[EPL],
+                                        double (&lc_mini)[EPL]) {
+    if (cls >= 0) {
+        const double* row = c.lcc + cls * c.ec_stride + lane;
 #pragma unroll
-            for (int s = 0; s < EPL; ++s) {
-                const int e = lane + 64 * s;
-                vp[s] = fma(b, pl.p[s] == p0 ? j0 : (pl.p[s] == p1 ? j1 : 0.0), vp[s]);
-                vq[s] = fma(b, pl.q[s] == p0 ? j0 : (pl.q[s] == p1 ? j1 : 0.0), vq[s]);
-                lc[s] = fma(b, e == e0 ? c0 : (e == e1 ? c1 : (e == e2 ? c2 : 0.0)), lc[s]);
-            }
+        for (int s = 0; s < EPL; ++s) lc[s] = fma(coef, row[64 * s], lc[s]);
+    } else if (cls <= -3) {
+        const MiniKnot& m = c.mini[-3 - cls];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int e = __builtin_amdgcn_readfirstlane(m.e[i]);      // wave-uniform entry, -1 when unused
+            const double val = coef * m.lc[i];
+#pragma unroll
+            for (int s = 0; s < EPL; ++s)
+                if ((e >> 6) == s && lane == (e & 63)) lc_mini[s] += val;
         }
-    }                                   // cls == -2: nothing depends on this knot
+    }
 }
 
 template <bool DELTA, bool GAMMA, int EPL>
@@ -198,7 +195,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     double* s_invx = s_log + cv.Kc;
     double* s_ljc = s_invx + cv.Kc;
     double* s_lcc = s_ljc + n_ljc;
-    double* s_stage = s_lcc + n_lcc;
+    double* s_uv = s_lcc + n_lcc;                         // [waves][2][32]: u = omega*v and v of the current node
+    double* s_stage = s_uv + (GAMMA ? kWavesPerBlock * 2 * kPillarPad : 0);
     int16_t* s_first = reinterpret_cast<int16_t*>(s_stage + kWavesPerBlock * stage_stride);
     int16_t* s_comp = s_first + cv.K;
     int16_t* s_class = s_comp + cv.K;
@@ -230,6 +228,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar header loads
     double* stage = s_stage + wave * stage_stride;
+    double* ubuf = s_uv + wave * 2 * kPillarPad;
+    double* vbuf = ubuf + kPillarPad;
     const int P = cv.P;
     const int bi = lane >> 3, bj = lane & 7;
 
@@ -240,11 +240,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     for (int s = 0; s < EPL; ++s) {
         const int e = lane + 64 * s;
         const bool on = GAMMA && e < cv.Eu;
-        pl.p[s] = on ? cv.ent_pq[2 * e] : 255;
-        pl.q[s] = on ? cv.ent_pq[2 * e + 1] : 255;
-        pl.cp[s] = on ? cv.pillar_to_core[pl.p[s]] : cv.Pc;
-        pl.cq[s] = on ? cv.pillar_to_core[pl.q[s]] : cv.Pc;
-        pl.ec[s] = (on && e < cv.Ec) ? e : cv.Ec;
+        pl.up[s] = on ? cv.ent_pq[2 * e] : 0;
+        pl.vq[s] = on ? cv.ent_pq[2 * e + 1] : 0;
     }
     int omap[GAMMA ? kGammaPerLane : 1];
     if (GAMMA) {
@@ -271,6 +268,9 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 
         Ladders<GAMMA, EPL> acc;
         acc.clear();
+        double lc_sum[GAMMA ? EPL : 1], lc_mini[GAMMA ? EPL : 1];
+#pragma unroll
+        for (int s = 0; s < (GAMMA ? EPL : 1); ++s) { lc_sum[s] = 0.0; lc_mini[s] = 0.0; }
 
         // Two kinds of lookup passes: float chunks (payment nodes + start nodes in the spare lanes) and
         // fixed chunks (only the fixed coupons that did not merge into a float payment node).
@@ -352,18 +352,26 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                     if (ca == -2 && cb == -2) continue;          // e.g. the start node at t = 0
                     const double om = readlane_d(omega, n);
                     const double wa = readlane_d(ba, n), wb = readlane_d(bb, n);
-                    double v = 0.0, vp[EPL], vq[EPL], lc[EPL];
-#pragma unroll
-                    for (int s = 0; s < EPL; ++s) { vp[s] = 0.0; vq[s] = 0.0; lc[s] = 0.0; }
-                    knot_terms<GAMMA, EPL>(ca, wa, c, pl, lane, v, vp, vq, lc);
-                    knot_terms<GAMMA, EPL>(cb, wb, c, pl, lane, v, vp, vq, lc);
+                    const double v = knot_v(cb, wb, c, pl.col, pl.pil, knot_v(ca, wa, c, pl.col, pl.pil, 0.0));
                     acc.delta = fma(om, v, acc.delta);
                     if (GAMMA) {
+                        // rank-1 part: hand v (and omega*v) to all lanes through the wave's LDS slot
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < 32) { ubuf[lane] = om * v; vbuf[lane] = v; }
+                        wave_lds_sync();
 #pragma unroll
-                        for (int s = 0; s < EPL; ++s) acc.gamma[s] = fma(om, fma(vp[s], vq[s], lc[s]), acc.gamma[s]);
+                        for (int s = 0; s < EPL; ++s) acc.gamma[s] = fma(ubuf[pl.up[s]], vbuf[pl.vq[s]], acc.gamma[s]);
+                        // curve-convexity part
+                        knot_lc<EPL>(ca, om * wa, c, lane, lc_sum, lc_mini);
+                        knot_lc<EPL>(cb, om * wb, c, lane, lc_sum, lc_mini);
                     }
                 }
             }
+        }
+        if (GAMMA) {   // fold the core rows' convexity sums in; only core-pair entries are meaningful
+#pragma unroll
+            for (int s = 0; s < EPL; ++s)
+                acc.gamma[s] += lc_mini[s] + (lane + 64 * s < cv.Ec ? lc_sum[s] : 0.0);
         }
 
         // ---------------------------------------------------------------- results of this trade
@@ -484,7 +492,8 @@ void launch_epl(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, 
 size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
     const size_t stage_stride = gamma ? ((cv.Eu + 1) & ~1) : 0;
     size_t doubles = static_cast<size_t>(cv.K) + 2 * cv.Kc + static_cast<size_t>(cv.Kcore) * cv.pc_pad +
-                     (gamma ? static_cast<size_t>(cv.Kcore) * (cv.Ec + 1) : 0) + kWavesPerBlock * stage_stride;
+                     (gamma ? static_cast<size_t>(cv.Kcore) * (cv.Ec + 1) + kWavesPerBlock * 2 * kPillarPad : 0) +
+                     kWavesPerBlock * stage_stride + 64 * 9;   // slack: convexity rows are read 64*EPL wide
     size_t tables = sizeof(MiniKnot) * cv.n_mini + sizeof(double) * doubles +
                     sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + cv.Kc);
     size_t reduce = sizeof(double) * kWavesPerBlock * kAggStride;
