@@ -121,6 +121,9 @@ bool build_packed_layout(CurveTables& t) {
             t.ent_pq.push_back(static_cast<uint8_t>(core_pillars[i]));
             t.ent_pq.push_back(static_cast<uint8_t>(core_pillars[j]));
         }
+    // Fringe entries start on a 64-entry boundary so that no lane slot mixes core pairs (whose convexity
+    // rows are read as contiguous 64-wide slices) with fringe pairs; the entries in between are unused.
+    while ((t.ent_pq.size() / 2) % 64 != 0) { t.ent_pq.push_back(0); t.ent_pq.push_back(0); }
     auto add_pairs = [&](uint32_t S) {
         for (int p = 0; p < P; ++p) {
             if (!(S & (1u << p))) continue;

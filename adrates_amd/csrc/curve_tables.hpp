@@ -54,7 +54,7 @@ struct CurveTables {
     int Pc = 0;                        // pillars in the core set
     int pc_pad = 0;                    // row stride of ljc: >= Pc + 1 (column Pc is all zero), even
     int Ec = 0;                        // Pc*(Pc+1)/2 core x core pairs = the first Ec packed entries
-    int Eu = 0;                        // all packed entries: core pairs, then the fringe pairs
+    int Eu = 0;                        // all packed entries: core pairs, padding to a multiple of 64, fringe pairs
     int epl = 0;                       // packed entries per lane the kernel is instantiated for (Eu <= 64*epl)
     int Kcore = 0;                     // rows of ljc / lcc
     int n_mini = 0;                    // knots with at most two pillars outside the core

@@ -5,11 +5,15 @@
 
 #include "curve_tables.hpp"
 
+#ifndef ADR_FAST_THREADS
+#define ADR_FAST_THREADS 768
+#endif
+
 namespace adr {
 
 constexpr int kAggStride = 1 + kPillarPad + kPillarPad * kPillarPad; // padded [pv, delta, gamma] record
 constexpr int kGeneralThreads = 256;                                 // general kernel: 4 wavefronts per block
-constexpr int kFastThreads = 512;                                    // fast kernel: 8 wavefronts per block
+constexpr int kFastThreads = ADR_FAST_THREADS;                                   // fast kernel: 8 wavefronts per block
 
 // Per-trade header, 32 bytes, read once per trade with scalar loads.
 struct TradeHeader {

@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace adr {
@@ -73,6 +75,7 @@ struct CurveLds {
     const int16_t* compact_of;  // [K]
     const int16_t* knot_class;  // [Kc]
     int K, method, pc_pad, ec_stride;
+    int core_slots;             // 64-entry slots that hold core pairs: ceil(Ec / 64)
 };
 
 struct Lookup {
@@ -159,15 +162,16 @@ __device__ __forceinline__ double knot_v(int cls, double b, const CurveLds& c, i
 }
 
 // Second-derivative share of one knot: coef * LC[knot] added to the packed entries.
-// Core knots stream a contiguous row (entry lane + 64 s sits at row[lane + 64 s]); lanes whose entry is
-// not a core pair pick up whatever follows the row - those lanes' `lc` sums are discarded at the end.
+// A core knot's row is contiguous: entry lane + 64 s sits at row[lane + 64 s] for the slots that hold core
+// pairs.  The last of those slots is only partly used by core pairs; its other lanes pick up whatever
+// follows the row (finite numbers: the next row or the zero slack) into entries nothing ever reads.
 template <int EPL>
-__device__ __forceinline__ void knot_lc(int cls, double coef, const CurveLds& c, int lane, double (&lc)[EPL],
-                                        double (&lc_mini)[EPL]) {
+__device__ __forceinline__ void knot_lc(int cls, double coef, const CurveLds& c, int lane, double (&gamma)[EPL]) {
     if (cls >= 0) {
         const double* row = c.lcc + cls * c.ec_stride + lane;
 #pragma unroll
-        for (int s = 0; s < EPL; ++s) lc[s] = fma(coef, row[64 * s], lc[s]);
+        for (int s = 0; s < EPL; ++s)
+            if (s < c.core_slots) gamma[s] = fma(coef, row[64 * s], gamma[s]);
     } else if (cls <= -3) {
         const MiniKnot& m = c.mini[-3 - cls];
 #pragma unroll
@@ -176,7 +180,7 @@ __device__ __forceinline__ void knot_lc(int cls, double coef, const CurveLds& c,
             const double val = coef * m.lc[i];
 #pragma unroll
             for (int s = 0; s < EPL; ++s)
-                if ((e >> 6) == s && lane == (e & 63)) lc_mini[s] += val;
+                if ((e >> 6) == s && lane == (e & 63)) gamma[s] += val;
         }
     }
 }
@@ -188,18 +192,20 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     const int ec_stride = cv.Ec + 1;
     const int n_ljc = cv.Kcore * cv.pc_pad;
     const int n_lcc = GAMMA ? cv.Kcore * ec_stride : 0;
-    const int stage_stride = GAMMA ? ((cv.Eu + 1) & ~1) : 0;
+    const int n_slack = GAMMA ? 64 * EPL : 0;            // zeros behind the last row (rows are read 64 wide)
+    const int stage_stride = GAMMA ? max((cv.Eu + 1) & ~1, 2 * kPillarPad) : 0;
     MiniKnot* s_mini = reinterpret_cast<MiniKnot*>(smem_raw);
     double* s_x = reinterpret_cast<double*>(s_mini + cv.n_mini);
     double* s_log = s_x + cv.K;
     double* s_invx = s_log + cv.Kc;
     double* s_ljc = s_invx + cv.Kc;
     double* s_lcc = s_ljc + n_ljc;
-    double* s_uv = s_lcc + n_lcc;                         // [waves][2][32]: u = omega*v and v of the current node
-    double* s_stage = s_uv + (GAMMA ? kWavesPerBlock * 2 * kPillarPad : 0);
+    double* s_stage = s_lcc + n_lcc + n_slack;                      // per wave: packed ladder at output time; its first
+                                                          // 64 doubles double as the node hand-off buffers u, v
     int16_t* s_first = reinterpret_cast<int16_t*>(s_stage + kWavesPerBlock * stage_stride);
     int16_t* s_comp = s_first + cv.K;
     int16_t* s_class = s_comp + cv.K;
+    int16_t* s_omap = s_class + cv.Kc;                    // [32*32] packed entry of gamma[r][c], -1 if none
 
     {
         const double* src = reinterpret_cast<const double*>(cv.mini);
@@ -216,19 +222,23 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
         s_invx[i] = cv.inv_x[i];
         s_class[i] = cv.knot_class[i];
     }
+    if (GAMMA)
+        for (int i = threadIdx.x; i < kPillarPad * kPillarPad; i += kBlockThreads) s_omap[i] = cv.out_map[i];
     for (int i = threadIdx.x; i < n_ljc; i += kBlockThreads) s_ljc[i] = cv.ljc[i];
     for (int i = threadIdx.x; i < n_lcc; i += kBlockThreads) s_lcc[i] = cv.lcc[i];
+    for (int i = threadIdx.x; i < n_slack; i += kBlockThreads) s_lcc[n_lcc + i] = 0.0;
     __syncthreads();
 
     CurveLds c;
     c.x = s_x; c.log_df = s_log; c.inv_x = s_invx; c.ljc = s_ljc; c.lcc = s_lcc; c.mini = s_mini;
     c.first_of = s_first; c.compact_of = s_comp; c.knot_class = s_class;
     c.K = cv.K; c.method = cv.method; c.pc_pad = cv.pc_pad; c.ec_stride = ec_stride;
+    c.core_slots = (cv.Ec + 63) >> 6;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar header loads
     double* stage = s_stage + wave * stage_stride;
-    double* ubuf = s_uv + wave * 2 * kPillarPad;
+    double* ubuf = stage;
     double* vbuf = ubuf + kPillarPad;
     const int P = cv.P;
     const int bi = lane >> 3, bj = lane & 7;
@@ -243,12 +253,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
         pl.up[s] = on ? cv.ent_pq[2 * e] : 0;
         pl.vq[s] = on ? cv.ent_pq[2 * e + 1] : 0;
     }
-    int omap[GAMMA ? kGammaPerLane : 1];
-    if (GAMMA) {
-#pragma unroll
-        for (int e = 0; e < kGammaPerLane; ++e)
-            omap[e] = cv.out_map[(4 * bi + (e >> 2)) * kPillarPad + 4 * bj + (e & 3)];
-    }
+    // this lane's 4x4 block of the output matrix starts at row 4*bi, column 4*bj
+    const int16_t* omap = s_omap + (4 * bi) * kPillarPad + 4 * bj;
 
     Ladders<GAMMA, EPL> total;   // this wave's share of the portfolio aggregate
     total.clear();
@@ -268,9 +274,6 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 
         Ladders<GAMMA, EPL> acc;
         acc.clear();
-        double lc_sum[GAMMA ? EPL : 1], lc_mini[GAMMA ? EPL : 1];
-#pragma unroll
-        for (int s = 0; s < (GAMMA ? EPL : 1); ++s) { lc_sum[s] = 0.0; lc_mini[s] = 0.0; }
 
         // Two kinds of lookup passes: float chunks (payment nodes + start nodes in the spare lanes) and
         // fixed chunks (only the fixed coupons that did not merge into a float payment node).
@@ -362,18 +365,12 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 #pragma unroll
                         for (int s = 0; s < EPL; ++s) acc.gamma[s] = fma(ubuf[pl.up[s]], vbuf[pl.vq[s]], acc.gamma[s]);
                         // curve-convexity part
-                        knot_lc<EPL>(ca, om * wa, c, lane, lc_sum, lc_mini);
-                        knot_lc<EPL>(cb, om * wb, c, lane, lc_sum, lc_mini);
+                        knot_lc<EPL>(ca, om * wa, c, lane, acc.gamma);
+                        knot_lc<EPL>(cb, om * wb, c, lane, acc.gamma);
                     }
                 }
             }
         }
-        if (GAMMA) {   // fold the core rows' convexity sums in; only core-pair entries are meaningful
-#pragma unroll
-            for (int s = 0; s < EPL; ++s)
-                acc.gamma[s] += lc_mini[s] + (lane + 64 * s < cv.Ec ? lc_sum[s] : 0.0);
-        }
-
         // ---------------------------------------------------------------- results of this trade
         const double pv = wave_sum(acc.pv);
         if (lane == 0) {
@@ -401,7 +398,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                     double gv[4];
 #pragma unroll
                     for (int jx = 0; jx < 4; ++jx) {
-                        const int m = omap[i * 4 + jx];
+                        const int m = omap[i * kPillarPad + jx];
                         gv[jx] = m >= 0 ? stage[m] * 1e-8 : 0.0;
                     }
                     if (r < P) {
@@ -430,7 +427,10 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                 if (lane + 64 * s < cv.Eu) stage[lane + 64 * s] = total.gamma[s];
             wave_lds_sync();
 #pragma unroll
-            for (int e = 0; e < kGammaPerLane; ++e) tot_gamma[e] = omap[e] >= 0 ? stage[omap[e]] * 1e-8 : 0.0;
+            for (int e = 0; e < kGammaPerLane; ++e) {
+                const int m = omap[(e >> 2) * kPillarPad + (e & 3)];
+                tot_gamma[e] = m >= 0 ? stage[m] * 1e-8 : 0.0;
+            }
         }
         __syncthreads();   // every wave is done with the curve tables; reuse the LDS for the reduction
         double* red = reinterpret_cast<double*>(smem_raw);   // [waves][kAggStride]
@@ -490,12 +490,12 @@ void launch_epl(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, 
 }  // namespace
 
 size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
-    const size_t stage_stride = gamma ? ((cv.Eu + 1) & ~1) : 0;
+    const size_t stage_stride = gamma ? std::max<size_t>((cv.Eu + 1) & ~1, 2 * kPillarPad) : 0;
     size_t doubles = static_cast<size_t>(cv.K) + 2 * cv.Kc + static_cast<size_t>(cv.Kcore) * cv.pc_pad +
-                     (gamma ? static_cast<size_t>(cv.Kcore) * (cv.Ec + 1) + kWavesPerBlock * 2 * kPillarPad : 0) +
+                     (gamma ? static_cast<size_t>(cv.Kcore) * (cv.Ec + 1) : 0) +
                      kWavesPerBlock * stage_stride + 64 * 9;   // slack: convexity rows are read 64*EPL wide
     size_t tables = sizeof(MiniKnot) * cv.n_mini + sizeof(double) * doubles +
-                    sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + cv.Kc);
+                    sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + cv.Kc + (gamma ? kPillarPad * kPillarPad : 0));
     size_t reduce = sizeof(double) * kWavesPerBlock * kAggStride;
     size_t need = tables > reduce ? tables : reduce;
     return (need + 15) & ~static_cast<size_t>(15);
