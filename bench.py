@@ -47,6 +47,23 @@ def cpu_baseline(curve, value_dt, interp_value, want_gamma, budget_s):
     return cpu_port.timed_baseline(curve, value_dt, interp_value, want_gamma, budget_s)
 
 
+def measured_traffic(n, want_gamma, kind, interp):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command
+    (tools/profile.sh + tools/profile_summary.py -> profiles/*_traffic.json), or None when the workload
+    differs from the profiled one.  bench.py cannot run the profiler on itself."""
+    import glob
+    if not (n == 1_000_000 and want_gamma and kind == "offgrid" and interp == "LINEAR_ZERO_RATES"):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return float(json.load(f)["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     import numpy as np
@@ -152,7 +169,8 @@ def main():
                        "requests": sorted(reqs), "parallelism": f"trade-axis shard x{world}, RCCL all-reduce of "
                                                                f"{1 + P + P * P} doubles"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(n, want_gamma, args.kind, args.interp),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_bytes_per_trade": algo_bytes / n},
         }

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Run on the GPU box (gpurun -- 'bash tools/profile.sh TAG'): kernel-trace stats and, in separate passes as the
+# MI355X guide prescribes, the HBM traffic counters of the same bench command.  Summaries land in gpurun_out/.
+TAG=${1:-run}
+OUT=/root/repo/gpurun_out/prof_$TAG
+cd /tmp && export TMPDIR=/tmp
+CMD="python3 /root/repo/bench.py --steps 5 --warmup 1 --cpu-baseline-seconds 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT.trace.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT.fetch.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT.write.log 2>&1

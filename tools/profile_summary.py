@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_TAG/{trace,fetch,write} into profiles/rNN_TAG_* summaries (kernel stats CSV + traffic JSON).
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are collected in
+separate passes, are in KiB, and on gfx950 FETCH_SIZE reports half the bytes of a coalesced streaming read, so
+read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact for 16-byte-per-lane stores (the gamma rows)."""
+import csv, glob, json, shutil, sys
+tag, rnd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r01")
+base = f"gpurun_out/prof_{tag}"
+stats = glob.glob(f"{base}/trace/*/*kernel_stats.csv")[0]
+shutil.copy(stats, f"profiles/{rnd}_{tag}_kernel_stats.csv")
+out = {"tag": tag}
+for name in ("fetch", "write"):
+    vals = {}
+    for r in csv.DictReader(open(glob.glob(f"{base}/{name}/*/*counter_collection.csv")[0])):
+        if "price_fast" in r["Kernel_Name"] or "price_general" in r["Kernel_Name"]:
+            vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, v in vals.items():
+        out[k + "_KiB_per_launch"] = sum(v) / len(v)
+for r in csv.DictReader(open(stats)):
+    if "price_fast" in r["Name"]:
+        out["kernel"] = r["Name"].split("(")[0]
+        out["avg_ns"] = float(r["AverageNs"]); out["calls"] = int(r["Calls"])
+rd = 2.0 * out.get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024
+wr = out.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
+out.update(read_bytes_corrected=rd, write_bytes=wr, hbm_bytes_per_launch=rd + wr,
+           note="read = 2 x FETCH_SIZE x 1024 (gfx950 half-count correction), write = WRITE_SIZE x 1024")
+json.dump(out, open(f"profiles/{rnd}_{tag}_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
