@@ -178,8 +178,10 @@ bool build_packed_layout(CurveTables& t) {
     }
     t.n_mini = static_cast<int>(t.mini.size());
 
-    t.ljc.assign(static_cast<size_t>(t.Kcore) * t.pc_pad, 0.0);
-    t.lcc.assign(t.has_hess ? static_cast<size_t>(t.Kcore) * (Ec + 1) : 0, 0.0);   // trailing 0 per row
+    // one extra all-zero row (index Kcore) stands in for knots nothing depends on, so the kernel's hot loop
+    // needs no branch for them
+    t.ljc.assign(static_cast<size_t>(t.Kcore + 1) * t.pc_pad, 0.0);
+    t.lcc.assign(t.has_hess ? static_cast<size_t>(t.Kcore + 1) * (Ec + 1) : 0, 0.0);   // trailing 0 per row
     for (int c = 0; c < Kc; ++c) {
         const int row = t.knot_class[c];
         if (row < 0) continue;

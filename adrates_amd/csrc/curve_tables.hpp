@@ -60,8 +60,8 @@ struct CurveTables {
     int n_mini = 0;                    // knots with at most two pillars outside the core
     std::vector<int16_t> pillar_to_core;   // [32]   core column of pillar p; Pc (the zero column) outside the core
     std::vector<int16_t> knot_class;       // [Kc]   >= 0: core row; -2: all-zero knot; <= -3: mini record -3 - m
-    std::vector<double> ljc;               // [Kcore][pc_pad]  LJ on the core pillars
-    std::vector<double> lcc;               // [Kcore][Ec + 1]  LC on the packed core x core pairs, then a 0
+    std::vector<double> ljc;               // [Kcore + 1][pc_pad]  LJ on the core pillars; last row all zero
+    std::vector<double> lcc;               // [Kcore + 1][Ec + 1]  LC on the packed core pairs, then a 0; last row zero
     std::vector<uint8_t> ent_pq;           // [Eu][2]          pillars (p <= q) of packed entry e
     std::vector<int16_t> out_map;          // [32*32]          packed entry feeding gamma[r][c], -1 if none
     std::vector<MiniKnot> mini;            // [n_mini]

@@ -190,8 +190,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS carve-up: 64-byte records, doubles, then the int16 tables
     const int ec_stride = cv.Ec + 1;
-    const int n_ljc = cv.Kcore * cv.pc_pad;
-    const int n_lcc = GAMMA ? cv.Kcore * ec_stride : 0;
+    const int n_ljc = (cv.Kcore + 1) * cv.pc_pad;          // + the all-zero row
+    const int n_lcc = GAMMA ? (cv.Kcore + 1) * ec_stride : 0;
     const int n_slack = GAMMA ? 64 * EPL : 0;            // zeros behind the last row (rows are read 64 wide)
     const int stage_stride = GAMMA ? max((cv.Eu + 1) & ~1, 2 * kPillarPad) : 0;
     MiniKnot* s_mini = reinterpret_cast<MiniKnot*>(smem_raw);
@@ -242,6 +242,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     double* vbuf = ubuf + kPillarPad;
     const int P = cv.P;
     const int bi = lane >> 3, bj = lane & 7;
+    const int zero_row = cv.Kcore;
 
     PackedLane<EPL> pl;
     pl.pil = lane & 31;
@@ -345,32 +346,58 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                     omega = qa * exp(fma(ba, c.log_df[q.ka], bb * c.log_df[q.kb]));
                     acc.pv += omega;
                 }
-                // ---- consume: one node at a time, all lanes
                 if (!DELTA) continue;
-                unsigned long long mask = mask0;
+                // Nodes whose knots are core rows (an all-zero row standing in for a knot nothing depends
+                // on) take the branch-free loop; nodes touching a short-end knot the general one.
+                const bool greeks = qon && !(cls_a == -2 && cls_b == -2);
+                const bool has_mini = cls_a <= -3 || cls_b <= -3;
+                const int row_a = cls_a >= 0 ? cls_a : zero_row, row_b = cls_b >= 0 ? cls_b : zero_row;
+                unsigned long long mask = __ballot(greeks && !has_mini);
+                while (mask) {
+                    const int n = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const int ra = readlane_i(row_a, n), rb = readlane_i(row_b, n);
+                    const double om = readlane_d(omega, n);
+                    const double wa = readlane_d(ba, n), wb = readlane_d(bb, n);
+                    const double v = fma(wb, c.ljc[rb * c.pc_pad + pl.col], wa * c.ljc[ra * c.pc_pad + pl.col]);
+                    acc.delta = fma(om, v, acc.delta);
+                    if (GAMMA) {
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < 32) { ubuf[lane] = om * v; vbuf[lane] = v; }
+                        wave_lds_sync();
+                        const double* rowa = c.lcc + ra * c.ec_stride + lane;
+                        const double* rowb = c.lcc + rb * c.ec_stride + lane;
+                        const double coa = om * wa, cob = om * wb;
+#pragma unroll
+                        for (int s = 0; s < EPL; ++s) {
+                            double g = fma(ubuf[pl.up[s]], vbuf[pl.vq[s]], acc.gamma[s]);
+                            if (s < c.core_slots) g = fma(cob, rowb[64 * s], fma(coa, rowa[64 * s], g));
+                            acc.gamma[s] = g;
+                        }
+                    }
+                }
+                mask = __ballot(greeks && has_mini);
                 while (mask) {
                     const int n = __builtin_ctzll(mask);
                     mask &= mask - 1;
                     const int ca = readlane_i(cls_a, n), cb = readlane_i(cls_b, n);
-                    if (ca == -2 && cb == -2) continue;          // e.g. the start node at t = 0
                     const double om = readlane_d(omega, n);
                     const double wa = readlane_d(ba, n), wb = readlane_d(bb, n);
                     const double v = knot_v(cb, wb, c, pl.col, pl.pil, knot_v(ca, wa, c, pl.col, pl.pil, 0.0));
                     acc.delta = fma(om, v, acc.delta);
                     if (GAMMA) {
-                        // rank-1 part: hand v (and omega*v) to all lanes through the wave's LDS slot
                         __builtin_amdgcn_wave_barrier();
                         if (lane < 32) { ubuf[lane] = om * v; vbuf[lane] = v; }
                         wave_lds_sync();
 #pragma unroll
                         for (int s = 0; s < EPL; ++s) acc.gamma[s] = fma(ubuf[pl.up[s]], vbuf[pl.vq[s]], acc.gamma[s]);
-                        // curve-convexity part
                         knot_lc<EPL>(ca, om * wa, c, lane, acc.gamma);
                         knot_lc<EPL>(cb, om * wb, c, lane, acc.gamma);
                     }
                 }
             }
         }
+
         // ---------------------------------------------------------------- results of this trade
         const double pv = wave_sum(acc.pv);
         if (lane == 0) {
@@ -491,8 +518,8 @@ void launch_epl(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, 
 
 size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
     const size_t stage_stride = gamma ? std::max<size_t>((cv.Eu + 1) & ~1, 2 * kPillarPad) : 0;
-    size_t doubles = static_cast<size_t>(cv.K) + 2 * cv.Kc + static_cast<size_t>(cv.Kcore) * cv.pc_pad +
-                     (gamma ? static_cast<size_t>(cv.Kcore) * (cv.Ec + 1) : 0) +
+    size_t doubles = static_cast<size_t>(cv.K) + 2 * cv.Kc + static_cast<size_t>(cv.Kcore + 1) * cv.pc_pad +
+                     (gamma ? static_cast<size_t>(cv.Kcore + 1) * (cv.Ec + 1) : 0) +
                      kWavesPerBlock * stage_stride + 64 * 9;   // slack: convexity rows are read 64*EPL wide
     size_t tables = sizeof(MiniKnot) * cv.n_mini + sizeof(double) * doubles +
                     sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + cv.Kc + (gamma ? kPillarPad * kPillarPad : 0));
