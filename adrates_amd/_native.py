@@ -14,7 +14,9 @@ import numpy as np
 
 from .utils.error import LibError
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadrates_hip.so")
+# ADRATES_HIP_LIB lets a tuning run point at an alternative build of the same library
+_LIB_PATH = os.environ.get("ADRATES_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                               "libadrates_hip.so")
 _lib = None
 
 REQ_VALUE, REQ_DELTA, REQ_GAMMA = 1, 2, 4

@@ -64,8 +64,9 @@ struct adr_trades {
     adr_ctx* ctx = nullptr;
     adr::TradesDev dev{};
     int64_t n_fix_flows = 0, n_flt_flows = 0;
-    // trades with a coupon whose accrual end differs from its payment time (payment lag) need the
-    // general kernel; when there are none both lists stay null and the fast kernel walks 0..n-1
+    // Trades with a coupon whose accrual end differs from its payment time (payment lag) need the general
+    // kernel (list_general, null when there are none).  list_fast holds the others sorted by coupon
+    // count, so that the trades sharing a wavefront in the fast kernel have similar lengths.
     int64_t n_fast = 0, n_general = 0;
     const int32_t* list_fast = nullptr;
     const int32_t* list_general = nullptr;
@@ -213,7 +214,8 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     c->dev.K = t.K; c->dev.Kc = t.Kc; c->dev.P = t.P; c->dev.method = interp_method;
     c->dev.x = d_x; c->dev.log_df = d_log; c->dev.inv_x = d_invx; c->dev.lj = d_lj; c->dev.lc_lanes = d_lc;
     c->dev.first_of = d_first; c->dev.compact_of = d_comp;
-    c->dev.packed_ok = t.packed_ok ? 1 : 0;
+    // the fast kernels write whole 32-wide rows; curves with fewer pillars use the general kernel
+    c->dev.packed_ok = (t.packed_ok && t.P == adr::kPillarPad) ? 1 : 0;
     c->dev.Pc = t.Pc; c->dev.pc_pad = t.pc_pad; c->dev.Ec = t.Ec; c->dev.Eu = t.Eu; c->dev.epl = t.epl;
     c->dev.Kcore = t.Kcore; c->dev.n_mini = t.n_mini;
     c->dev.ljc = d_ljc; c->dev.lcc = d_lcc; c->dev.mini = d_mini; c->dev.knot_class = d_class;
@@ -318,10 +320,11 @@ int adr_trades_upload(adr_ctx* ctx, int64_t n, const int64_t* fix_off, const int
     tr->dev.n_list = n;
     tr->n_fast = static_cast<int64_t>(list_fast.size());
     tr->n_general = static_cast<int64_t>(list_general.size());
-    if (tr->n_general > 0) {
-        tr->list_fast = static_cast<const int32_t*>(put(list_fast.data(), list_fast.size() * sizeof(int32_t)));
-        tr->list_general = static_cast<const int32_t*>(put(list_general.data(), list_general.size() * sizeof(int32_t)));
-    }
+    std::stable_sort(list_fast.begin(), list_fast.end(), [&](int32_t a, int32_t b) {
+        return hdr[static_cast<size_t>(a)].n_flt > hdr[static_cast<size_t>(b)].n_flt;
+    });
+    tr->list_fast = static_cast<const int32_t*>(put(list_fast.data(), list_fast.size() * sizeof(int32_t)));
+    tr->list_general = static_cast<const int32_t*>(put(list_general.data(), list_general.size() * sizeof(int32_t)));
     if (e != hipSuccess) { adr_free_trades(tr); return fail_hip(e, "adr_trades_upload: copying trades"); }
     *out = tr;
     return ADR_OK;
@@ -366,7 +369,8 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     if (fast.n_list > 0) {
         const size_t lds = adr::fast_kernel_lds_bytes(curve->dev, want_gamma);
         const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
-        const int64_t need = (fast.n_list + adr::kFastThreads / 64 - 1) / (adr::kFastThreads / 64);
+        const int64_t units = (fast.n_list + adr::fast_kernel_groups() - 1) / adr::fast_kernel_groups();
+        const int64_t need = (units + adr::kFastThreads / 64 - 1) / (adr::kFastThreads / 64);
         blocks_fast = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * per_cu));
     }
     if (general.n_list > 0) {

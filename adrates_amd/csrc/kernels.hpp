@@ -8,6 +8,12 @@
 #ifndef ADR_FAST_THREADS
 #define ADR_FAST_THREADS 768
 #endif
+#ifndef ADR_FAST_BATCH
+#define ADR_FAST_BATCH 4    // packed entries whose LDS operands are fetched together
+#endif
+#ifndef ADR_FAST_GROUPS
+#define ADR_FAST_GROUPS 2   // trades per wavefront in the fast kernel (2 or 4)
+#endif
 
 namespace adr {
 
@@ -76,6 +82,7 @@ struct OutputsDev {
 
 size_t general_kernel_lds_bytes(int K, int Kc);
 size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma);
+int fast_kernel_groups();
 hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes);
 hipError_t launch_price_general(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                                 bool want_gamma, int n_blocks, hipStream_t stream);

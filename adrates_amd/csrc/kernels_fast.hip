@@ -22,11 +22,18 @@
 //
 // Layout.  Everything a node touches lives in LDS: the knot search arrays, LJ restricted to the curve's
 // core pillars, LC on the packed upper triangle of core x core, and 64-byte records for the short-end
-// knots that depend on at most two par rates (curve_tables.cpp, build_packed_layout).  One 64-lane
-// wavefront prices one trade at a time: lanes = cash flows while nodes are built (coalesced loads, binary
-// search, exp), then lanes = packed gamma entries (EPL per lane) and lanes = pillars for delta while the
-// nodes are consumed, their few scalars broadcast with v_readlane.  The packed ladder is expanded to the
-// full 32x32 matrix through a per-wave LDS slot when the trade is written (full 512-byte row stores).
+// knots that depend on at most two par rates (curve_tables.cpp, build_packed_layout).
+//
+// Mapping.  OIS trades are short (15.5 coupons on average), so a 64-lane wavefront prices G trades at a
+// time, L = 64/G lanes each (the host sorts the trades by coupon count so the G trades of a wavefront
+// have similar lengths).  Inside a group: lanes = coupons while nodes are built (coalesced loads, binary
+// search in LDS, exp); then the groups walk their nodes in lockstep - node n of every group is fetched
+// from the lane that built it (ds_bpermute), lane l builds v for pillars l, l+L, ..., v and omega*v go
+// to the group's LDS slot, and every lane updates its packed gamma entries l + L*i: the rank-1 term from
+// two LDS reads, the convexity term from contiguous slices of the two knots' LC rows.  The short-end
+// knots' 2x2 convexity blocks are applied as two extra rank-1 passes, so there is a single accumulation
+// mechanism.  Each trade's packed ladder is then expanded through the wave's LDS slot to the symmetric
+// 32x32 matrix and written as full 512-byte rows.  No atomics; the aggregate is a fixed-order reduction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -41,20 +48,7 @@ namespace {
 constexpr int kBlockThreads = kFastThreads;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 
-__device__ __forceinline__ int readlane_i(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
-
-__device__ __forceinline__ double readlane_d(double x, int lane) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_readlane(lo, lane);
-    hi = __builtin_amdgcn_readlane(hi, lane);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-    return x;
-}
+__device__ __forceinline__ double shfl_d(double x, int src) { return __shfl(x, src, 64); }
 
 // Same-wave LDS hand-off: LDS operations of one wave execute in order; the fences only stop the
 // compiler from moving accesses across the hand-off point.
@@ -68,14 +62,13 @@ struct CurveLds {
     const double* x;            // [K]
     const double* log_df;       // [Kc]
     const double* inv_x;        // [Kc]
-    const double* ljc;          // [Kcore][pc_pad]
-    const double* lcc;          // [Kcore][Ec + 1]
+    const double* ljc;          // [Kcore + 1][pc_pad]
+    const double* lcc;          // [Kcore + 1][Ec + 1]
     const MiniKnot* mini;       // [n_mini]
     const int16_t* first_of;    // [K]
     const int16_t* compact_of;  // [K]
     const int16_t* knot_class;  // [Kc]
     int K, method, pc_pad, ec_stride;
-    int core_slots;             // 64-entry slots that hold core pairs: ceil(Ec / 64)
 };
 
 struct Lookup {
@@ -130,82 +123,38 @@ __device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
     return r;
 }
 
-template <bool GAMMA, int EPL>
-struct Ladders {
-    double pv;
-    double delta;                      // lane p (and p + 32, duplicated) holds pillar p
-    double gamma[GAMMA ? EPL : 1];     // packed entry lane + 64 s
-    __device__ __forceinline__ void clear() {
-        pv = 0.0; delta = 0.0;
-#pragma unroll
-        for (int s = 0; s < (GAMMA ? EPL : 1); ++s) gamma[s] = 0.0;
-    }
-};
-
-// Per-lane constants of the packed layout.
-template <int EPL>
-struct PackedLane {
-    int pil;                 // pillar this lane builds v for (lanes 32..63 duplicate 0..31)
-    int col;                 // its column in ljc (the zero column outside the core)
-    int up[EPL];             // p and q of packed entry lane + 64 s (entry 0's when there is none)
-    int vq[EPL];
-};
-
-// v_p = d lnD / d r_p share of one knot for this lane's pillar.
-__device__ __forceinline__ double knot_v(int cls, double b, const CurveLds& c, int col, int pil, double v) {
-    if (cls >= 0) return fma(b, c.ljc[cls * c.pc_pad + col], v);
-    if (cls <= -3) {
-        const MiniKnot& m = c.mini[-3 - cls];
-        return fma(b, pil == m.p[0] ? m.lj[0] : (pil == m.p[1] ? m.lj[1] : 0.0), v);
-    }
-    return v;
-}
-
-// Second-derivative share of one knot: coef * LC[knot] added to the packed entries.
-// A core knot's row is contiguous: entry lane + 64 s sits at row[lane + 64 s] for the slots that hold core
-// pairs.  The last of those slots is only partly used by core pairs; its other lanes pick up whatever
-// follows the row (finite numbers: the next row or the zero slack) into entries nothing ever reads.
-template <int EPL>
-__device__ __forceinline__ void knot_lc(int cls, double coef, const CurveLds& c, int lane, double (&gamma)[EPL]) {
-    if (cls >= 0) {
-        const double* row = c.lcc + cls * c.ec_stride + lane;
-#pragma unroll
-        for (int s = 0; s < EPL; ++s)
-            if (s < c.core_slots) gamma[s] = fma(coef, row[64 * s], gamma[s]);
-    } else if (cls <= -3) {
-        const MiniKnot& m = c.mini[-3 - cls];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int e = __builtin_amdgcn_readfirstlane(m.e[i]);      // wave-uniform entry, -1 when unused
-            const double val = coef * m.lc[i];
-#pragma unroll
-            for (int s = 0; s < EPL; ++s)
-                if ((e >> 6) == s && lane == (e & 63)) gamma[s] += val;
-        }
-    }
-}
-
-template <bool DELTA, bool GAMMA, int EPL>
+// DELTA/GAMMA: what to compute; EPL: packed entries / 64 and CS: how many of those 64-entry slots hold core
+// pairs (both curve dependent; compile-time so that the loops below have no branches); G: trades per wavefront.
+// CS == EPL is the universal variant: it reads a convexity slice for every slot and zeroes the coefficient of
+// the slots that are not core pairs at run time.
+template <bool DELTA, bool GAMMA, int EPL, int CS, int G>
 __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
+    constexpr int L = 64 / G;                          // lanes per trade
+    constexpr int PPL = kPillarPad / L;                // pillars per lane: l + L*k
+    constexpr int EPG = GAMMA ? 64 * EPL / L : 1;      // packed entries per lane: l + L*i
+    constexpr int CPG = GAMMA ? 64 * CS / L : 0;       // of which core pairs (convexity rows are read for these)
+    static_assert(kPillarPad % L == 0 && PPL >= 1, "a group must cover the pillars evenly");
+    constexpr unsigned long long kGroupMask = (L == 64) ? ~0ull : ((1ull << L) - 1);
+
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS carve-up: 64-byte records, doubles, then the int16 tables
     const int ec_stride = cv.Ec + 1;
-    const int n_ljc = (cv.Kcore + 1) * cv.pc_pad;          // + the all-zero row
+    const int n_ljc = (cv.Kcore + 1) * cv.pc_pad;            // + the all-zero row
     const int n_lcc = GAMMA ? (cv.Kcore + 1) * ec_stride : 0;
-    const int n_slack = GAMMA ? 64 * EPL : 0;            // zeros behind the last row (rows are read 64 wide)
-    const int stage_stride = GAMMA ? max((cv.Eu + 1) & ~1, 2 * kPillarPad) : 0;
+    const int n_slack = GAMMA ? 64 * EPL : 0;                // zeros behind the last row (rows are read 64*EPL wide)
+    constexpr int kSlotDoubles = GAMMA ? (64 * EPL > G * 2 * kPillarPad ? 64 * EPL : G * 2 * kPillarPad) : 0;
     MiniKnot* s_mini = reinterpret_cast<MiniKnot*>(smem_raw);
     double* s_x = reinterpret_cast<double*>(s_mini + cv.n_mini);
     double* s_log = s_x + cv.K;
     double* s_invx = s_log + cv.Kc;
     double* s_ljc = s_invx + cv.Kc;
     double* s_lcc = s_ljc + n_ljc;
-    double* s_stage = s_lcc + n_lcc + n_slack;                      // per wave: packed ladder at output time; its first
-                                                          // 64 doubles double as the node hand-off buffers u, v
-    int16_t* s_first = reinterpret_cast<int16_t*>(s_stage + kWavesPerBlock * stage_stride);
+    double* s_slot = s_lcc + n_lcc + n_slack;                // per wave: u/v hand-off buffers, reused as the
+                                                             // packed-ladder staging area at output time
+    int16_t* s_first = reinterpret_cast<int16_t*>(s_slot + kWavesPerBlock * kSlotDoubles);
     int16_t* s_comp = s_first + cv.K;
     int16_t* s_class = s_comp + cv.K;
-    int16_t* s_omap = s_class + cv.Kc;                    // [32*32] packed entry of gamma[r][c], -1 if none
+    int16_t* s_omap = s_class + cv.Kc;                       // [32*32] packed entry of gamma[r][c], -1 if none
 
     {
         const double* src = reinterpret_cast<const double*>(cv.mini);
@@ -233,108 +182,132 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     c.x = s_x; c.log_df = s_log; c.inv_x = s_invx; c.ljc = s_ljc; c.lcc = s_lcc; c.mini = s_mini;
     c.first_of = s_first; c.compact_of = s_comp; c.knot_class = s_class;
     c.K = cv.K; c.method = cv.method; c.pc_pad = cv.pc_pad; c.ec_stride = ec_stride;
-    c.core_slots = (cv.Ec + 63) >> 6;
 
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar header loads
-    double* stage = s_stage + wave * stage_stride;
-    double* ubuf = stage;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane / L, l = lane % L;
+    const int gbase = g * L;                      // first lane of this lane's group
+    double* slot = s_slot + wave * kSlotDoubles;
+    double* ubuf = slot + g * 2 * kPillarPad;     // this group's omega*v and v, 32 doubles each
     double* vbuf = ubuf + kPillarPad;
     const int P = cv.P;
     const int bi = lane >> 3, bj = lane & 7;
     const int zero_row = cv.Kcore;
+    const int core_entries = GAMMA ? (((cv.Ec + 63) >> 6) * 64) / L : 0;   // entries i < this are core pairs
 
-    PackedLane<EPL> pl;
-    pl.pil = lane & 31;
-    pl.col = cv.pillar_to_core[pl.pil];
+    // per-lane constants
+    int col[PPL];                                 // ljc column of pillar l + L*k
 #pragma unroll
-    for (int s = 0; s < EPL; ++s) {
-        const int e = lane + 64 * s;
+    for (int k = 0; k < PPL; ++k) col[k] = cv.pillar_to_core[l + L * k];
+    int up[EPG], vq[EPG];                         // the two pillars of packed entry l + L*i (0, 0 if none)
+#pragma unroll
+    for (int i = 0; i < EPG; ++i) {
+        const int e = l + L * i;
         const bool on = GAMMA && e < cv.Eu;
-        pl.up[s] = on ? cv.ent_pq[2 * e] : 0;
-        pl.vq[s] = on ? cv.ent_pq[2 * e + 1] : 0;
+        up[i] = on ? cv.ent_pq[2 * e] : 0;
+        vq[i] = on ? cv.ent_pq[2 * e + 1] : 0;
     }
-    // this lane's 4x4 block of the output matrix starts at row 4*bi, column 4*bj
-    const int16_t* omap = s_omap + (4 * bi) * kPillarPad + 4 * bj;
 
-    Ladders<GAMMA, EPL> total;   // this wave's share of the portfolio aggregate
-    total.clear();
+    // running portfolio sums of this wave: pv per group (lane l == 0), delta per group lane/pillar,
+    // gamma in the 64-lane packed layout (entry lane + 64 s)
+    double tot_pv = 0.0, tot_delta[PPL], tot_gamma[GAMMA ? EPL : 1];
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) tot_delta[k] = 0.0;
+#pragma unroll
+    for (int s = 0; s < (GAMMA ? EPL : 1); ++s) tot_gamma[s] = 0.0;
 
+    const int64_t n_units = (tr.n_list + G - 1) / G;
     const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-    for (int64_t it = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; it < tr.n_list; it += wave_stride) {
-        const int64_t t = tr.list ? static_cast<int64_t>(tr.list[it]) : it;
-        const TradeHeader h = tr.header[t];
-        const double N = h.notional, spread = h.spread;
-        const double sl = static_cast<double>(h.flt_sign), sf = static_cast<double>(h.fix_sign);
-        const int n_flt = h.n_flt, n_fix = h.n_fix;
-        const double* f_tp = tr.flt_tp + h.flt_begin;
-        const double* f_ts = tr.flt_ts + h.flt_begin;
-        const double* f_al = tr.flt_alpha + h.flt_begin;
-        const double* x_tp = tr.fix_tp + h.fix_begin;
-        const double* x_pay = tr.fix_pay + h.fix_begin;
+    for (int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; unit < n_units; unit += wave_stride) {
+        // ------------------------------------------------------------------ this group's trade
+        const int64_t it = unit * G + g;
+        const bool live = it < tr.n_list;
+        const int t = live ? (tr.list ? tr.list[it] : static_cast<int>(it)) : -1;   // < 2^31 trades per batch
+        double N = 0.0, spread = 0.0, sl = 0.0, sf = 0.0;
+        int n_flt = 0, n_fix = 0, flt_begin = 0, fix_begin = 0;
+        if (live) {
+            const TradeHeader h = tr.header[t];
+            N = h.notional; spread = h.spread;
+            sl = static_cast<double>(h.flt_sign); sf = static_cast<double>(h.fix_sign);
+            n_flt = h.n_flt; n_fix = h.n_fix; flt_begin = h.flt_begin; fix_begin = h.fix_begin;
+        }
+        // cash-flow arrays are indexed from the batch-wide base pointers (scalar registers) with the
+        // trade's 32-bit begin offsets instead of keeping five 64-bit per-lane pointers alive
+        const double* __restrict__ f_tp = tr.flt_tp;
+        const double* __restrict__ f_ts = tr.flt_ts;
+        const double* __restrict__ f_al = tr.flt_alpha;
+        const double* __restrict__ x_tp = tr.fix_tp;
+        const double* __restrict__ x_pay = tr.fix_pay;
 
-        Ladders<GAMMA, EPL> acc;
-        acc.clear();
+        double pv = 0.0, dacc[PPL], acc[EPG];
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) dacc[k] = 0.0;
+#pragma unroll
+        for (int i = 0; i < EPG; ++i) acc[i] = 0.0;
 
-        // Two kinds of lookup passes: float chunks (payment nodes + start nodes in the spare lanes) and
-        // fixed chunks (only the fixed coupons that did not merge into a float payment node).
-        const int n_flt_chunks = (n_flt + 63) >> 6, n_fix_chunks = (n_fix + 63) >> 6;
-        for (int chunk = 0; chunk < n_flt_chunks + n_fix_chunks; ++chunk) {
-            double qt = 0.0, qa = 0.0;      // this lane's query: time and coefficient
-            bool qon = false;
-            unsigned long long leftover = 0;
-            double ts = 0.0;
+        // Lookup passes: float chunks (payment nodes + the first start node in a spare lane) and fixed
+        // chunks (only the fixed coupons that did not merge into a float payment node).  The groups run
+        // their own chunk counts in lockstep; a group that has run out simply has no queries.
+        const int n_flt_chunks = (n_flt + L - 1) / L, n_fix_chunks = (n_fix + L - 1) / L;
+        const int my_chunks = n_flt_chunks + n_fix_chunks;
+        int max_chunks = my_chunks;
+#pragma unroll
+        for (int off = L; off < 64; off <<= 1) max_chunks = max(max_chunks, __shfl_xor(max_chunks, off, 64));
+        max_chunks = __builtin_amdgcn_readfirstlane(max_chunks);
+
+        for (int chunk = 0; chunk < max_chunks; ++chunk) {
+            double qt = 0.0, qa = 0.0, ts = 0.0;    // this lane's query: time and coefficient
+            bool qon = false, own_start = false;
             if (chunk < n_flt_chunks) {
-                const int base = chunk << 6;
-                const int j = base + lane;
+                const int j = chunk * L + l;
                 const bool in = j < n_flt;
                 double tp = 0.0, al = 0.0;
-                if (in) { tp = f_tp[j]; ts = f_ts[j]; al = f_al[j]; }
+                if (in) { tp = f_tp[flt_begin + j]; ts = f_ts[flt_begin + j]; al = f_al[flt_begin + j]; }
                 const bool valid = in && tp >= 0.0;
                 const bool accrues = al > 0.0;        // te == tp for every coupon of a fast-path trade
                 // payment node P_j: -N(1 - spread*a) D(tp)   (N*spread*a*D(tp) when nothing accrues)
                 double a_pay = valid ? sl * N * (spread * al - (accrues ? 1.0 : 0.0)) : 0.0;
                 // the next coupon's start node lands here when its accrual starts on this payment time
                 if (in && j + 1 < n_flt) {
-                    const double ntp = f_tp[j + 1], nts = f_ts[j + 1], nal = f_al[j + 1];
+                    const double ntp = f_tp[flt_begin + j + 1], nts = f_ts[flt_begin + j + 1], nal = f_al[flt_begin + j + 1];
                     if (nal > 0.0 && ntp >= 0.0 && nts == tp) a_pay += sl * N;
                 }
                 // the fixed coupon paid at the same time joins the node
                 if (in && j < n_fix) {
-                    const double xtp = x_tp[j];
-                    if (xtp == tp && xtp > 0.0) a_pay = fma(sf, x_pay[j], a_pay);
+                    const double xtp = x_tp[fix_begin + j];
+                    if (xtp == tp && xtp > 0.0) a_pay = fma(sf, x_pay[fix_begin + j], a_pay);
                 }
                 // own start node S_j unless it coincides with the previous payment node
-                bool own_start = valid && accrues;
-                if (own_start && j > 0 && f_tp[j - 1] == ts) own_start = false;
-
+                own_start = valid && accrues;
+                if (own_start && j > 0 && f_tp[flt_begin + j - 1] == ts) own_start = false;
                 qt = tp; qa = a_pay; qon = in && a_pay != 0.0;
-                leftover = __ballot(own_start);
-                int dst = min(n_flt - base, 64);      // first spare lane
-                while (leftover && dst < 64) {
-                    const int src = __builtin_ctzll(leftover);
-                    leftover &= leftover - 1;
-                    const double st = readlane_d(ts, src);
-                    if (lane == dst) { qt = st; qa = sl * N; qon = true; }
-                    ++dst;
-                }
-            } else {
-                const int j = ((chunk - n_flt_chunks) << 6) + lane;
+            } else if (chunk < my_chunks) {
+                const int j = (chunk - n_flt_chunks) * L + l;
                 if (j < n_fix) {
-                    qt = x_tp[j];
-                    const bool merged = j < n_flt && f_tp[j] == qt;
-                    qa = sf * x_pay[j];
+                    qt = x_tp[fix_begin + j];
+                    const bool merged = j < n_flt && f_tp[flt_begin + j] == qt;
+                    qa = sf * x_pay[fix_begin + j];
                     qon = !merged && qt > 0.0 && qa != 0.0;
                 }
             }
+            // start nodes: the group's first one moves to the group's first spare lane (if there is one);
+            // the rest - and a first one that found no spare lane - get a pass of their own
+            {
+                const unsigned long long mine = (__ballot(own_start) >> gbase) & kGroupMask;
+                const int first_spare = (chunk < n_flt_chunks) ? min(n_flt - chunk * L, L) : L;
+                const bool move = mine != 0 && first_spare < L;
+                const int src = gbase + (mine ? __builtin_ctzll(mine) : 0);
+                const double st = shfl_d(ts, src);               // all lanes take part in the shuffle
+                if (move && l == first_spare) { qt = st; qa = sl * N; qon = true; }
+                if (move && lane == src) own_start = false;
+            }
+            const bool more_starts = __ballot(own_start) != 0;
 
             for (int pass = 0; pass < 2; ++pass) {
-                if (pass == 1) {        // start nodes that found no spare lane (a full 64-coupon chunk)
-                    if (!leftover) break;
-                    qt = ts; qa = sl * N; qon = ((leftover >> lane) & 1ull) != 0;
+                if (pass == 1) {
+                    if (!more_starts) break;
+                    qt = ts; qa = sl * N; qon = own_start;
                 }
-                const unsigned long long mask0 = __ballot(qon);
-                if (!mask0) continue;
                 // ---- build: lookup + exp in the lanes that own a query
                 int cls_a = -2, cls_b = -2;
                 double ba = 0.0, bb = 0.0, omega = 0.0;
@@ -344,100 +317,177 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                     cls_a = c.knot_class[q.ka];
                     cls_b = bb != 0.0 ? c.knot_class[q.kb] : -2;
                     omega = qa * exp(fma(ba, c.log_df[q.ka], bb * c.log_df[q.kb]));
-                    acc.pv += omega;
+                    pv += omega;
                 }
                 if (!DELTA) continue;
-                // Nodes whose knots are core rows (an all-zero row standing in for a knot nothing depends
-                // on) take the branch-free loop; nodes touching a short-end knot the general one.
                 const bool greeks = qon && !(cls_a == -2 && cls_b == -2);
-                const bool has_mini = cls_a <= -3 || cls_b <= -3;
-                const int row_a = cls_a >= 0 ? cls_a : zero_row, row_b = cls_b >= 0 ? cls_b : zero_row;
-                unsigned long long mask = __ballot(greeks && !has_mini);
-                while (mask) {
-                    const int n = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    const int ra = readlane_i(row_a, n), rb = readlane_i(row_b, n);
-                    const double om = readlane_d(omega, n);
-                    const double wa = readlane_d(ba, n), wb = readlane_d(bb, n);
-                    const double v = fma(wb, c.ljc[rb * c.pc_pad + pl.col], wa * c.ljc[ra * c.pc_pad + pl.col]);
-                    acc.delta = fma(om, v, acc.delta);
-                    if (GAMMA) {
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane < 32) { ubuf[lane] = om * v; vbuf[lane] = v; }
-                        wave_lds_sync();
-                        const double* rowa = c.lcc + ra * c.ec_stride + lane;
-                        const double* rowb = c.lcc + rb * c.ec_stride + lane;
-                        const double coa = om * wa, cob = om * wb;
+                if (!greeks) { omega = 0.0; cls_a = -2; cls_b = -2; }
+                // ---- consume: the groups walk their nodes in lockstep, node n sits in lane gbase + n
+                unsigned long long any_row = __ballot(greeks);
 #pragma unroll
-                        for (int s = 0; s < EPL; ++s) {
-                            double g = fma(ubuf[pl.up[s]], vbuf[pl.vq[s]], acc.gamma[s]);
-                            if (s < c.core_slots) g = fma(cob, rowb[64 * s], fma(coa, rowa[64 * s], g));
-                            acc.gamma[s] = g;
+                for (int off = L; off < 64; off <<= 1) any_row |= any_row >> off;
+                any_row &= kGroupMask;
+                while (any_row) {
+                    const int n = __builtin_ctzll(any_row);
+                    any_row &= any_row - 1;
+                    const int src = gbase + n;
+                    const int ca = __shfl(cls_a, src, 64), cb = __shfl(cls_b, src, 64);
+                    const double om = shfl_d(omega, src), wa = shfl_d(ba, src), wb = shfl_d(bb, src);
+                    const int ra = ca >= 0 ? ca : zero_row, rb = cb >= 0 ? cb : zero_row;
+                    const bool mini_a = ca <= -3, mini_b = cb <= -3;
+                    const bool any_mini = __ballot(mini_a || mini_b) != 0;
+
+                    // v for this lane's pillars: core rows (the zero row for anything else) ...
+                    double v[PPL];
+                    {
+                        const double* lja = c.ljc + ra * c.pc_pad;
+                        const double* ljb = c.ljc + rb * c.pc_pad;
+#pragma unroll
+                        for (int k = 0; k < PPL; ++k) v[k] = fma(wb, ljb[col[k]], wa * lja[col[k]]);
+                    }
+                    // ... plus the short-end knots' one or two entries
+                    if (any_mini) {
+                        if (mini_a) {
+                            const MiniKnot& m = c.mini[-3 - ca];
+#pragma unroll
+                            for (int k = 0; k < PPL; ++k) {
+                                const int p = l + L * k;
+                                v[k] = fma(wa, p == m.p[0] ? m.lj[0] : (p == m.p[1] ? m.lj[1] : 0.0), v[k]);
+                            }
+                        }
+                        if (mini_b) {
+                            const MiniKnot& m = c.mini[-3 - cb];
+#pragma unroll
+                            for (int k = 0; k < PPL; ++k) {
+                                const int p = l + L * k;
+                                v[k] = fma(wb, p == m.p[0] ? m.lj[0] : (p == m.p[1] ? m.lj[1] : 0.0), v[k]);
+                            }
                         }
                     }
-                }
-                mask = __ballot(greeks && has_mini);
-                while (mask) {
-                    const int n = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    const int ca = readlane_i(cls_a, n), cb = readlane_i(cls_b, n);
-                    const double om = readlane_d(omega, n);
-                    const double wa = readlane_d(ba, n), wb = readlane_d(bb, n);
-                    const double v = knot_v(cb, wb, c, pl.col, pl.pil, knot_v(ca, wa, c, pl.col, pl.pil, 0.0));
-                    acc.delta = fma(om, v, acc.delta);
-                    if (GAMMA) {
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane < 32) { ubuf[lane] = om * v; vbuf[lane] = v; }
-                        wave_lds_sync();
 #pragma unroll
-                        for (int s = 0; s < EPL; ++s) acc.gamma[s] = fma(ubuf[pl.up[s]], vbuf[pl.vq[s]], acc.gamma[s]);
-                        knot_lc<EPL>(ca, om * wa, c, lane, acc.gamma);
-                        knot_lc<EPL>(cb, om * wb, c, lane, acc.gamma);
+                    for (int k = 0; k < PPL; ++k) dacc[k] = fma(om, v[k], dacc[k]);
+                    if (GAMMA) {
+                        // rank-1 part: omega * v v^T through the group's LDS slot
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int k = 0; k < PPL; ++k) { ubuf[l + L * k] = om * v[k]; vbuf[l + L * k] = v[k]; }
+                        wave_lds_sync();
+                        const double* rowa = c.lcc + ra * c.ec_stride + l;
+                        const double* rowb = c.lcc + rb * c.ec_stride + l;
+                        const double coa = om * wa, cob = om * wb;
+                        // All operands of a batch of entries are fetched before any of them is used: the
+                        // scheduling barrier keeps the compiler from pairing each LDS read with its FMA (which
+                        // would expose one LDS round trip per entry).
+                        constexpr int kBatch = EPG < ADR_FAST_BATCH ? EPG : ADR_FAST_BATCH;
+#pragma unroll
+                        for (int i0 = 0; i0 < EPG; i0 += kBatch) {
+                            double uu[kBatch], vv[kBatch], la[kBatch], lb[kBatch];
+#pragma unroll
+                            for (int i = 0; i < kBatch; ++i) {
+#ifndef ADR_ABLATE_RANK1
+                                uu[i] = ubuf[up[i0 + i]];
+                                vv[i] = vbuf[vq[i0 + i]];
+#else
+                                uu[i] = om; vv[i] = wa;
+#endif
+                                // convexity rows: entry l + L*i of a row sits at row[l + L*i]
+#ifndef ADR_ABLATE_LC
+                                if (i0 + i < CPG) { la[i] = rowa[L * (i0 + i)]; lb[i] = rowb[L * (i0 + i)]; }
+#else
+                                if (i0 + i < CPG) { la[i] = wa; lb[i] = wb; }
+#endif
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int i = 0; i < kBatch; ++i) {
+                                double gsum = fma(uu[i], vv[i], acc[i0 + i]);
+                                if (i0 + i < CPG) {
+                                    const bool core = CS < EPL || (i0 + i) < core_entries;   // compile-time true unless universal
+                                    gsum = fma(core ? cob : 0.0, lb[i], fma(core ? coa : 0.0, la[i], gsum));
+                                }
+                                acc[i0 + i] = gsum;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        // convexity of short-end knots: the symmetric 2x2 block [[c0, c1], [c1, c2]] on pillars
+                        // (p0, p1) as two more rank-1 passes: (c0 e0 + c2 e1)(e0 + e1)^T puts c0, c0, c2 on the
+                        // entries (p0,p0), (p0,p1), (p1,p1); ((c1 - c0) e0) e1^T then corrects (p0,p1) to c1.
+                        if (any_mini) {
+#pragma unroll
+                            for (int side = 0; side < 2; ++side) {
+                                const bool mine = side == 0 ? mini_a : mini_b;
+                                if (!__ballot(mine)) continue;
+                                const MiniKnot& m = c.mini[mine ? (-3 - (side == 0 ? ca : cb)) : 0];
+                                const double coef = mine ? (side == 0 ? coa : cob) : 0.0;
+                                const int p0 = m.p[0], p1 = m.p[1];
+                                const double c0 = m.lc[0], c1 = m.lc[1], c2 = m.lc[2];
+#pragma unroll
+                                for (int rnd = 0; rnd < 2; ++rnd) {
+                                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                                    for (int k = 0; k < PPL; ++k) {
+                                        const int p = l + L * k;
+                                        double uu, vv;
+                                        if (rnd == 0) {
+                                            uu = p == p0 ? c0 : (p == p1 ? c2 : 0.0);
+                                            vv = (p == p0 || p == p1) ? 1.0 : 0.0;
+                                        } else {
+                                            uu = (p == p0 && p1 >= 0) ? c1 - c0 : 0.0;
+                                            vv = p == p1 ? 1.0 : 0.0;
+                                        }
+                                        ubuf[p] = coef * uu;
+                                        vbuf[p] = vv;
+                                    }
+                                    wave_lds_sync();
+#pragma unroll
+                                    for (int i = 0; i < EPG; ++i) acc[i] = fma(ubuf[up[i]], vbuf[vq[i]], acc[i]);
+                                }
+                            }
+                        }
                     }
                 }
             }
         }
 
-        // ---------------------------------------------------------------- results of this trade
-        const double pv = wave_sum(acc.pv);
-        if (lane == 0) {
+        // ------------------------------------------------------------------ results, one group at a time
+#pragma unroll
+        for (int off = 1; off < L; off <<= 1) pv += __shfl_xor(pv, off, 64);
+        if (live && l == 0) {
             if (out.pv) out.pv[t] = pv;
-            total.pv += pv;
+            tot_pv += pv;
         }
         if (DELTA) {
-            if (lane < P && out.delta) out.delta[t * P + lane] = acc.delta * 1e-4;
-            total.delta += acc.delta;
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+                const int p = l + L * k;
+                if (live && p < P && out.delta) out.delta[static_cast<int64_t>(t) * P + p] = dacc[k] * 1e-4;
+                tot_delta[k] += dacc[k];
+            }
         }
         if (GAMMA) {
 #pragma unroll
-            for (int s = 0; s < EPL; ++s) total.gamma[s] += acc.gamma[s];
-            if (out.gamma) {
-                // expand the packed entries to the symmetric 32x32 matrix through the wave's LDS slot
+            for (int gg = 0; gg < G; ++gg) {
+                const int tt = __builtin_amdgcn_readfirstlane(__shfl(t, gg * L, 64));
+                if (tt < 0) continue;
                 __builtin_amdgcn_wave_barrier();
+                if (g == gg) {
 #pragma unroll
-                for (int s = 0; s < EPL; ++s)
-                    if (lane + 64 * s < cv.Eu) stage[lane + 64 * s] = acc.gamma[s];
+                    for (int i = 0; i < EPG; ++i) slot[l + L * i] = acc[i];
+                }
                 wave_lds_sync();
-                double* g = out.gamma + t * static_cast<int64_t>(P) * P;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 4 * bi + i;
-                    double gv[4];
+                for (int s = 0; s < EPL; ++s) tot_gamma[s] += slot[lane + 64 * s];
+                if (out.gamma) {
+                    // lane writes elements 2*lane, 2*lane + 1 of each 128-element band (4 rows of 32): every
+                    // store instruction covers 1 KB of consecutive addresses
+                    double* gm = out.gamma + static_cast<int64_t>(tt) * (kPillarPad * kPillarPad) + 2 * lane;
+                    const int16_t* om = s_omap + 2 * lane;
 #pragma unroll
-                    for (int jx = 0; jx < 4; ++jx) {
-                        const int m = omap[i * kPillarPad + jx];
-                        gv[jx] = m >= 0 ? stage[m] * 1e-8 : 0.0;
-                    }
-                    if (r < P) {
-                        if (P == kPillarPad) {
-                            double2* dst = reinterpret_cast<double2*>(g + r * kPillarPad + 4 * bj);
-                            dst[0] = make_double2(gv[0], gv[1]);
-                            dst[1] = make_double2(gv[2], gv[3]);
-                        } else {
-#pragma unroll
-                            for (int jx = 0; jx < 4; ++jx)
-                                if (4 * bj + jx < P) g[r * P + 4 * bj + jx] = gv[jx];
-                        }
+                    for (int band = 0; band < 8; ++band) {
+                        const int m0 = om[band * 128], m1 = om[band * 128 + 1];
+                        const double g0 = m0 >= 0 ? slot[m0] * 1e-8 : 0.0;
+                        const double g1 = m1 >= 0 ? slot[m1] * 1e-8 : 0.0;
+                        *reinterpret_cast<double2*>(gm + band * 128) = make_double2(g0, g1);
                     }
                 }
             }
@@ -446,28 +496,38 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 
     // ------------------------------------------------------------------------ block partial of the aggregate
     if (out.block_partials) {
-        double tot_gamma[GAMMA ? kGammaPerLane : 1];
+        // gamma: packed 64-lane layout -> 4x4 blocks through the wave's slot
+        double blk_gamma[GAMMA ? kGammaPerLane : 1];
         if (GAMMA) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int s = 0; s < EPL; ++s)
-                if (lane + 64 * s < cv.Eu) stage[lane + 64 * s] = total.gamma[s];
+            for (int s = 0; s < EPL; ++s) slot[lane + 64 * s] = tot_gamma[s];
             wave_lds_sync();
 #pragma unroll
             for (int e = 0; e < kGammaPerLane; ++e) {
-                const int m = omap[(e >> 2) * kPillarPad + (e & 3)];
-                tot_gamma[e] = m >= 0 ? stage[m] * 1e-8 : 0.0;
+                const int m = s_omap[(4 * bi + (e >> 2)) * kPillarPad + 4 * bj + (e & 3)];
+                blk_gamma[e] = m >= 0 ? slot[m] * 1e-8 : 0.0;
             }
+        }
+        // delta and pv: sum the groups (lanes l, l + L, ... hold the same pillar)
+#pragma unroll
+        for (int off = L; off < 64; off <<= 1) {
+            tot_pv += __shfl_xor(tot_pv, off, 64);
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) tot_delta[k] += __shfl_xor(tot_delta[k], off, 64);
         }
         __syncthreads();   // every wave is done with the curve tables; reuse the LDS for the reduction
         double* red = reinterpret_cast<double*>(smem_raw);   // [waves][kAggStride]
         double* mine = red + wave * kAggStride;
-        if (lane == 0) mine[0] = total.pv;
-        if (lane < kPillarPad) mine[1 + lane] = DELTA ? total.delta * 1e-4 : 0.0;
+        if (lane == 0) mine[0] = tot_pv;
+        if (g == 0) {
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) mine[1 + l + L * k] = DELTA ? tot_delta[k] * 1e-4 : 0.0;
+        }
 #pragma unroll
         for (int e = 0; e < kGammaPerLane; ++e) {
             const int r = 4 * bi + (e >> 2), q = 4 * bj + (e & 3);
-            mine[1 + kPillarPad + r * kPillarPad + q] = GAMMA ? tot_gamma[GAMMA ? e : 0] : 0.0;
+            mine[1 + kPillarPad + r * kPillarPad + q] = GAMMA ? blk_gamma[GAMMA ? e : 0] : 0.0;
         }
         __syncthreads();
         double* dst = out.block_partials + static_cast<size_t>(blockIdx.x) * kAggStride;
@@ -494,33 +554,44 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* part
     else { const int r = (i - 1 - P) / P, q = (i - 1 - P) % P; src = 1 + kPillarPad + r * kPillarPad + q; }
     double s = 0.0;
     for (int b = lane; b < n_blocks; b += 64) s += partials[static_cast<size_t>(b) * kAggStride + src];
-    s = wave_sum(s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) agg[i] = s;
 }
 
-template <bool DELTA, bool GAMMA>
-void launch_epl(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, int n_blocks, size_t lds,
-                hipStream_t stream) {
-    dim3 grid(n_blocks), block(kBlockThreads);
-    if (!GAMMA) {
-        hipLaunchKernelGGL((price_fast_kernel<DELTA, false, 1>), grid, block, lds, stream, cv, tr, out);
-        return;
-    }
+constexpr int kGroups = ADR_FAST_GROUPS;
+
+// Kernel variant for a curve: (EPL, CS) with CS = EPL - 1 (one fringe slot, the usual case), CS = EPL (no fringe
+// entries) or, for anything else, the universal variant (EPL, EPL).
+using KernelFn = void (*)(CurveDev, TradesDev, OutputsDev);
+
+template <int EPL>
+KernelFn gamma_kernel(int core_slots) {
+    if (core_slots == EPL - 1 && EPL > 1) return &price_fast_kernel<true, true, EPL, (EPL > 1 ? EPL - 1 : 1), kGroups>;
+    return &price_fast_kernel<true, true, EPL, EPL, kGroups>;
+}
+
+KernelFn pick_kernel(const CurveDev& cv, bool want_delta, bool want_gamma) {
+    if (!want_gamma)
+        return want_delta ? &price_fast_kernel<true, false, 1, 1, kGroups> : &price_fast_kernel<false, false, 1, 1, kGroups>;
+    const int core_slots = (cv.Ec + 63) >> 6;
     switch (cv.epl) {
-        case 3: hipLaunchKernelGGL((price_fast_kernel<true, true, 3>), grid, block, lds, stream, cv, tr, out); break;
-        case 4: hipLaunchKernelGGL((price_fast_kernel<true, true, 4>), grid, block, lds, stream, cv, tr, out); break;
-        case 6: hipLaunchKernelGGL((price_fast_kernel<true, true, 6>), grid, block, lds, stream, cv, tr, out); break;
-        default: hipLaunchKernelGGL((price_fast_kernel<true, true, 9>), grid, block, lds, stream, cv, tr, out); break;
+        case 3: return gamma_kernel<3>(core_slots);
+        case 4: return gamma_kernel<4>(core_slots);
+        case 6: return gamma_kernel<6>(core_slots);
+        default: return gamma_kernel<9>(core_slots);
     }
 }
 
 }  // namespace
 
+int fast_kernel_groups() { return kGroups; }
+
 size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
-    const size_t stage_stride = gamma ? std::max<size_t>((cv.Eu + 1) & ~1, 2 * kPillarPad) : 0;
+    const size_t slot = gamma ? std::max<size_t>(64 * cv.epl, kGroups * 2 * kPillarPad) : 0;
     size_t doubles = static_cast<size_t>(cv.K) + 2 * cv.Kc + static_cast<size_t>(cv.Kcore + 1) * cv.pc_pad +
-                     (gamma ? static_cast<size_t>(cv.Kcore + 1) * (cv.Ec + 1) : 0) +
-                     kWavesPerBlock * stage_stride + 64 * 9;   // slack: convexity rows are read 64*EPL wide
+                     (gamma ? static_cast<size_t>(cv.Kcore + 1) * (cv.Ec + 1) + 64 * cv.epl : 0) +
+                     kWavesPerBlock * slot;
     size_t tables = sizeof(MiniKnot) * cv.n_mini + sizeof(double) * doubles +
                     sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + cv.Kc + (gamma ? kPillarPad * kPillarPad : 0));
     size_t reduce = sizeof(double) * kWavesPerBlock * kAggStride;
@@ -531,9 +602,8 @@ size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
 hipError_t launch_price_fast(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                              bool want_gamma, int n_blocks, hipStream_t stream) {
     const size_t lds = fast_kernel_lds_bytes(cv, want_gamma);
-    if (want_gamma) launch_epl<true, true>(cv, tr, out, n_blocks, lds, stream);
-    else if (want_delta) launch_epl<true, false>(cv, tr, out, n_blocks, lds, stream);
-    else launch_epl<false, false>(cv, tr, out, n_blocks, lds, stream);
+    hipLaunchKernelGGL(pick_kernel(cv, want_delta, want_gamma), dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv,
+                       tr, out);
     return hipGetLastError();
 }
 
@@ -550,12 +620,12 @@ hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes) {
     hipError_t e = set_general_kernel_lds_limit(general_bytes);
     if (e != hipSuccess) return e;
     const void* fns[] = {
-        reinterpret_cast<const void*>(&price_fast_kernel<true, true, 3>),
-        reinterpret_cast<const void*>(&price_fast_kernel<true, true, 4>),
-        reinterpret_cast<const void*>(&price_fast_kernel<true, true, 6>),
-        reinterpret_cast<const void*>(&price_fast_kernel<true, true, 9>),
-        reinterpret_cast<const void*>(&price_fast_kernel<true, false, 1>),
-        reinterpret_cast<const void*>(&price_fast_kernel<false, false, 1>),
+        reinterpret_cast<const void*>(gamma_kernel<3>(2)), reinterpret_cast<const void*>(gamma_kernel<3>(3)),
+        reinterpret_cast<const void*>(gamma_kernel<4>(3)), reinterpret_cast<const void*>(gamma_kernel<4>(4)),
+        reinterpret_cast<const void*>(gamma_kernel<6>(5)), reinterpret_cast<const void*>(gamma_kernel<6>(6)),
+        reinterpret_cast<const void*>(gamma_kernel<9>(8)), reinterpret_cast<const void*>(gamma_kernel<9>(9)),
+        reinterpret_cast<const void*>(&price_fast_kernel<true, false, 1, 1, kGroups>),
+        reinterpret_cast<const void*>(&price_fast_kernel<false, false, 1, 1, kGroups>),
     };
     for (const void* f : fns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(fast_bytes));
