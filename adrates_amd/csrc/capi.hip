@@ -51,6 +51,7 @@ struct adr_ctx {
     int n_cu = 0;
     size_t lds_limit = 0;
     double* partials = nullptr;     // [max_blocks][kAggStride] scratch for the aggregate
+    unsigned long long* stamps = nullptr;   // diagnostic builds: [max_blocks*16][8]
     int max_blocks = 0;
 };
 
@@ -108,9 +109,20 @@ int adr_init(int device_ordinal, adr_ctx** out) {
     e = hipMalloc(reinterpret_cast<void**>(&ctx->partials),
                   sizeof(double) * static_cast<size_t>(ctx->max_blocks) * adr::kAggStride);
     if (e != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return fail_hip(e, "hipMalloc(partials)"); }
+#ifdef ADR_STAMPS
+    hipMalloc(reinterpret_cast<void**>(&ctx->stamps), sizeof(unsigned long long) * ctx->max_blocks * 16 * 8);
+    hipMemset(ctx->stamps, 0, sizeof(unsigned long long) * ctx->max_blocks * 16 * 8);
+#endif
     *out = ctx;
     return ADR_OK;
 }
+
+#ifdef ADR_STAMPS
+extern "C" int adr_debug_stamps(adr_ctx* ctx, unsigned long long* host, int n_waves) {
+    hipDeviceSynchronize();
+    return hipMemcpy(host, ctx->stamps, sizeof(unsigned long long) * n_waves * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif
 
 void adr_free_ctx(adr_ctx* ctx) {
     if (!ctx) return;
@@ -268,10 +280,10 @@ int adr_trades_upload(adr_ctx* ctx, int64_t n, const int64_t* fix_off, const int
     std::vector<int32_t> list_fast, list_general;
     if (n > INT32_MAX) return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^31 trades in one batch");
     for (int64_t t = 0; t < n; ++t) {
-        bool lagged = false;
-        for (int64_t j = flt_off[t]; j < flt_off[t + 1] && !lagged; ++j)
-            lagged = flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j];
-        (lagged ? list_general : list_fast).push_back(static_cast<int32_t>(t));
+        bool general = flt_off[t + 1] - flt_off[t] > adr::kRowSlots || fix_off[t + 1] - fix_off[t] > adr::kRowSlots;
+        for (int64_t j = flt_off[t]; j < flt_off[t + 1] && !general; ++j)
+            general = flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j];       // payment lag: ratio terms
+        (general ? list_general : list_fast).push_back(static_cast<int32_t>(t));
     }
     for (int64_t t = 0; t < n; ++t) {
         const int64_t mf = fix_off[t + 1] - fix_off[t], ml = flt_off[t + 1] - flt_off[t];
@@ -325,6 +337,33 @@ int adr_trades_upload(adr_ctx* ctx, int64_t n, const int64_t* fix_off, const int
     });
     tr->list_fast = static_cast<const int32_t*>(put(list_fast.data(), list_fast.size() * sizeof(int32_t)));
     tr->list_general = static_cast<const int32_t*>(put(list_general.data(), list_general.size() * sizeof(int32_t)));
+    {   // row table of the fast kernel (kernels.hpp): sorted rows, 32 zero-padded slots per array
+        const size_t rows = list_fast.size(), S = adr::kRowSlots;
+        std::vector<double> r_tp(rows * S, 0.0), r_ts(rows * S, 0.0), r_al(rows * S, 0.0), r_xtp(rows * S, 0.0),
+            r_xpay(rows * S, 0.0), r_n(rows), r_sp(rows);
+        std::vector<int32_t> r_meta(rows);
+        for (size_t r = 0; r < rows; ++r) {
+            const int64_t t = list_fast[r];
+            const int64_t l0 = flt_off[t], ml = flt_off[t + 1] - l0, f0 = fix_off[t], mf = fix_off[t + 1] - f0;
+            for (int64_t j = 0; j < ml; ++j) {
+                r_tp[r * S + j] = flt_tp[l0 + j]; r_ts[r * S + j] = flt_ts[l0 + j]; r_al[r * S + j] = flt_alpha[l0 + j];
+            }
+            for (int64_t j = 0; j < mf; ++j) { r_xtp[r * S + j] = fix_tp[f0 + j]; r_xpay[r * S + j] = fix_pay[f0 + j]; }
+            r_n[r] = notional[t]; r_sp[r] = spread[t];
+            r_meta[r] = static_cast<int32_t>(ml | (mf << 8) | ((flt_sign[t] < 0.0) ? 0x10000 : 0) |
+                                             ((fix_sign[t] < 0.0) ? 0x20000 : 0));
+        }
+        tr->dev.n_rows = static_cast<int64_t>(rows);
+        tr->dev.row_tp = static_cast<const double*>(put(r_tp.data(), r_tp.size() * sizeof(double)));
+        tr->dev.row_ts = static_cast<const double*>(put(r_ts.data(), r_ts.size() * sizeof(double)));
+        tr->dev.row_alpha = static_cast<const double*>(put(r_al.data(), r_al.size() * sizeof(double)));
+        tr->dev.row_xtp = static_cast<const double*>(put(r_xtp.data(), r_xtp.size() * sizeof(double)));
+        tr->dev.row_xpay = static_cast<const double*>(put(r_xpay.data(), r_xpay.size() * sizeof(double)));
+        tr->dev.row_notional = static_cast<const double*>(put(r_n.data(), r_n.size() * sizeof(double)));
+        tr->dev.row_spread = static_cast<const double*>(put(r_sp.data(), r_sp.size() * sizeof(double)));
+        tr->dev.row_meta = static_cast<const int32_t*>(put(r_meta.data(), r_meta.size() * sizeof(int32_t)));
+        tr->dev.row_trade = tr->list_fast;
+    }
     if (e != hipSuccess) { adr_free_trades(tr); return fail_hip(e, "adr_trades_upload: copying trades"); }
     *out = tr;
     return ADR_OK;
@@ -351,6 +390,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     }
 
     adr::OutputsDev o;
+    o.stamps = ctx->stamps;
     o.pv = (req_mask & ADR_REQ_VALUE) ? pv_dev : nullptr;
     o.delta = (req_mask & ADR_REQ_DELTA) ? delta_dev : nullptr;
     o.gamma = want_gamma ? gamma_dev : nullptr;
@@ -360,7 +400,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     const bool use_fast = curve->dev.packed_ok != 0;
     adr::TradesDev fast = trades->dev, general = trades->dev;
     if (use_fast) {
-        fast.list = trades->list_fast;       fast.n_list = trades->n_fast;
+        fast.n_list = trades->n_fast;        // = n_rows
         general.list = trades->list_general; general.n_list = trades->n_general;
     } else {
         fast.n_list = 0;                     // general walks all n trades through the identity list

@@ -9,17 +9,18 @@
 #define ADR_FAST_THREADS 768
 #endif
 #ifndef ADR_FAST_BATCH
-#define ADR_FAST_BATCH 4    // packed entries whose LDS operands are fetched together
+#define ADR_FAST_BATCH 2    // packed entries whose LDS operands are fetched together
 #endif
 #ifndef ADR_FAST_GROUPS
-#define ADR_FAST_GROUPS 2   // trades per wavefront in the fast kernel (2 or 4)
+#define ADR_FAST_GROUPS 2   // trades per wavefront in the fast kernel (rows have 64 / 2 = 32 slots)
 #endif
 
 namespace adr {
 
 constexpr int kAggStride = 1 + kPillarPad + kPillarPad * kPillarPad; // padded [pv, delta, gamma] record
 constexpr int kGeneralThreads = 256;                                 // general kernel: 4 wavefronts per block
-constexpr int kFastThreads = ADR_FAST_THREADS;                                   // fast kernel: 8 wavefronts per block
+constexpr int kFastThreads = ADR_FAST_THREADS;
+constexpr int kRowSlots = 32;                                        // cash-flow slots per row of the fast table                                   // fast kernel: 8 wavefronts per block
 
 // Per-trade header, 32 bytes, read once per trade with scalar loads.
 struct TradeHeader {
@@ -46,9 +47,21 @@ struct TradesDev {
     const double* flt_ts;
     const double* flt_te;
     const double* flt_alpha;
-    // The launch covers n_list trades: list[i] when list != null, else trade i.
+    // General kernel: the launch covers n_list trades: list[i] when list != null, else trade i.
     const int32_t* list;
     int64_t n_list;
+    // Fast kernel: the eligible trades (no payment lag, at most kRowSlots coupons per leg) as a table of
+    // n_rows rows sorted by coupon count, kRowSlots zero-padded slots per row and array.
+    int64_t n_rows;
+    const double* row_tp;        // [n_rows][kRowSlots] float payment times
+    const double* row_ts;        //                     accrual start times
+    const double* row_alpha;     //                     accrual fractions
+    const double* row_xtp;       //                     fixed payment times
+    const double* row_xpay;      //                     fixed payment amounts
+    const double* row_notional;  // [n_rows]
+    const double* row_spread;    // [n_rows]
+    const int32_t* row_meta;     // [n_rows] n_flt | n_fix << 8 | (float leg pays) << 16 | (fixed leg pays) << 17
+    const int32_t* row_trade;    // [n_rows] index of the trade in the batch (where its results go)
 };
 
 // Curve tables in HBM.
@@ -78,6 +91,7 @@ struct OutputsDev {
     double* delta;           // [n*P] or null
     double* gamma;           // [n*P*P] or null
     double* block_partials;  // [grid][kAggStride] or null
+    unsigned long long* stamps;  // diagnostic builds only (ADR_STAMPS): [grid*waves][8] cycle sums per phase
 };
 
 size_t general_kernel_lds_bytes(int K, int Kc);

@@ -24,9 +24,11 @@
 // core pillars, LC on the packed upper triangle of core x core, and 64-byte records for the short-end
 // knots that depend on at most two par rates (curve_tables.cpp, build_packed_layout).
 //
-// Mapping.  OIS trades are short (15.5 coupons on average), so a 64-lane wavefront prices G trades at a
-// time, L = 64/G lanes each (the host sorts the trades by coupon count so the G trades of a wavefront
-// have similar lengths).  Inside a group: lanes = coupons while nodes are built (coalesced loads, binary
+// Mapping.  OIS trades are short (15.5 coupons on average), so a 64-lane wavefront prices G = 2 trades at a
+// time, L = 32 lanes each.  The host lays the eligible trades out as a table of rows sorted by coupon count
+// (one row = one trade = 32 padded cash-flow slots per array), so the two trades of a wavefront have similar
+// lengths, every input load is a full-width coalesced row read whose address depends only on the row number,
+// and the next rows can be requested before the current results are stored.  Inside a group: lanes = coupons while nodes are built (coalesced loads, binary
 // search in LDS, exp); then the groups walk their nodes in lockstep - node n of every group is fetched
 // from the lane that built it (ds_bpermute), lane l builds v for pillars l, l+L, ..., v and omega*v go
 // to the group's LDS slot, and every lane updates its packed gamma entries l + L*i: the rank-1 term from
@@ -57,6 +59,12 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+#ifdef ADR_STAMPS
+#define ADR_STAMP(slot_) do { const unsigned long long now_ = clock64(); stamp_sum[slot_] += now_ - stamp_t; stamp_t = now_; } while (0)
+#else
+#define ADR_STAMP(slot_) do {} while (0)
+#endif
 
 struct CurveLds {
     const double* x;            // [K]
@@ -134,6 +142,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     constexpr int EPG = GAMMA ? 64 * EPL / L : 1;      // packed entries per lane: l + L*i
     constexpr int CPG = GAMMA ? 64 * CS / L : 0;       // of which core pairs (convexity rows are read for these)
     static_assert(kPillarPad % L == 0 && PPL >= 1, "a group must cover the pillars evenly");
+    static_assert(L == kRowSlots, "one lane per cash-flow slot of a row");
     constexpr unsigned long long kGroupMask = (L == 64) ? ~0ull : ((1ull << L) - 1);
 
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -216,28 +225,45 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 #pragma unroll
     for (int s = 0; s < (GAMMA ? EPL : 1); ++s) tot_gamma[s] = 0.0;
 
-    const int64_t n_units = (tr.n_list + G - 1) / G;
+#ifdef ADR_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = clock64();
+#endif
+    // ---------------------------------------------------------------------------------------------------
+    // Main loop.  A unit is G consecutive rows of the sorted, padded trade table (one row = one trade, 32
+    // cash-flow slots); group g of the wave takes row G*unit + g.  All loads of a unit depend only on the
+    // unit number, and the loads of the NEXT unit are issued before this unit's result stores: vector
+    // memory operations of a wave retire in order, so a load issued behind 16 KB of stores would also wait
+    // for those stores.
+    const int64_t n_units = (tr.n_rows + G - 1) / G;
     const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-    for (int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave; unit < n_units; unit += wave_stride) {
-        // ------------------------------------------------------------------ this group's trade
-        const int64_t it = unit * G + g;
-        const bool live = it < tr.n_list;
-        const int t = live ? (tr.list ? tr.list[it] : static_cast<int>(it)) : -1;   // < 2^31 trades per batch
-        double N = 0.0, spread = 0.0, sl = 0.0, sf = 0.0;
-        int n_flt = 0, n_fix = 0, flt_begin = 0, fix_begin = 0;
-        if (live) {
-            const TradeHeader h = tr.header[t];
-            N = h.notional; spread = h.spread;
-            sl = static_cast<double>(h.flt_sign); sf = static_cast<double>(h.fix_sign);
-            n_flt = h.n_flt; n_fix = h.n_fix; flt_begin = h.flt_begin; fix_begin = h.fix_begin;
+    int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+
+    double nx_tp = 0.0, nx_ts = 0.0, nx_al = 0.0, nx_xtp = 0.0, nx_xpay = 0.0, nx_N = 0.0, nx_spread = 0.0;
+    int nx_meta = 0, nx_trade = -1;
+    auto load_unit = [&](int64_t u) {
+        const int64_t row = u * G + g;
+        nx_tp = nx_ts = nx_al = nx_xtp = nx_xpay = nx_N = nx_spread = 0.0;
+        nx_meta = 0; nx_trade = -1;
+        if (u < n_units && row < tr.n_rows) {
+            const int64_t at = row * kRowSlots + l;
+            nx_tp = tr.row_tp[at]; nx_ts = tr.row_ts[at]; nx_al = tr.row_alpha[at];
+            nx_xtp = tr.row_xtp[at]; nx_xpay = tr.row_xpay[at];
+            nx_N = tr.row_notional[row]; nx_spread = tr.row_spread[row];
+            nx_meta = tr.row_meta[row]; nx_trade = tr.row_trade[row];
         }
-        // cash-flow arrays are indexed from the batch-wide base pointers (scalar registers) with the
-        // trade's 32-bit begin offsets instead of keeping five 64-bit per-lane pointers alive
-        const double* __restrict__ f_tp = tr.flt_tp;
-        const double* __restrict__ f_ts = tr.flt_ts;
-        const double* __restrict__ f_al = tr.flt_alpha;
-        const double* __restrict__ x_tp = tr.fix_tp;
-        const double* __restrict__ x_pay = tr.fix_pay;
+    };
+    load_unit(unit);
+
+    for (; unit < n_units; unit += wave_stride) {
+        // ------------------------------------------------------------------ this group's trade
+        const double tp = nx_tp, ts = nx_ts, al = nx_al, xtp = nx_xtp, xpay = nx_xpay;
+        const double N = nx_N, spread = nx_spread;
+        const int t = nx_trade;
+        const bool live = t >= 0;
+        const int n_flt = nx_meta & 0xff, n_fix = (nx_meta >> 8) & 0xff;
+        const double sl = (nx_meta & 0x10000) ? -1.0 : 1.0, sf = (nx_meta & 0x20000) ? -1.0 : 1.0;
+        ADR_STAMP(0);   // waiting for the unit's inputs
 
         double pv = 0.0, dacc[PPL], acc[EPG];
 #pragma unroll
@@ -245,209 +271,190 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 #pragma unroll
         for (int i = 0; i < EPG; ++i) acc[i] = 0.0;
 
-        // Lookup passes: float chunks (payment nodes + the first start node in a spare lane) and fixed
-        // chunks (only the fixed coupons that did not merge into a float payment node).  The groups run
-        // their own chunk counts in lockstep; a group that has run out simply has no queries.
-        const int n_flt_chunks = (n_flt + L - 1) / L, n_fix_chunks = (n_fix + L - 1) / L;
-        const int my_chunks = n_flt_chunks + n_fix_chunks;
-        int max_chunks = my_chunks;
-#pragma unroll
-        for (int off = L; off < 64; off <<= 1) max_chunks = max(max_chunks, __shfl_xor(max_chunks, off, 64));
-        max_chunks = __builtin_amdgcn_readfirstlane(max_chunks);
+        // ---- fold the coupons into nodes (lane l = coupon l of the group's trade)
+        const bool in = live && l < n_flt;
+        const int up1 = lane < 63 ? lane + 1 : lane, dn1 = lane > 0 ? lane - 1 : lane;
+        const double ntp = shfl_d(tp, up1), nts = shfl_d(ts, up1), nal = shfl_d(al, up1), ptp = shfl_d(tp, dn1);
+        const bool valid = in && tp >= 0.0;
+        const bool accrues = al > 0.0;            // te == tp for every coupon of a fast-path trade
+        // payment node P_l: -N(1 - spread*a) D(tp)   (N*spread*a*D(tp) when nothing accrues)
+        double a_pay = valid ? sl * N * (spread * al - (accrues ? 1.0 : 0.0)) : 0.0;
+        // the next coupon's start node lands here when its accrual starts on this payment time
+        if (in && l + 1 < n_flt && nal > 0.0 && ntp >= 0.0 && nts == tp) a_pay += sl * N;
+        // the fixed coupon paid at the same time joins the node
+        const bool fix_in = live && l < n_fix;
+        const bool fix_merged = fix_in && in && xtp == tp;
+        if (fix_merged && xtp > 0.0) a_pay = fma(sf, xpay, a_pay);
+        // own start node S_l unless it coincides with the previous payment node
+        bool own_start = valid && accrues && !(l > 0 && ptp == ts);
+        const bool own_fixed = fix_in && !fix_merged && xtp > 0.0 && sf * xpay != 0.0;
 
-        for (int chunk = 0; chunk < max_chunks; ++chunk) {
-            double qt = 0.0, qa = 0.0, ts = 0.0;    // this lane's query: time and coefficient
-            bool qon = false, own_start = false;
-            if (chunk < n_flt_chunks) {
-                const int j = chunk * L + l;
-                const bool in = j < n_flt;
-                double tp = 0.0, al = 0.0;
-                if (in) { tp = f_tp[flt_begin + j]; ts = f_ts[flt_begin + j]; al = f_al[flt_begin + j]; }
-                const bool valid = in && tp >= 0.0;
-                const bool accrues = al > 0.0;        // te == tp for every coupon of a fast-path trade
-                // payment node P_j: -N(1 - spread*a) D(tp)   (N*spread*a*D(tp) when nothing accrues)
-                double a_pay = valid ? sl * N * (spread * al - (accrues ? 1.0 : 0.0)) : 0.0;
-                // the next coupon's start node lands here when its accrual starts on this payment time
-                if (in && j + 1 < n_flt) {
-                    const double ntp = f_tp[flt_begin + j + 1], nts = f_ts[flt_begin + j + 1], nal = f_al[flt_begin + j + 1];
-                    if (nal > 0.0 && ntp >= 0.0 && nts == tp) a_pay += sl * N;
-                }
-                // the fixed coupon paid at the same time joins the node
-                if (in && j < n_fix) {
-                    const double xtp = x_tp[fix_begin + j];
-                    if (xtp == tp && xtp > 0.0) a_pay = fma(sf, x_pay[fix_begin + j], a_pay);
-                }
-                // own start node S_j unless it coincides with the previous payment node
-                own_start = valid && accrues;
-                if (own_start && j > 0 && f_tp[flt_begin + j - 1] == ts) own_start = false;
-                qt = tp; qa = a_pay; qon = in && a_pay != 0.0;
-            } else if (chunk < my_chunks) {
-                const int j = (chunk - n_flt_chunks) * L + l;
-                if (j < n_fix) {
-                    qt = x_tp[fix_begin + j];
-                    const bool merged = j < n_flt && f_tp[flt_begin + j] == qt;
-                    qa = sf * x_pay[fix_begin + j];
-                    qon = !merged && qt > 0.0 && qa != 0.0;
-                }
-            }
-            // start nodes: the group's first one moves to the group's first spare lane (if there is one);
-            // the rest - and a first one that found no spare lane - get a pass of their own
-            {
-                const unsigned long long mine = (__ballot(own_start) >> gbase) & kGroupMask;
-                const int first_spare = (chunk < n_flt_chunks) ? min(n_flt - chunk * L, L) : L;
-                const bool move = mine != 0 && first_spare < L;
-                const int src = gbase + (mine ? __builtin_ctzll(mine) : 0);
-                const double st = shfl_d(ts, src);               // all lanes take part in the shuffle
-                if (move && l == first_spare) { qt = st; qa = sl * N; qon = true; }
-                if (move && lane == src) own_start = false;
-            }
-            const bool more_starts = __ballot(own_start) != 0;
-
-            for (int pass = 0; pass < 2; ++pass) {
-                if (pass == 1) {
-                    if (!more_starts) break;
-                    qt = ts; qa = sl * N; qon = own_start;
-                }
-                // ---- build: lookup + exp in the lanes that own a query
-                int cls_a = -2, cls_b = -2;
-                double ba = 0.0, bb = 0.0, omega = 0.0;
-                if (qon) {
-                    const Lookup q = curve_lookup(c, qt);
-                    ba = q.ba; bb = q.bb;
-                    cls_a = c.knot_class[q.ka];
-                    cls_b = bb != 0.0 ? c.knot_class[q.kb] : -2;
-                    omega = qa * exp(fma(ba, c.log_df[q.ka], bb * c.log_df[q.kb]));
-                    pv += omega;
-                }
-                if (!DELTA) continue;
-                const bool greeks = qon && !(cls_a == -2 && cls_b == -2);
-                if (!greeks) { omega = 0.0; cls_a = -2; cls_b = -2; }
-                // ---- consume: the groups walk their nodes in lockstep, node n sits in lane gbase + n
-                unsigned long long any_row = __ballot(greeks);
-#pragma unroll
-                for (int off = L; off < 64; off <<= 1) any_row |= any_row >> off;
-                any_row &= kGroupMask;
-                while (any_row) {
-                    const int n = __builtin_ctzll(any_row);
-                    any_row &= any_row - 1;
-                    const int src = gbase + n;
-                    const int ca = __shfl(cls_a, src, 64), cb = __shfl(cls_b, src, 64);
-                    const double om = shfl_d(omega, src), wa = shfl_d(ba, src), wb = shfl_d(bb, src);
-                    const int ra = ca >= 0 ? ca : zero_row, rb = cb >= 0 ? cb : zero_row;
-                    const bool mini_a = ca <= -3, mini_b = cb <= -3;
-                    const bool any_mini = __ballot(mini_a || mini_b) != 0;
-
-                    // v for this lane's pillars: core rows (the zero row for anything else) ...
-                    double v[PPL];
-                    {
-                        const double* lja = c.ljc + ra * c.pc_pad;
-                        const double* ljb = c.ljc + rb * c.pc_pad;
-#pragma unroll
-                        for (int k = 0; k < PPL; ++k) v[k] = fma(wb, ljb[col[k]], wa * lja[col[k]]);
-                    }
-                    // ... plus the short-end knots' one or two entries
-                    if (any_mini) {
-                        if (mini_a) {
-                            const MiniKnot& m = c.mini[-3 - ca];
-#pragma unroll
-                            for (int k = 0; k < PPL; ++k) {
-                                const int p = l + L * k;
-                                v[k] = fma(wa, p == m.p[0] ? m.lj[0] : (p == m.p[1] ? m.lj[1] : 0.0), v[k]);
-                            }
-                        }
-                        if (mini_b) {
-                            const MiniKnot& m = c.mini[-3 - cb];
-#pragma unroll
-                            for (int k = 0; k < PPL; ++k) {
-                                const int p = l + L * k;
-                                v[k] = fma(wb, p == m.p[0] ? m.lj[0] : (p == m.p[1] ? m.lj[1] : 0.0), v[k]);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < PPL; ++k) dacc[k] = fma(om, v[k], dacc[k]);
-                    if (GAMMA) {
-                        // rank-1 part: omega * v v^T through the group's LDS slot
-                        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                        for (int k = 0; k < PPL; ++k) { ubuf[l + L * k] = om * v[k]; vbuf[l + L * k] = v[k]; }
-                        wave_lds_sync();
-                        const double* rowa = c.lcc + ra * c.ec_stride + l;
-                        const double* rowb = c.lcc + rb * c.ec_stride + l;
-                        const double coa = om * wa, cob = om * wb;
-                        // All operands of a batch of entries are fetched before any of them is used: the
-                        // scheduling barrier keeps the compiler from pairing each LDS read with its FMA (which
-                        // would expose one LDS round trip per entry).
-                        constexpr int kBatch = EPG < ADR_FAST_BATCH ? EPG : ADR_FAST_BATCH;
-#pragma unroll
-                        for (int i0 = 0; i0 < EPG; i0 += kBatch) {
-                            double uu[kBatch], vv[kBatch], la[kBatch], lb[kBatch];
-#pragma unroll
-                            for (int i = 0; i < kBatch; ++i) {
-#ifndef ADR_ABLATE_RANK1
-                                uu[i] = ubuf[up[i0 + i]];
-                                vv[i] = vbuf[vq[i0 + i]];
-#else
-                                uu[i] = om; vv[i] = wa;
-#endif
-                                // convexity rows: entry l + L*i of a row sits at row[l + L*i]
-#ifndef ADR_ABLATE_LC
-                                if (i0 + i < CPG) { la[i] = rowa[L * (i0 + i)]; lb[i] = rowb[L * (i0 + i)]; }
-#else
-                                if (i0 + i < CPG) { la[i] = wa; lb[i] = wb; }
-#endif
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int i = 0; i < kBatch; ++i) {
-                                double gsum = fma(uu[i], vv[i], acc[i0 + i]);
-                                if (i0 + i < CPG) {
-                                    const bool core = CS < EPL || (i0 + i) < core_entries;   // compile-time true unless universal
-                                    gsum = fma(core ? cob : 0.0, lb[i], fma(core ? coa : 0.0, la[i], gsum));
-                                }
-                                acc[i0 + i] = gsum;
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        // convexity of short-end knots: the symmetric 2x2 block [[c0, c1], [c1, c2]] on pillars
-                        // (p0, p1) as two more rank-1 passes: (c0 e0 + c2 e1)(e0 + e1)^T puts c0, c0, c2 on the
-                        // entries (p0,p0), (p0,p1), (p1,p1); ((c1 - c0) e0) e1^T then corrects (p0,p1) to c1.
-                        if (any_mini) {
-#pragma unroll
-                            for (int side = 0; side < 2; ++side) {
-                                const bool mine = side == 0 ? mini_a : mini_b;
-                                if (!__ballot(mine)) continue;
-                                const MiniKnot& m = c.mini[mine ? (-3 - (side == 0 ? ca : cb)) : 0];
-                                const double coef = mine ? (side == 0 ? coa : cob) : 0.0;
-                                const int p0 = m.p[0], p1 = m.p[1];
-                                const double c0 = m.lc[0], c1 = m.lc[1], c2 = m.lc[2];
-#pragma unroll
-                                for (int rnd = 0; rnd < 2; ++rnd) {
-                                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                                    for (int k = 0; k < PPL; ++k) {
-                                        const int p = l + L * k;
-                                        double uu, vv;
-                                        if (rnd == 0) {
-                                            uu = p == p0 ? c0 : (p == p1 ? c2 : 0.0);
-                                            vv = (p == p0 || p == p1) ? 1.0 : 0.0;
-                                        } else {
-                                            uu = (p == p0 && p1 >= 0) ? c1 - c0 : 0.0;
-                                            vv = p == p1 ? 1.0 : 0.0;
-                                        }
-                                        ubuf[p] = coef * uu;
-                                        vbuf[p] = vv;
-                                    }
-                                    wave_lds_sync();
-#pragma unroll
-                                    for (int i = 0; i < EPG; ++i) acc[i] = fma(ubuf[up[i]], vbuf[vq[i]], acc[i]);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
+        double qt = tp, qa = a_pay;               // this lane's query: time and coefficient
+        bool qon = in && a_pay != 0.0;
+        {   // the group's first start node moves to the group's first spare lane, if there is one
+            const unsigned long long mine = (__ballot(own_start) >> gbase) & kGroupMask;
+            const bool move = mine != 0 && n_flt < L;
+            const int src = gbase + (mine ? __builtin_ctzll(mine) : 0);
+            const double st = shfl_d(ts, src);
+            if (move && l == n_flt) { qt = st; qa = sl * N; qon = true; }
+            if (move && lane == src) own_start = false;
         }
+        const bool more_starts = __ballot(own_start) != 0, more_fixed = __ballot(own_fixed) != 0;
+        ADR_STAMP(1);   // node folding
+
+        for (int pass = 0; pass < 3; ++pass) {
+            if (pass == 1) {            // fixed coupons that did not merge into a float payment node
+                if (!more_fixed) continue;
+                qt = xtp; qa = sf * xpay; qon = own_fixed;
+            } else if (pass == 2) {     // start nodes that found no spare lane
+                if (!more_starts) break;
+                qt = ts; qa = sl * N; qon = own_start;
+            }
+            // ---- build: lookup + exp in the lanes that own a query
+            int cls_a = -2, cls_b = -2;
+            double ba = 0.0, bb = 0.0, omega = 0.0;
+            if (qon) {
+                const Lookup q = curve_lookup(c, qt);
+                ba = q.ba; bb = q.bb;
+                cls_a = c.knot_class[q.ka];
+                cls_b = bb != 0.0 ? c.knot_class[q.kb] : -2;
+                omega = qa * exp(fma(ba, c.log_df[q.ka], bb * c.log_df[q.kb]));
+                pv += omega;
+            }
+            ADR_STAMP(2);   // lookup + exp
+            if (!DELTA) continue;
+            const bool greeks = qon && !(cls_a == -2 && cls_b == -2);
+            if (!greeks) { omega = 0.0; cls_a = -2; cls_b = -2; }
+            // ---- consume: the groups walk their nodes in lockstep, node n sits in lane gbase + n
+            unsigned long long any_row = __ballot(greeks);
+#pragma unroll
+            for (int off = L; off < 64; off <<= 1) any_row |= any_row >> off;
+            any_row &= kGroupMask;
+            while (any_row) {
+                const int n = __builtin_ctzll(any_row);
+                any_row &= any_row - 1;
+                const int src = gbase + n;
+                const int ca = __shfl(cls_a, src, 64), cb = __shfl(cls_b, src, 64);
+                const double om = shfl_d(omega, src), wa = shfl_d(ba, src), wb = shfl_d(bb, src);
+                const int ra = ca >= 0 ? ca : zero_row, rb = cb >= 0 ? cb : zero_row;
+                const bool mini_a = ca <= -3, mini_b = cb <= -3;
+                const bool any_mini = __ballot(mini_a || mini_b) != 0;
+
+                // v for this lane's pillars: core rows (the zero row for anything else) ...
+                double v[PPL];
+                {
+                    const double* lja = c.ljc + ra * c.pc_pad;
+                    const double* ljb = c.ljc + rb * c.pc_pad;
+#pragma unroll
+                    for (int k = 0; k < PPL; ++k) v[k] = fma(wb, ljb[col[k]], wa * lja[col[k]]);
+                }
+                // ... plus the short-end knots' one or two entries
+                if (any_mini) {
+                    if (mini_a) {
+                        const MiniKnot& m = c.mini[-3 - ca];
+#pragma unroll
+                        for (int k = 0; k < PPL; ++k) {
+                            const int p = l + L * k;
+                            v[k] = fma(wa, p == m.p[0] ? m.lj[0] : (p == m.p[1] ? m.lj[1] : 0.0), v[k]);
+                        }
+                    }
+                    if (mini_b) {
+                        const MiniKnot& m = c.mini[-3 - cb];
+#pragma unroll
+                        for (int k = 0; k < PPL; ++k) {
+                            const int p = l + L * k;
+                            v[k] = fma(wb, p == m.p[0] ? m.lj[0] : (p == m.p[1] ? m.lj[1] : 0.0), v[k]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < PPL; ++k) dacc[k] = fma(om, v[k], dacc[k]);
+                if (GAMMA) {
+                    // rank-1 part: omega * v v^T through the group's LDS slot
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < PPL; ++k) { ubuf[l + L * k] = om * v[k]; vbuf[l + L * k] = v[k]; }
+                    wave_lds_sync();
+                    const double* rowa = c.lcc + ra * c.ec_stride + l;
+                    const double* rowb = c.lcc + rb * c.ec_stride + l;
+                    const double coa = om * wa, cob = om * wb;
+                    // All operands of a batch of entries are fetched before any of them is used: the
+                    // scheduling barrier keeps the compiler from pairing each LDS read with its FMA (which
+                    // would expose one LDS round trip per entry).
+                    constexpr int kBatch = EPG < ADR_FAST_BATCH ? EPG : ADR_FAST_BATCH;
+#pragma unroll
+                    for (int i0 = 0; i0 < EPG; i0 += kBatch) {
+                        double uu[kBatch], vv[kBatch], la[kBatch], lb[kBatch];
+#pragma unroll
+                        for (int i = 0; i < kBatch; ++i) {
+#ifndef ADR_ABLATE_RANK1
+                            uu[i] = ubuf[up[i0 + i]];
+                            vv[i] = vbuf[vq[i0 + i]];
+#else
+                            uu[i] = om; vv[i] = wa;
+#endif
+                            // convexity rows: entry l + L*i of a row sits at row[l + L*i]
+#ifndef ADR_ABLATE_LC
+                            if (i0 + i < CPG) { la[i] = rowa[L * (i0 + i)]; lb[i] = rowb[L * (i0 + i)]; }
+#else
+                            if (i0 + i < CPG) { la[i] = wa; lb[i] = wb; }
+#endif
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < kBatch; ++i) {
+                            double gsum = fma(uu[i], vv[i], acc[i0 + i]);
+                            if (i0 + i < CPG) {
+                                const bool core = CS < EPL || (i0 + i) < core_entries;   // compile-time true unless universal
+                                gsum = fma(core ? cob : 0.0, lb[i], fma(core ? coa : 0.0, la[i], gsum));
+                            }
+                            acc[i0 + i] = gsum;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // convexity of short-end knots: the symmetric 2x2 block [[c0, c1], [c1, c2]] on pillars
+                    // (p0, p1) as two more rank-1 passes: (c0 e0 + c2 e1)(e0 + e1)^T puts c0, c0, c2 on the
+                    // entries (p0,p0), (p0,p1), (p1,p1); ((c1 - c0) e0) e1^T then corrects (p0,p1) to c1.
+                    if (any_mini) {
+#pragma unroll
+                        for (int side = 0; side < 2; ++side) {
+                            const bool mine = side == 0 ? mini_a : mini_b;
+                            if (!__ballot(mine)) continue;
+                            const MiniKnot& m = c.mini[mine ? (-3 - (side == 0 ? ca : cb)) : 0];
+                            const double coef = mine ? (side == 0 ? coa : cob) : 0.0;
+                            const int p0 = m.p[0], p1 = m.p[1];
+                            const double c0 = m.lc[0], c1 = m.lc[1], c2 = m.lc[2];
+#pragma unroll
+                            for (int rnd = 0; rnd < 2; ++rnd) {
+                                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                                for (int k = 0; k < PPL; ++k) {
+                                    const int p = l + L * k;
+                                    double uu, vv;
+                                    if (rnd == 0) {
+                                        uu = p == p0 ? c0 : (p == p1 ? c2 : 0.0);
+                                        vv = (p == p0 || p == p1) ? 1.0 : 0.0;
+                                    } else {
+                                        uu = (p == p0 && p1 >= 0) ? c1 - c0 : 0.0;
+                                        vv = p == p1 ? 1.0 : 0.0;
+                                    }
+                                    ubuf[p] = coef * uu;
+                                    vbuf[p] = vv;
+                                }
+                                wave_lds_sync();
+#pragma unroll
+                                for (int i = 0; i < EPG; ++i) acc[i] = fma(ubuf[up[i]], vbuf[vq[i]], acc[i]);
+                            }
+                        }
+                    }
+                }
+            }
+
+            ADR_STAMP(3);   // node consumption
+        }
+
+        // ---- inputs of the wave's next unit, requested before this unit's stores
+        load_unit(unit + wave_stride);
 
         // ------------------------------------------------------------------ results, one group at a time
 #pragma unroll
@@ -492,8 +499,15 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                 }
             }
         }
+        ADR_STAMP(4);   // outputs
     }
 
+#ifdef ADR_STAMPS
+    if (out.stamps && lane == 0) {
+        unsigned long long* dst = out.stamps + (static_cast<size_t>(blockIdx.x) * kWavesPerBlock + wave) * 8;
+        for (int i = 0; i < 8; ++i) dst[i] = stamp_sum[i];
+    }
+#endif
     // ------------------------------------------------------------------------ block partial of the aggregate
     if (out.block_partials) {
         // gamma: packed 64-lane layout -> 4x4 blocks through the wave's slot
