@@ -217,6 +217,16 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
         vq[i] = on ? cv.ent_pq[2 * e + 1] : 0;
     }
 
+    // Output map of this lane: it writes elements 2*lane, 2*lane + 1 of each 128-element band (4 rows of 32) of
+    // a trade's matrix, so every store instruction covers 1 KB of consecutive addresses; two int16 packed
+    // entry indices per band, -1 where the matrix is structurally zero.
+    int mm[GAMMA ? 8 : 1];
+    if (GAMMA) {
+#pragma unroll
+        for (int band = 0; band < 8; ++band)
+            mm[band] = *reinterpret_cast<const int*>(cv.out_map + 2 * lane + band * 128);
+    }
+
     // running portfolio sums of this wave: pv per group (lane l == 0), delta per group lane/pillar,
     // gamma in the 64-lane packed layout (entry lane + 64 s)
     double tot_pv = 0.0, tot_delta[PPL], tot_gamma[GAMMA ? EPL : 1];
@@ -482,19 +492,36 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                     for (int i = 0; i < EPG; ++i) slot[l + L * i] = acc[i];
                 }
                 wave_lds_sync();
+                // LDS reads of a trade in two batches: the running-total slice + bands 0-3, then bands 4-7
+                double* gm = out.gamma ? out.gamma + static_cast<int64_t>(tt) * (kPillarPad * kPillarPad) + 2 * lane : nullptr;
 #pragma unroll
-                for (int s = 0; s < EPL; ++s) tot_gamma[s] += slot[lane + 64 * s];
-                if (out.gamma) {
-                    // lane writes elements 2*lane, 2*lane + 1 of each 128-element band (4 rows of 32): every
-                    // store instruction covers 1 KB of consecutive addresses
-                    double* gm = out.gamma + static_cast<int64_t>(tt) * (kPillarPad * kPillarPad) + 2 * lane;
-                    const int16_t* om = s_omap + 2 * lane;
+                for (int half = 0; half < 2; ++half) {
+                    double ts_[EPL], gv[8];
+                    if (half == 0) {
 #pragma unroll
-                    for (int band = 0; band < 8; ++band) {
-                        const int m0 = om[band * 128], m1 = om[band * 128 + 1];
-                        const double g0 = m0 >= 0 ? slot[m0] * 1e-8 : 0.0;
-                        const double g1 = m1 >= 0 ? slot[m1] * 1e-8 : 0.0;
-                        *reinterpret_cast<double2*>(gm + band * 128) = make_double2(g0, g1);
+                        for (int s = 0; s < EPL; ++s) ts_[s] = slot[lane + 64 * s];
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int band = 4 * half + b;
+                        const int m0 = static_cast<int16_t>(mm[band] & 0xffff), m1 = mm[band] >> 16;
+                        gv[2 * b] = slot[m0 < 0 ? 0 : m0];
+                        gv[2 * b + 1] = slot[m1 < 0 ? 0 : m1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (half == 0) {
+#pragma unroll
+                        for (int s = 0; s < EPL; ++s) tot_gamma[s] += ts_[s];
+                    }
+                    if (gm) {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int band = 4 * half + b;
+                            const int m0 = static_cast<int16_t>(mm[band] & 0xffff), m1 = mm[band] >> 16;
+                            const double g0 = m0 >= 0 ? gv[2 * b] * 1e-8 : 0.0;
+                            const double g1 = m1 >= 0 ? gv[2 * b + 1] * 1e-8 : 0.0;
+                            *reinterpret_cast<double2*>(gm + band * 128) = make_double2(g0, g1);
+                        }
                     }
                 }
             }
