@@ -47,17 +47,28 @@ namespace adr {
 
 namespace {
 
+#ifndef ADR_LDS_FENCE
+#define ADR_LDS_FENCE 0
+#endif
 constexpr int kBlockThreads = kFastThreads;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 
 __device__ __forceinline__ double shfl_d(double x, int src) { return __shfl(x, src, 64); }
 
-// Same-wave LDS hand-off: LDS operations of one wave execute in order; the fences only stop the
-// compiler from moving accesses across the hand-off point.
+// Same-wave LDS hand-off.  The DS instructions of one wavefront are executed in issue order, so data written
+// by one lane is visible to a later read of another lane of the same wave without waiting for the write to
+// retire; all that is needed is that the compiler keeps the program order of the accesses (it does for
+// may-aliasing LDS accesses; the empty asm is a belt-and-braces compiler barrier with no instructions).
 __device__ __forceinline__ void wave_lds_sync() {
+#if ADR_LDS_FENCE
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+#endif
 }
 
 #ifdef ADR_STAMPS
