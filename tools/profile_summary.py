@@ -4,15 +4,16 @@
 HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are collected in
 separate passes, are in KiB, and on gfx950 FETCH_SIZE reports half the bytes of a coalesced streaming read, so
 read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact for 16-byte-per-lane stores (the gamma rows)."""
-import csv, glob, json, shutil, sys
+import csv, glob, json, os, shutil, sys
 tag, rnd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "r01")
 base = f"gpurun_out/prof_{tag}"
-stats = glob.glob(f"{base}/trace/*/*kernel_stats.csv")[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+stats = newest(f"{base}/trace/*/*kernel_stats.csv")
 shutil.copy(stats, f"profiles/{rnd}_{tag}_kernel_stats.csv")
 out = {"tag": tag}
 for name in ("fetch", "write"):
     vals = {}
-    for r in csv.DictReader(open(glob.glob(f"{base}/{name}/*/*counter_collection.csv")[0])):
+    for r in csv.DictReader(open(newest(f"{base}/{name}/*/*counter_collection.csv"))):
         if "price_fast" in r["Kernel_Name"] or "price_general" in r["Kernel_Name"]:
             vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for k, v in vals.items():
