@@ -323,6 +323,22 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
         const bool more_starts = __ballot(own_start) != 0, more_fixed = __ballot(own_fixed) != 0;
         ADR_STAMP(1);   // node folding
 
+        // convexity row whose weight is still to be added (see the consume loop), per group
+        int carry_row = zero_row;
+        double carry_w = 0.0;
+        auto lc_row_pass = [&](int row, double w) {
+            const double* src = c.lcc + row * c.ec_stride + l;
+            double lr[CPG > 0 ? CPG : 1];
+#pragma unroll
+            for (int i = 0; i < CPG; ++i) lr[i] = src[L * i];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < CPG; ++i) {
+                const bool core = CS < EPL || i < core_entries;
+                acc[i] = fma(core ? w : 0.0, lr[i], acc[i]);
+            }
+        };
+
         for (int pass = 0; pass < 3; ++pass) {
             if (pass == 1) {            // fixed coupons that did not merge into a float payment node
                 if (!more_fixed) continue;
@@ -396,30 +412,31 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 #pragma unroll
                     for (int k = 0; k < PPL; ++k) { ubuf[l + L * k] = om * v[k]; vbuf[l + L * k] = v[k]; }
                     wave_lds_sync();
+                    // Convexity rows.  Consecutive nodes of a swap usually share a knot (the right neighbour of
+                    // one payment time is the left neighbour of the next), so the right-hand row is not read
+                    // here: its weight is carried to the next node and joins that node's left-hand weight when
+                    // the rows agree; a carried row that does not match is added on its own first.
+                    if (__ballot(carry_row != zero_row && carry_row != ra)) {
+                        const bool flush = carry_row != ra;
+                        lc_row_pass(flush ? carry_row : zero_row, flush ? carry_w : 0.0);
+                        if (flush) { carry_row = zero_row; carry_w = 0.0; }
+                    }
                     const double* rowa = c.lcc + ra * c.ec_stride + l;
-                    const double* rowb = c.lcc + rb * c.ec_stride + l;
-                    const double coa = om * wa, cob = om * wb;
+                    const double coa = om * wa + (carry_row == ra ? carry_w : 0.0), cob = om * wb;
+                    carry_row = rb; carry_w = cob;
                     // All operands of a batch of entries are fetched before any of them is used: the
                     // scheduling barrier keeps the compiler from pairing each LDS read with its FMA (which
                     // would expose one LDS round trip per entry).
                     constexpr int kBatch = EPG < ADR_FAST_BATCH ? EPG : ADR_FAST_BATCH;
 #pragma unroll
                     for (int i0 = 0; i0 < EPG; i0 += kBatch) {
-                        double uu[kBatch], vv[kBatch], la[kBatch], lb[kBatch];
+                        double uu[kBatch], vv[kBatch], la[kBatch];
 #pragma unroll
                         for (int i = 0; i < kBatch; ++i) {
-#ifndef ADR_ABLATE_RANK1
                             uu[i] = ubuf[up[i0 + i]];
                             vv[i] = vbuf[vq[i0 + i]];
-#else
-                            uu[i] = om; vv[i] = wa;
-#endif
                             // convexity rows: entry l + L*i of a row sits at row[l + L*i]
-#ifndef ADR_ABLATE_LC
-                            if (i0 + i < CPG) { la[i] = rowa[L * (i0 + i)]; lb[i] = rowb[L * (i0 + i)]; }
-#else
-                            if (i0 + i < CPG) { la[i] = wa; lb[i] = wb; }
-#endif
+                            if (i0 + i < CPG) la[i] = rowa[L * (i0 + i)];
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -427,7 +444,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                             double gsum = fma(uu[i], vv[i], acc[i0 + i]);
                             if (i0 + i < CPG) {
                                 const bool core = CS < EPL || (i0 + i) < core_entries;   // compile-time true unless universal
-                                gsum = fma(core ? cob : 0.0, lb[i], fma(core ? coa : 0.0, la[i], gsum));
+                                gsum = fma(core ? coa : 0.0, la[i], gsum);
                             }
                             acc[i0 + i] = gsum;
                         }
@@ -442,11 +459,13 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                             const bool mine = side == 0 ? mini_a : mini_b;
                             if (!__ballot(mine)) continue;
                             const MiniKnot& m = c.mini[mine ? (-3 - (side == 0 ? ca : cb)) : 0];
-                            const double coef = mine ? (side == 0 ? coa : cob) : 0.0;
+                            const double coef = mine ? om * (side == 0 ? wa : wb) : 0.0;
                             const int p0 = m.p[0], p1 = m.p[1];
                             const double c0 = m.lc[0], c1 = m.lc[1], c2 = m.lc[2];
 #pragma unroll
                             for (int rnd = 0; rnd < 2; ++rnd) {
+                                // most short-end knots depend on one pillar only: nothing to correct
+                                if (rnd == 1 && !__ballot(mine && p1 >= 0)) continue;
                                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                                 for (int k = 0; k < PPL; ++k) {
@@ -473,6 +492,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 
             ADR_STAMP(3);   // node consumption
         }
+        if (GAMMA && __ballot(carry_row != zero_row)) lc_row_pass(carry_row, carry_w);
 
         // ---- inputs of the wave's next unit, requested before this unit's stores
         load_unit(unit + wave_stride);
