@@ -51,6 +51,7 @@ struct adr_ctx {
     int n_cu = 0;
     size_t lds_limit = 0;
     double* partials = nullptr;     // [max_blocks][kAggStride] scratch for the aggregate
+    double* dump = nullptr;                 // [32*32] store sink (kernels.hpp, OutputsDev::dump)
     unsigned long long* stamps = nullptr;   // diagnostic builds: [max_blocks*16][8]
     int max_blocks = 0;
 };
@@ -109,6 +110,11 @@ int adr_init(int device_ordinal, adr_ctx** out) {
     e = hipMalloc(reinterpret_cast<void**>(&ctx->partials),
                   sizeof(double) * static_cast<size_t>(ctx->max_blocks) * adr::kAggStride);
     if (e != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return fail_hip(e, "hipMalloc(partials)"); }
+    e = hipMalloc(reinterpret_cast<void**>(&ctx->dump), sizeof(double) * adr::kPillarPad * adr::kPillarPad);
+    if (e != hipSuccess) {
+        hipFree(ctx->partials); hipStreamDestroy(ctx->stream); delete ctx;
+        return fail_hip(e, "hipMalloc(dump)");
+    }
 #ifdef ADR_STAMPS
     hipMalloc(reinterpret_cast<void**>(&ctx->stamps), sizeof(unsigned long long) * ctx->max_blocks * 16 * 8);
     hipMemset(ctx->stamps, 0, sizeof(unsigned long long) * ctx->max_blocks * 16 * 8);
@@ -128,6 +134,7 @@ void adr_free_ctx(adr_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->partials) hipFree(ctx->partials);
+    if (ctx->dump) hipFree(ctx->dump);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -160,7 +167,7 @@ int adr_curve_layout_host(int K, int P, const double* times, const double* dfs, 
     const std::string err = adr::build_curve_tables(K, P, times, dfs, jac, hess, t);
     if (!err.empty()) return fail(ADR_ERR_INVALID, "adr_curve_layout_host: " + err);
     adr::CurveDev d{};
-    d.K = t.K; d.Kc = t.Kc; d.Kcore = t.Kcore; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Eu = t.Eu; d.n_mini = t.n_mini;
+    d.K = t.K; d.Kc = t.Kc; d.Kcore = t.Kcore; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Eu = t.Eu; d.epl = t.epl; d.n_mini = t.n_mini;
     info[0] = t.packed_ok ? 1 : 0; info[1] = t.Pc; info[2] = t.Ec; info[3] = t.Eu; info[4] = t.epl;
     info[5] = t.Kcore; info[6] = t.n_mini;
     info[7] = t.packed_ok ? static_cast<int64_t>(adr::fast_kernel_lds_bytes(d, t.has_hess)) : 0;
@@ -391,6 +398,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
 
     adr::OutputsDev o;
     o.stamps = ctx->stamps;
+    o.dump = ctx->dump;
     o.pv = (req_mask & ADR_REQ_VALUE) ? pv_dev : nullptr;
     o.delta = (req_mask & ADR_REQ_DELTA) ? delta_dev : nullptr;
     o.gamma = want_gamma ? gamma_dev : nullptr;

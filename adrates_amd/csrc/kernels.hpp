@@ -91,6 +91,7 @@ struct OutputsDev {
     double* delta;           // [n*P] or null
     double* gamma;           // [n*P*P] or null
     double* block_partials;  // [grid][kAggStride] or null
+    double* dump;            // [32*32] sink for the gamma stores of the idle trade slot of a wave's last unit
     unsigned long long* stamps;  // diagnostic builds only (ADR_STAMPS): [grid*waves][8] cycle sums per phase
 };
 

@@ -142,11 +142,18 @@ __device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
     return r;
 }
 
+// Doubles of LDS per wavefront (see the carve-up in the kernel).
+__host__ __device__ constexpr int slot_doubles(bool gamma, int epl, int groups) {
+    const int hand_off = 64 * 3 + (gamma ? groups * 2 * kPillarPad : 0);
+    const int staging = gamma ? 64 * epl : 0;
+    return hand_off > staging ? hand_off : staging;
+}
+
 // DELTA/GAMMA: what to compute; EPL: packed entries / 64 and CS: how many of those 64-entry slots hold core
 // pairs (both curve dependent; compile-time so that the loops below have no branches); G: trades per wavefront.
 // CS == EPL is the universal variant: it reads a convexity slice for every slot and zeroes the coefficient of
 // the slots that are not core pairs at run time.
-template <bool DELTA, bool GAMMA, int EPL, int CS, int G>
+template <bool DELTA, bool GAMMA, bool STORE, int EPL, int CS, int G>
 __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
     constexpr int L = 64 / G;                          // lanes per trade
     constexpr int PPL = kPillarPad / L;                // pillars per lane: l + L*k
@@ -161,20 +168,23 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     const int ec_stride = cv.Ec + 1;
     const int n_ljc = (cv.Kcore + 1) * cv.pc_pad;            // + the all-zero row
     const int n_lcc = GAMMA ? (cv.Kcore + 1) * ec_stride : 0;
-    const int n_slack = GAMMA ? 64 * EPL : 0;                // zeros behind the last row (rows are read 64*EPL wide)
-    constexpr int kSlotDoubles = GAMMA ? (64 * EPL > G * 2 * kPillarPad ? 64 * EPL : G * 2 * kPillarPad) : 0;
+    // zeros behind the last row: a row is read 64*CS entries wide; CS < EPL means CS = ceil(Ec / 64)
+    const int n_slack = GAMMA ? (CS < EPL ? 64 : 64 * EPL) : 0;
+    // per-wave slot: the lanes' node scalars (omega, ba, bb: 3 x 64 doubles), then (gamma) the groups' u/v
+    // hand-off buffers; the front is reused as the packed-ladder staging area at output time
+    constexpr int kRecDoubles = 64 * 3;
+    constexpr int kSlotDoubles = slot_doubles(GAMMA, EPL, G);
     MiniKnot* s_mini = reinterpret_cast<MiniKnot*>(smem_raw);
     double* s_x = reinterpret_cast<double*>(s_mini + cv.n_mini);
     double* s_log = s_x + cv.K;
     double* s_invx = s_log + cv.Kc;
     double* s_ljc = s_invx + cv.Kc;
     double* s_lcc = s_ljc + n_ljc;
-    double* s_slot = s_lcc + n_lcc + n_slack;                // per wave: u/v hand-off buffers, reused as the
-                                                             // packed-ladder staging area at output time
+    const int n_front = cv.K + 2 * cv.Kc + n_ljc + n_lcc + n_slack;
+    double* s_slot = s_x + n_front + (n_front & 1);          // 16-byte aligned (the records are read as b128)
     int16_t* s_first = reinterpret_cast<int16_t*>(s_slot + kWavesPerBlock * kSlotDoubles);
     int16_t* s_comp = s_first + cv.K;
     int16_t* s_class = s_comp + cv.K;
-    int16_t* s_omap = s_class + cv.Kc;                       // [32*32] packed entry of gamma[r][c], -1 if none
 
     {
         const double* src = reinterpret_cast<const double*>(cv.mini);
@@ -191,8 +201,6 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
         s_invx[i] = cv.inv_x[i];
         s_class[i] = cv.knot_class[i];
     }
-    if (GAMMA)
-        for (int i = threadIdx.x; i < kPillarPad * kPillarPad; i += kBlockThreads) s_omap[i] = cv.out_map[i];
     for (int i = threadIdx.x; i < n_ljc; i += kBlockThreads) s_ljc[i] = cv.ljc[i];
     for (int i = threadIdx.x; i < n_lcc; i += kBlockThreads) s_lcc[i] = cv.lcc[i];
     for (int i = threadIdx.x; i < n_slack; i += kBlockThreads) s_lcc[n_lcc + i] = 0.0;
@@ -208,7 +216,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     const int g = lane / L, l = lane % L;
     const int gbase = g * L;                      // first lane of this lane's group
     double* slot = s_slot + wave * kSlotDoubles;
-    double* ubuf = slot + g * 2 * kPillarPad;     // this group's omega*v and v, 32 doubles each
+    double* rec = slot;                           // node scalars: omega[64], ba[64], bb[64]
+    double* ubuf = slot + kRecDoubles + g * 2 * kPillarPad;   // this group's omega*v and v, 32 doubles each
     double* vbuf = ubuf + kPillarPad;
     const int P = cv.P;
     const int bi = lane >> 3, bj = lane & 7;
@@ -274,7 +283,16 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             nx_meta = tr.row_meta[row]; nx_trade = tr.row_trade[row];
         }
     };
+    // The wait for a unit's inputs is placed by hand at the END of the previous iteration, where exactly the
+    // unit's 16 result stores are younger than the loads (vector memory operations retire in order, so the
+    // wait is "all but the last 16").  Left to the top of the loop, the wait would have to be correct for the
+    // entry edge as well and would drain the stores too.
+    auto pin_next = [&]() {
+        asm volatile("" : "+v"(nx_tp), "+v"(nx_ts), "+v"(nx_al), "+v"(nx_xtp), "+v"(nx_xpay), "+v"(nx_N),
+                          "+v"(nx_spread), "+v"(nx_meta), "+v"(nx_trade));
+    };
     load_unit(unit);
+    pin_next();
 
     for (; unit < n_units; unit += wave_stride) {
         // ------------------------------------------------------------------ this group's trade
@@ -285,6 +303,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
         const int n_flt = nx_meta & 0xff, n_fix = (nx_meta >> 8) & 0xff;
         const double sl = (nx_meta & 0x10000) ? -1.0 : 1.0, sf = (nx_meta & 0x20000) ? -1.0 : 1.0;
         ADR_STAMP(0);   // waiting for the unit's inputs
+        if (!GAMMA) load_unit(unit + wave_stride);   // small kernels have the registers to fetch a whole unit ahead
 
         double pv = 0.0, dacc[PPL], acc[EPG];
 #pragma unroll
@@ -362,17 +381,33 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             if (!DELTA) continue;
             const bool greeks = qon && !(cls_a == -2 && cls_b == -2);
             if (!greeks) { omega = 0.0; cls_a = -2; cls_b = -2; }
-            // ---- consume: the groups walk their nodes in lockstep, node n sits in lane gbase + n
+            // ---- consume: the groups walk their nodes in lockstep.  Every lane leaves its node's three doubles
+            // in LDS; node n of a group is then two broadcast reads plus one ds_bpermute for the packed knot
+            // classes (instead of eight ds_bpermute), issued one node ahead so that the round trip hides
+            // behind the previous node's work.
+            const int classes = (cls_a & 0xffff) | (cls_b << 16);
+            __builtin_amdgcn_wave_barrier();
+            rec[lane] = omega; rec[64 + lane] = ba; rec[128 + lane] = bb;
+            wave_lds_sync();
             unsigned long long any_row = __ballot(greeks);
 #pragma unroll
             for (int off = L; off < 64; off <<= 1) any_row |= any_row >> off;
             any_row &= kGroupMask;
-            while (any_row) {
-                const int n = __builtin_ctzll(any_row);
+            if (!any_row) continue;
+            int n = __builtin_ctzll(any_row);
+            any_row &= any_row - 1;
+            double nx_om = rec[gbase + n], nx_wa = rec[64 + gbase + n], nx_wb = rec[128 + gbase + n];
+            int nx_classes = __shfl(classes, gbase + n, 64);
+            while (true) {
+                const bool has_next = any_row != 0;
+                const int n_next = has_next ? __builtin_ctzll(any_row) : n;   // nothing left: read n again
                 any_row &= any_row - 1;
-                const int src = gbase + n;
-                const int ca = __shfl(cls_a, src, 64), cb = __shfl(cls_b, src, 64);
-                const double om = shfl_d(omega, src), wa = shfl_d(ba, src), wb = shfl_d(bb, src);
+                const double om = nx_om, wa = nx_wa, wb = nx_wb;
+                const int ca = static_cast<int16_t>(nx_classes & 0xffff), cb = nx_classes >> 16;
+                nx_om = rec[gbase + n_next]; nx_wa = rec[64 + gbase + n_next]; nx_wb = rec[128 + gbase + n_next];
+                nx_classes = __shfl(classes, gbase + n_next, 64);
+                n = n_next;
+                __builtin_amdgcn_sched_barrier(0);
                 const int ra = ca >= 0 ? ca : zero_row, rb = cb >= 0 ? cb : zero_row;
                 const bool mini_a = ca <= -3, mini_b = cb <= -3;
                 const bool any_mini = __ballot(mini_a || mini_b) != 0;
@@ -383,7 +418,11 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                     const double* lja = c.ljc + ra * c.pc_pad;
                     const double* ljb = c.ljc + rb * c.pc_pad;
 #pragma unroll
+#ifndef ADR_ABLATE_V
                     for (int k = 0; k < PPL; ++k) v[k] = fma(wb, ljb[col[k]], wa * lja[col[k]]);
+#else
+                    for (int k = 0; k < PPL; ++k) v[k] = wb * ra + wa * rb;
+#endif
                 }
                 // ... plus the short-end knots' one or two entries
                 if (any_mini) {
@@ -409,8 +448,10 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                 if (GAMMA) {
                     // rank-1 part: omega * v v^T through the group's LDS slot
                     __builtin_amdgcn_wave_barrier();
+#ifndef ADR_ABLATE_UVWRITE
 #pragma unroll
                     for (int k = 0; k < PPL; ++k) { ubuf[l + L * k] = om * v[k]; vbuf[l + L * k] = v[k]; }
+#endif
                     wave_lds_sync();
                     // Convexity rows.  Consecutive nodes of a swap usually share a knot (the right neighbour of
                     // one payment time is the left neighbour of the next), so the right-hand row is not read
@@ -433,10 +474,18 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                         double uu[kBatch], vv[kBatch], la[kBatch];
 #pragma unroll
                         for (int i = 0; i < kBatch; ++i) {
+#ifndef ADR_ABLATE_RANK1
                             uu[i] = ubuf[up[i0 + i]];
                             vv[i] = vbuf[vq[i0 + i]];
+#else
+                            uu[i] = om; vv[i] = wa;
+#endif
                             // convexity rows: entry l + L*i of a row sits at row[l + L*i]
+#ifndef ADR_ABLATE_LC
                             if (i0 + i < CPG) la[i] = rowa[L * (i0 + i)];
+#else
+                            if (i0 + i < CPG) la[i] = wb;
+#endif
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -488,16 +537,18 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                         }
                     }
                 }
+                if (!has_next) break;
             }
 
             ADR_STAMP(3);   // node consumption
         }
         if (GAMMA && __ballot(carry_row != zero_row)) lc_row_pass(carry_row, carry_w);
 
-        // ---- inputs of the wave's next unit, requested before this unit's stores
-        load_unit(unit + wave_stride);
-
-        // ------------------------------------------------------------------ results, one group at a time
+        // ------------------------------------------------------------------ results
+        // pv and delta first: after them nothing refers to the per-lane trade index any more, so the next
+        // unit's inputs can be loaded straight into the registers this unit used (a copy at the loop's back
+        // edge would have to wait for the loads - and, vector memory operations retiring in order, for
+        // every store issued behind them).
 #pragma unroll
         for (int off = 1; off < L; off <<= 1) pv += __shfl_xor(pv, off, 64);
         if (live && l == 0) {
@@ -512,11 +563,17 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                 tot_delta[k] += dacc[k];
             }
         }
+        int group_trade[G];
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg) group_trade[gg] = __builtin_amdgcn_readfirstlane(__shfl(t, gg * L, 64));
+
+        // ---- inputs of the wave's next unit, requested before this unit's (large) gamma stores
+        if (GAMMA) load_unit(unit + wave_stride);
+
         if (GAMMA) {
 #pragma unroll
             for (int gg = 0; gg < G; ++gg) {
-                const int tt = __builtin_amdgcn_readfirstlane(__shfl(t, gg * L, 64));
-                if (tt < 0) continue;
+                const int tt = group_trade[gg];   // < 0: idle slot of the last unit, stored to the sink
                 __builtin_amdgcn_wave_barrier();
                 if (g == gg) {
 #pragma unroll
@@ -524,18 +581,21 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                 }
                 wave_lds_sync();
                 // LDS reads of a trade in two batches: the running-total slice + bands 0-3, then bands 4-7
-                double* gm = out.gamma ? out.gamma + static_cast<int64_t>(tt) * (kPillarPad * kPillarPad) + 2 * lane : nullptr;
+                double* gm = (tt >= 0 ? out.gamma + static_cast<int64_t>(tt) * (kPillarPad * kPillarPad) : out.dump) + 2 * lane;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     double ts_[EPL], gv[8];
+                    int mbs[4];
                     if (half == 0) {
 #pragma unroll
                         for (int s = 0; s < EPL; ++s) ts_[s] = slot[lane + 64 * s];
                     }
 #pragma unroll
+                    for (int b = 0; b < 4; ++b) mbs[b] = mm[4 * half + b];
+#pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        const int band = 4 * half + b;
-                        const int m0 = static_cast<int16_t>(mm[band] & 0xffff), m1 = mm[band] >> 16;
+                        const int mb = mbs[b];
+                        const int m0 = static_cast<int16_t>(mb & 0xffff), m1 = mb >> 16;
                         gv[2 * b] = slot[m0 < 0 ? 0 : m0];
                         gv[2 * b + 1] = slot[m1 < 0 ? 0 : m1];
                     }
@@ -544,11 +604,12 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 #pragma unroll
                         for (int s = 0; s < EPL; ++s) tot_gamma[s] += ts_[s];
                     }
-                    if (gm) {
+                    if (STORE) {
 #pragma unroll
                         for (int b = 0; b < 4; ++b) {
                             const int band = 4 * half + b;
-                            const int m0 = static_cast<int16_t>(mm[band] & 0xffff), m1 = mm[band] >> 16;
+                            const int mb = mbs[b];
+                            const int m0 = static_cast<int16_t>(mb & 0xffff), m1 = mb >> 16;
                             const double g0 = m0 >= 0 ? gv[2 * b] * 1e-8 : 0.0;
                             const double g1 = m1 >= 0 ? gv[2 * b + 1] * 1e-8 : 0.0;
                             *reinterpret_cast<double2*>(gm + band * 128) = make_double2(g0, g1);
@@ -558,6 +619,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             }
         }
         ADR_STAMP(4);   // outputs
+        pin_next();
     }
 
 #ifdef ADR_STAMPS
@@ -577,7 +639,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             wave_lds_sync();
 #pragma unroll
             for (int e = 0; e < kGammaPerLane; ++e) {
-                const int m = s_omap[(4 * bi + (e >> 2)) * kPillarPad + 4 * bj + (e & 3)];
+                const int m = cv.out_map[(4 * bi + (e >> 2)) * kPillarPad + 4 * bj + (e & 3)];
                 blk_gamma[e] = m >= 0 ? slot[m] * 1e-8 : 0.0;
             }
         }
@@ -637,22 +699,29 @@ constexpr int kGroups = ADR_FAST_GROUPS;
 // entries) or, for anything else, the universal variant (EPL, EPL).
 using KernelFn = void (*)(CurveDev, TradesDev, OutputsDev);
 
-template <int EPL>
+template <int EPL, bool STORE>
 KernelFn gamma_kernel(int core_slots) {
-    if (core_slots == EPL - 1 && EPL > 1) return &price_fast_kernel<true, true, EPL, (EPL > 1 ? EPL - 1 : 1), kGroups>;
-    return &price_fast_kernel<true, true, EPL, EPL, kGroups>;
+    if (core_slots == EPL - 1 && EPL > 1)
+        return &price_fast_kernel<true, true, STORE, EPL, (EPL > 1 ? EPL - 1 : 1), kGroups>;
+    return &price_fast_kernel<true, true, STORE, EPL, EPL, kGroups>;
 }
 
-KernelFn pick_kernel(const CurveDev& cv, bool want_delta, bool want_gamma) {
-    if (!want_gamma)
-        return want_delta ? &price_fast_kernel<true, false, 1, 1, kGroups> : &price_fast_kernel<false, false, 1, 1, kGroups>;
+template <bool STORE>
+KernelFn gamma_kernel_for(const CurveDev& cv) {
     const int core_slots = (cv.Ec + 63) >> 6;
     switch (cv.epl) {
-        case 3: return gamma_kernel<3>(core_slots);
-        case 4: return gamma_kernel<4>(core_slots);
-        case 6: return gamma_kernel<6>(core_slots);
-        default: return gamma_kernel<9>(core_slots);
+        case 3: return gamma_kernel<3, STORE>(core_slots);
+        case 4: return gamma_kernel<4, STORE>(core_slots);
+        case 6: return gamma_kernel<6, STORE>(core_slots);
+        default: return gamma_kernel<9, STORE>(core_slots);
     }
+}
+
+KernelFn pick_kernel(const CurveDev& cv, bool want_delta, bool want_gamma, bool store_gamma) {
+    if (!want_gamma)
+        return want_delta ? &price_fast_kernel<true, false, false, 1, 1, kGroups>
+                          : &price_fast_kernel<false, false, false, 1, 1, kGroups>;
+    return store_gamma ? gamma_kernel_for<true>(cv) : gamma_kernel_for<false>(cv);
 }
 
 }  // namespace
@@ -660,12 +729,13 @@ KernelFn pick_kernel(const CurveDev& cv, bool want_delta, bool want_gamma) {
 int fast_kernel_groups() { return kGroups; }
 
 size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
-    const size_t slot = gamma ? std::max<size_t>(64 * cv.epl, kGroups * 2 * kPillarPad) : 0;
+    const size_t slot = slot_doubles(gamma, cv.epl, kGroups);
     size_t doubles = static_cast<size_t>(cv.K) + 2 * cv.Kc + static_cast<size_t>(cv.Kcore + 1) * cv.pc_pad +
-                     (gamma ? static_cast<size_t>(cv.Kcore + 1) * (cv.Ec + 1) + 64 * cv.epl : 0) +
-                     kWavesPerBlock * slot;
+                     (gamma ? static_cast<size_t>(cv.Kcore + 1) * (cv.Ec + 1) + (((cv.Ec + 63) >> 6) == cv.epl - 1 && cv.epl > 1 ? 64 : 64 * cv.epl) : 0);
+    doubles += doubles & 1;   // the slots start on a 16-byte boundary
+    doubles += kWavesPerBlock * slot;
     size_t tables = sizeof(MiniKnot) * cv.n_mini + sizeof(double) * doubles +
-                    sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + cv.Kc + (gamma ? kPillarPad * kPillarPad : 0));
+                    sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + cv.Kc);
     size_t reduce = sizeof(double) * kWavesPerBlock * kAggStride;
     size_t need = tables > reduce ? tables : reduce;
     return (need + 15) & ~static_cast<size_t>(15);
@@ -674,7 +744,7 @@ size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
 hipError_t launch_price_fast(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                              bool want_gamma, int n_blocks, hipStream_t stream) {
     const size_t lds = fast_kernel_lds_bytes(cv, want_gamma);
-    hipLaunchKernelGGL(pick_kernel(cv, want_delta, want_gamma), dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv,
+    hipLaunchKernelGGL(pick_kernel(cv, want_delta, want_gamma, out.gamma != nullptr), dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv,
                        tr, out);
     return hipGetLastError();
 }
@@ -692,12 +762,16 @@ hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes) {
     hipError_t e = set_general_kernel_lds_limit(general_bytes);
     if (e != hipSuccess) return e;
     const void* fns[] = {
-        reinterpret_cast<const void*>(gamma_kernel<3>(2)), reinterpret_cast<const void*>(gamma_kernel<3>(3)),
-        reinterpret_cast<const void*>(gamma_kernel<4>(3)), reinterpret_cast<const void*>(gamma_kernel<4>(4)),
-        reinterpret_cast<const void*>(gamma_kernel<6>(5)), reinterpret_cast<const void*>(gamma_kernel<6>(6)),
-        reinterpret_cast<const void*>(gamma_kernel<9>(8)), reinterpret_cast<const void*>(gamma_kernel<9>(9)),
-        reinterpret_cast<const void*>(&price_fast_kernel<true, false, 1, 1, kGroups>),
-        reinterpret_cast<const void*>(&price_fast_kernel<false, false, 1, 1, kGroups>),
+        reinterpret_cast<const void*>(gamma_kernel<3, true>(2)), reinterpret_cast<const void*>(gamma_kernel<3, true>(3)),
+        reinterpret_cast<const void*>(gamma_kernel<4, true>(3)), reinterpret_cast<const void*>(gamma_kernel<4, true>(4)),
+        reinterpret_cast<const void*>(gamma_kernel<6, true>(5)), reinterpret_cast<const void*>(gamma_kernel<6, true>(6)),
+        reinterpret_cast<const void*>(gamma_kernel<9, true>(8)), reinterpret_cast<const void*>(gamma_kernel<9, true>(9)),
+        reinterpret_cast<const void*>(gamma_kernel<3, false>(2)), reinterpret_cast<const void*>(gamma_kernel<3, false>(3)),
+        reinterpret_cast<const void*>(gamma_kernel<4, false>(3)), reinterpret_cast<const void*>(gamma_kernel<4, false>(4)),
+        reinterpret_cast<const void*>(gamma_kernel<6, false>(5)), reinterpret_cast<const void*>(gamma_kernel<6, false>(6)),
+        reinterpret_cast<const void*>(gamma_kernel<9, false>(8)), reinterpret_cast<const void*>(gamma_kernel<9, false>(9)),
+        reinterpret_cast<const void*>(&price_fast_kernel<true, false, false, 1, 1, kGroups>),
+        reinterpret_cast<const void*>(&price_fast_kernel<false, false, false, 1, 1, kGroups>),
     };
     for (const void* f : fns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(fast_bytes));
