@@ -499,9 +499,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    // convexity of short-end knots: the symmetric 2x2 block [[c0, c1], [c1, c2]] on pillars
-                    // (p0, p1) as two more rank-1 passes: (c0 e0 + c2 e1)(e0 + e1)^T puts c0, c0, c2 on the
-                    // entries (p0,p0), (p0,p1), (p1,p1); ((c1 - c0) e0) e1^T then corrects (p0,p1) to c1.
+                    // convexity of short-end knots: one to three numbers (the symmetric 2x2 block on pillars
+                    // p0, p1), added by the lanes that own the packed entries (p0,p0), (p0,p1), (p1,p1)
                     if (any_mini) {
 #pragma unroll
                         for (int side = 0; side < 2; ++side) {
@@ -509,30 +508,15 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                             if (!__ballot(mine)) continue;
                             const MiniKnot& m = c.mini[mine ? (-3 - (side == 0 ? ca : cb)) : 0];
                             const double coef = mine ? om * (side == 0 ? wa : wb) : 0.0;
-                            const int p0 = m.p[0], p1 = m.p[1];
-                            const double c0 = m.lc[0], c1 = m.lc[1], c2 = m.lc[2];
 #pragma unroll
-                            for (int rnd = 0; rnd < 2; ++rnd) {
-                                // most short-end knots depend on one pillar only: nothing to correct
-                                if (rnd == 1 && !__ballot(mine && p1 >= 0)) continue;
-                                __builtin_amdgcn_wave_barrier();
+                            for (int j = 0; j < 3; ++j) {
+                                const int e = m.e[j];
+                                if (j > 0 && !__ballot(mine && e >= 0)) continue;   // single-pillar knots: one entry
+                                const bool owner = mine && e >= 0 && (e % L) == l;
+                                const double add = owner ? coef * m.lc[j] : 0.0;
+                                const int at = e / L;
 #pragma unroll
-                                for (int k = 0; k < PPL; ++k) {
-                                    const int p = l + L * k;
-                                    double uu, vv;
-                                    if (rnd == 0) {
-                                        uu = p == p0 ? c0 : (p == p1 ? c2 : 0.0);
-                                        vv = (p == p0 || p == p1) ? 1.0 : 0.0;
-                                    } else {
-                                        uu = (p == p0 && p1 >= 0) ? c1 - c0 : 0.0;
-                                        vv = p == p1 ? 1.0 : 0.0;
-                                    }
-                                    ubuf[p] = coef * uu;
-                                    vbuf[p] = vv;
-                                }
-                                wave_lds_sync();
-#pragma unroll
-                                for (int i = 0; i < EPG; ++i) acc[i] = fma(ubuf[up[i]], vbuf[vq[i]], acc[i]);
+                                for (int i = 0; i < EPG; ++i) acc[i] += (i == at) ? add : 0.0;
                             }
                         }
                     }
