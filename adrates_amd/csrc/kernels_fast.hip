@@ -144,7 +144,7 @@ __device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
 
 // Doubles of LDS per wavefront (see the carve-up in the kernel).
 __host__ __device__ constexpr int slot_doubles(bool gamma, int epl, int groups) {
-    const int hand_off = 64 * 3 + (gamma ? groups * 2 * kPillarPad : 0);
+    const int hand_off = 64 * 3 + 32 + (gamma ? groups * kPillarPad : 0);
     const int staging = gamma ? 64 * epl : 0;
     return hand_off > staging ? hand_off : staging;
 }
@@ -170,9 +170,10 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     const int n_lcc = GAMMA ? (cv.Kcore + 1) * ec_stride : 0;
     // zeros behind the last row: a row is read 64*CS entries wide; CS < EPL means CS = ceil(Ec / 64)
     const int n_slack = GAMMA ? (CS < EPL ? 64 : 64 * EPL) : 0;
-    // per-wave slot: the lanes' node scalars (omega, ba, bb: 3 x 64 doubles), then (gamma) the groups' u/v
-    // hand-off buffers; the front is reused as the packed-ladder staging area at output time
-    constexpr int kRecDoubles = 64 * 3;
+    // per-wave slot: the lanes' node scalars (omega, ba, bb: 3 x 64 doubles; packed knot classes: 64 ints),
+    // then (gamma) the groups' v hand-off buffers; the front is reused as the packed-ladder staging area at
+    // output time
+    constexpr int kRecDoubles = 64 * 3 + 32;
     constexpr int kSlotDoubles = slot_doubles(GAMMA, EPL, G);
     MiniKnot* s_mini = reinterpret_cast<MiniKnot*>(smem_raw);
     double* s_x = reinterpret_cast<double*>(s_mini + cv.n_mini);
@@ -217,8 +218,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     const int gbase = g * L;                      // first lane of this lane's group
     double* slot = s_slot + wave * kSlotDoubles;
     double* rec = slot;                           // node scalars: omega[64], ba[64], bb[64]
-    double* ubuf = slot + kRecDoubles + g * 2 * kPillarPad;   // this group's omega*v and v, 32 doubles each
-    double* vbuf = ubuf + kPillarPad;
+    int* rec_classes = reinterpret_cast<int*>(slot + 64 * 3);
+    double* vbuf = slot + kRecDoubles + g * kPillarPad;       // this group's v, 32 doubles
     const int P = cv.P;
     const int bi = lane >> 3, bj = lane & 7;
     const int zero_row = cv.Kcore;
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             // behind the previous node's work.
             const int classes = (cls_a & 0xffff) | (cls_b << 16);
             __builtin_amdgcn_wave_barrier();
-            rec[lane] = omega; rec[64 + lane] = ba; rec[128 + lane] = bb;
+            rec[lane] = omega; rec[64 + lane] = ba; rec[128 + lane] = bb; rec_classes[lane] = classes;
             wave_lds_sync();
             unsigned long long any_row = __ballot(greeks);
 #pragma unroll
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             int n = __builtin_ctzll(any_row);
             any_row &= any_row - 1;
             double nx_om = rec[gbase + n], nx_wa = rec[64 + gbase + n], nx_wb = rec[128 + gbase + n];
-            int nx_classes = __shfl(classes, gbase + n, 64);
+            int nx_classes = rec_classes[gbase + n];
             while (true) {
                 const bool has_next = any_row != 0;
                 const int n_next = has_next ? __builtin_ctzll(any_row) : n;   // nothing left: read n again
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                 const double om = nx_om, wa = nx_wa, wb = nx_wb;
                 const int ca = static_cast<int16_t>(nx_classes & 0xffff), cb = nx_classes >> 16;
                 nx_om = rec[gbase + n_next]; nx_wa = rec[64 + gbase + n_next]; nx_wb = rec[128 + gbase + n_next];
-                nx_classes = __shfl(classes, gbase + n_next, 64);
+                nx_classes = rec_classes[gbase + n_next];
                 n = n_next;
                 __builtin_amdgcn_sched_barrier(0);
                 const int ra = ca >= 0 ? ca : zero_row, rb = cb >= 0 ? cb : zero_row;
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                     __builtin_amdgcn_wave_barrier();
 #ifndef ADR_ABLATE_UVWRITE
 #pragma unroll
-                    for (int k = 0; k < PPL; ++k) { ubuf[l + L * k] = om * v[k]; vbuf[l + L * k] = v[k]; }
+                    for (int k = 0; k < PPL; ++k) vbuf[l + L * k] = v[k];
 #endif
                     wave_lds_sync();
                     // Convexity rows.  Consecutive nodes of a swap usually share a knot (the right neighbour of
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 #pragma unroll
                         for (int i = 0; i < kBatch; ++i) {
 #ifndef ADR_ABLATE_RANK1
-                            uu[i] = ubuf[up[i0 + i]];
+                            uu[i] = vbuf[up[i0 + i]];
                             vv[i] = vbuf[vq[i0 + i]];
 #else
                             uu[i] = om; vv[i] = wa;
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int i = 0; i < kBatch; ++i) {
-                            double gsum = fma(uu[i], vv[i], acc[i0 + i]);
+                            double gsum = fma(om * uu[i], vv[i], acc[i0 + i]);
                             if (i0 + i < CPG) {
                                 const bool core = CS < EPL || (i0 + i) < core_entries;   // compile-time true unless universal
                                 gsum = fma(core ? coa : 0.0, la[i], gsum);
