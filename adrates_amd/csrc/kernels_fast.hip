@@ -144,7 +144,7 @@ __device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
 
 // Doubles of LDS per wavefront (see the carve-up in the kernel).
 __host__ __device__ constexpr int slot_doubles(bool gamma, int epl, int groups) {
-    const int hand_off = 64 * 3 + 32 + (gamma ? groups * kPillarPad : 0);
+    const int hand_off = 64 * 4 + (gamma ? groups * kPillarPad : 0);
     const int staging = gamma ? 64 * epl : 0;
     return hand_off > staging ? hand_off : staging;
 }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     // per-wave slot: the lanes' node scalars (omega, ba, bb: 3 x 64 doubles; packed knot classes: 64 ints),
     // then (gamma) the groups' v hand-off buffers; the front is reused as the packed-ladder staging area at
     // output time
-    constexpr int kRecDoubles = 64 * 3 + 32;
+    constexpr int kRecDoubles = 64 * 4;
     constexpr int kSlotDoubles = slot_doubles(GAMMA, EPL, G);
     MiniKnot* s_mini = reinterpret_cast<MiniKnot*>(smem_raw);
     double* s_x = reinterpret_cast<double*>(s_mini + cv.n_mini);
@@ -218,7 +218,6 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     const int gbase = g * L;                      // first lane of this lane's group
     double* slot = s_slot + wave * kSlotDoubles;
     double* rec = slot;                           // node scalars: omega[64], ba[64], bb[64]
-    int* rec_classes = reinterpret_cast<int*>(slot + 64 * 3);
     double* vbuf = slot + kRecDoubles + g * kPillarPad;       // this group's v, 32 doubles
     const int P = cv.P;
     const int bi = lane >> 3, bj = lane & 7;
@@ -388,7 +387,11 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             // behind the previous node's work.
             const int classes = (cls_a & 0xffff) | (cls_b << 16);
             __builtin_amdgcn_wave_barrier();
-            rec[lane] = omega; rec[64 + lane] = ba; rec[128 + lane] = bb; rec_classes[lane] = classes;
+            {
+                double2* wp = reinterpret_cast<double2*>(rec + lane * 4);
+                wp[0] = make_double2(omega, ba);
+                wp[1] = make_double2(bb, __hiloint2double(0, classes));
+            }
             wave_lds_sync();
             unsigned long long any_row = __ballot(greeks);
 #pragma unroll
@@ -397,16 +400,16 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             if (!any_row) continue;
             int n = __builtin_ctzll(any_row);
             any_row &= any_row - 1;
-            double nx_om = rec[gbase + n], nx_wa = rec[64 + gbase + n], nx_wb = rec[128 + gbase + n];
-            int nx_classes = rec_classes[gbase + n];
+            const double2* rec_g = reinterpret_cast<const double2*>(rec + gbase * 4);
+            double2 nx0 = rec_g[2 * n], nx1 = rec_g[2 * n + 1];
             while (true) {
                 const bool has_next = any_row != 0;
                 const int n_next = has_next ? __builtin_ctzll(any_row) : n;   // nothing left: read n again
                 any_row &= any_row - 1;
-                const double om = nx_om, wa = nx_wa, wb = nx_wb;
+                const double om = nx0.x, wa = nx0.y, wb = nx1.x;
+                const int nx_classes = __double2loint(nx1.y);
                 const int ca = static_cast<int16_t>(nx_classes & 0xffff), cb = nx_classes >> 16;
-                nx_om = rec[gbase + n_next]; nx_wa = rec[64 + gbase + n_next]; nx_wb = rec[128 + gbase + n_next];
-                nx_classes = rec_classes[gbase + n_next];
+                nx0 = rec_g[2 * n_next]; nx1 = rec_g[2 * n_next + 1];
                 n = n_next;
                 __builtin_amdgcn_sched_barrier(0);
                 const int ra = ca >= 0 ? ca : zero_row, rb = cb >= 0 ? cb : zero_row;
