@@ -28,14 +28,20 @@
 // time, L = 32 lanes each.  The host lays the eligible trades out as a table of rows sorted by coupon count
 // (one row = one trade = 32 padded cash-flow slots per array), so the two trades of a wavefront have similar
 // lengths, every input load is a full-width coalesced row read whose address depends only on the row number,
-// and the next rows can be requested before the current results are stored.  Inside a group: lanes = coupons while nodes are built (coalesced loads, binary
-// search in LDS, exp); then the groups walk their nodes in lockstep - node n of every group is fetched
-// from the lane that built it (ds_bpermute), lane l builds v for pillars l, l+L, ..., v and omega*v go
-// to the group's LDS slot, and every lane updates its packed gamma entries l + L*i: the rank-1 term from
-// two LDS reads, the convexity term from contiguous slices of the two knots' LC rows.  The short-end
-// knots' 2x2 convexity blocks are applied as two extra rank-1 passes, so there is a single accumulation
-// mechanism.  Each trade's packed ladder is then expanded through the wave's LDS slot to the symmetric
-// 32x32 matrix and written as full 512-byte rows.  No atomics; the aggregate is a fixed-order reduction.
+// and the next rows can be requested before the current results are stored.  Inside a group: lanes = coupons
+// while nodes are built (coalesced loads, binary search in LDS, exp); every lane then leaves its node
+// (omega, the two weights, the two knot classes) as a 32-byte record in the wave's LDS slot and the groups
+// walk their nodes in lockstep: node n is two broadcast b128 reads issued one node ahead, lane l builds v
+// for pillar l, v goes to the group's LDS buffer, and every lane updates its packed gamma entries l + L*i -
+// the rank-1 term omega*v[p]*v[q] from two LDS reads, the convexity term from a contiguous slice of the
+// left knot's LC row (the right knot's weight is carried to the next node, whose left knot it usually is).
+// The short-end knots' one to three convexity numbers are added by the lanes that own those entries.  Each
+// trade's packed ladder is then expanded through the wave's LDS slot to the symmetric 32x32 matrix and written
+// as 1 KB-contiguous stores.  No atomics; the aggregate is a fixed-order reduction.
+//
+// The kernel is bound by the CU's LDS pipe (about 28 LDS instructions per node pair) at 3 waves/SIMD - the
+// tables fill the 160 KB of LDS, so there is one 768-thread block per CU.  ADR_ABLATE_* (diagnostic builds,
+// results are wrong) remove one class of LDS operations each to price it; see DESIGN.md section 7.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Run on the GPU box: the round's evidence in one call - GPU parity tests, the bench line (with the CPU baseline),
+# the other reported configurations, ablations, rocprofv3 kernel stats + HBM traffic passes and the PMC counters.
+# Everything lands in gpurun_out/; tools/profile_summary.py TAG rNN then copies the summaries into profiles/.
+TAG=${1:-final}
+cd /root/repo
+python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_$TAG.log 2>&1 || { tail -20 gpurun_out/gpu_tests_$TAG.log; exit 1; }
+tail -1 gpurun_out/gpu_tests_$TAG.log
+python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err || exit 1
+python bench.py --kind ongrid --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_ongrid.json 2>/dev/null || exit 1
+python bench.py --interp FLAT_FWD_RATES --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_flatfwd.json 2>/dev/null || exit 1
+python bench.py --trades 100000 --requests value,delta --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_config2_delta_100k.json 2>/dev/null || exit 1
+python tools/ablate.py > gpurun_out/ablate_$TAG.log 2>&1 || exit 1
+bash tools/profile.sh $TAG || exit 1
+bash tools/pmc.sh && python tools/pmc_summary.py > gpurun_out/pmc_$TAG.txt
+echo refresh-done
