@@ -39,6 +39,14 @@ _SIGNATURES = {
     "adr_curve_pillars": (C.c_int, [_vp]),
     "adr_curve_tables_host": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, _dp, _i32p, _dp, _dp, _dp]),
     "adr_curve_layout_host": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, _dp, _i64p]),
+    "adr_curve_plan_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _i32p, _i32p, _dp, _dp, _dp,
+                                        C.POINTER(_vp)]),
+    "adr_free_curve_plan": (None, [_vp]),
+    "adr_curve_set_build": (C.c_int, [_vp, _vp, C.c_int, _dp, C.POINTER(_vp)]),
+    "adr_curve_set_size": (C.c_int, [_vp]),
+    "adr_curve_set_get": (_vp, [_vp, C.c_int]),
+    "adr_curve_set_download": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
+    "adr_free_curve_set": (None, [_vp]),
     "adr_trades_upload": (C.c_int, [_vp, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, _dp, _dp, _dp,
                                     _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
     "adr_free_trades": (None, [_vp]),
@@ -138,6 +146,94 @@ class DeviceCurve:
     def close(self):
         if getattr(self, "_h", None):
             load().adr_free_curve(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CurvePlan:
+    """Rate-independent half of a curve build (adr_curve_plan_create): the bootstrap scan of one knot grid
+    and the table layout of its base curve.  ``host`` is an `EngineCurve` (curve_tables.build_engine_curve)."""
+
+    def __init__(self, ctx: Context, interp_method: int, host):
+        times, dfs, jac = _f64(host.times), _f64(host.dfs), _f64(host.jac)
+        K, P = jac.shape
+        acc = _f64(host.acc)
+        pillar = np.ascontiguousarray(host.pillar, dtype=np.int32)
+        prev_idx = np.ascontiguousarray(host.prev_idx, dtype=np.int32)
+        if acc.shape != (K,) or pillar.shape != (K,) or prev_idx.shape != (K,):
+            raise LibError("scan arrays must have one entry per knot")
+        hess_c = _f64(host.hess) if host.hess is not None else None
+        h = _vp()
+        _check(load().adr_curve_plan_create(ctx._h, int(interp_method), K, P, _ptr(times), _ptr(acc),
+                                            _ptr(pillar, _i32p), _ptr(prev_idx, _i32p), _ptr(dfs), _ptr(jac),
+                                            _ptr(hess_c), C.byref(h)), "adr_curve_plan_create")
+        self._h, self._ctx = h, ctx
+        self.n_pillars, self.n_knots = P, K
+        self.has_hess = hess_c is not None
+
+    def build(self, rates) -> "CurveSet":
+        """Bootstrap one curve per row of ``rates`` [S, P] (decimal par rates) on the GPU."""
+        return CurveSet(self, rates)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().adr_free_curve_plan(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _SetCurve:
+    """A curve owned by a `CurveSet`; accepted wherever a `DeviceCurve` is."""
+
+    def __init__(self, handle, owner):
+        self._h, self._owner = handle, owner        # keeps the set (and its plan) alive
+        self.n_pillars, self.n_knots, self.has_hess = owner.n_pillars, owner.n_knots, owner.has_hess
+
+
+class CurveSet:
+    """Curves bootstrapped together on the GPU (adr_curve_set_build)."""
+
+    def __init__(self, plan: CurvePlan, rates):
+        rates = _f64(np.atleast_2d(rates))
+        if rates.ndim != 2 or rates.shape[1] != plan.n_pillars:
+            raise LibError("rates must have shape [n_scenarios, n_pillars]")
+        h = _vp()
+        _check(load().adr_curve_set_build(plan._ctx._h, plan._h, rates.shape[0], _ptr(rates), C.byref(h)),
+               "adr_curve_set_build")
+        self._h, self._plan, self._ctx = h, plan, plan._ctx
+        self.n_pillars, self.n_knots, self.has_hess = plan.n_pillars, plan.n_knots, plan.has_hess
+        self.n_curves = rates.shape[0]
+
+    def __len__(self):
+        return self.n_curves
+
+    def __getitem__(self, i: int) -> _SetCurve:
+        if not 0 <= i < self.n_curves:
+            raise IndexError(i)
+        return _SetCurve(_vp(load().adr_curve_set_get(self._h, int(i))), self)
+
+    def download(self, i: int):
+        """Dense arrays of scenario ``i``: ``dfs [K]``, ``jac [K, P]``, ``hess [K, P, P]`` (None without hess)."""
+        K, P = self.n_knots, self.n_pillars
+        dfs, jac = np.empty(K), np.empty((K, P))
+        hess = np.empty((K, P, P)) if self.has_hess else None
+        _check(load().adr_curve_set_download(self._h, int(i), _ptr(dfs), _ptr(jac), _ptr(hess)),
+               "adr_curve_set_download")
+        return dfs, jac, hess
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().adr_free_curve_set(self._h)
             self._h = None
 
     def __del__(self):

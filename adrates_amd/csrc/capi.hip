@@ -1,5 +1,6 @@
 // C-ABI of libadrates_hip.so (declarations and reference citations: include/adrates.h).
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -59,6 +60,27 @@ struct adr_ctx {
 struct adr_curve {
     adr_ctx* ctx = nullptr;
     adr::CurveDev dev{};
+    std::vector<void*> allocations;
+};
+
+// Rate-independent description of one knot grid: its bootstrap scan and the table layout of the base curve.
+struct adr_curve_plan {
+    adr_ctx* ctx = nullptr;
+    int interp = 0;
+    bool has_hess = false;
+    adr::CurveTables base;               // host tables of the base curve (structure + base values)
+    adr::CurveBuildPlanDev dev{};
+    adr::CurveDev shared{};              // the structural device arrays every built curve points at
+    std::vector<void*> allocations;
+};
+
+// Curves built together on the device; `curves` are views into the set's slabs.
+struct adr_curve_set {
+    adr_ctx* ctx = nullptr;
+    const adr_curve_plan* plan = nullptr;
+    int n = 0;
+    double *dfs = nullptr, *jac = nullptr, *hess = nullptr;   // dense [n][K], [n][K][P], [n][K][P][P]
+    std::vector<adr_curve> curves;
     std::vector<void*> allocations;
 };
 
@@ -248,6 +270,194 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     e = adr::set_kernel_lds_limits(lds, std::max(fast_lds, lds));
     if (e != hipSuccess) { adr_free_curve(c); return fail_hip(e, "hipFuncSetAttribute(LDS)"); }
     *out = c;
+    return ADR_OK;
+}
+
+// ------------------------------------------------------------------------------ device curve builder
+void adr_free_curve_plan(adr_curve_plan* plan) {
+    if (!plan) return;
+    if (plan->ctx) hipSetDevice(plan->ctx->device);
+    for (void* p : plan->allocations) hipFree(p);
+    delete plan;
+}
+
+int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const double* times, const double* acc,
+                          const int32_t* pillar, const int32_t* prev_idx, const double* base_dfs,
+                          const double* base_jac, const double* base_hess, adr_curve_plan** out) {
+    if (!ctx || !out) return fail(ADR_ERR_INVALID, "adr_curve_plan_create: null ctx/out");
+    *out = nullptr;
+    if (interp_method != ADR_INTERP_FLAT_FWD_RATES && interp_method != ADR_INTERP_LINEAR_ZERO_RATES)
+        return fail(ADR_ERR_UNSUPPORTED,
+                    "adr_curve_plan_create: only FLAT_FWD_RATES (1) and LINEAR_ZERO_RATES (4) are implemented");
+    if (P > ADR_MAX_PILLARS) return fail(ADR_ERR_UNSUPPORTED, "adr_curve_plan_create: more than ADR_MAX_PILLARS pillars");
+    if (!acc || !pillar || !prev_idx) return fail(ADR_ERR_INVALID, "adr_curve_plan_create: null scan arrays");
+    for (int k = 0; k < K; ++k) {
+        if (pillar[k] < 0 || pillar[k] >= P) return fail(ADR_ERR_INVALID, "adr_curve_plan_create: pillar index out of range");
+        if (prev_idx[k] < -1 || prev_idx[k] >= K) return fail(ADR_ERR_INVALID, "adr_curve_plan_create: prev_idx out of range");
+    }
+    adr_curve_plan* plan = new (std::nothrow) adr_curve_plan();
+    if (!plan) return fail(ADR_ERR_NOMEM, "adr_curve_plan_create: out of memory");
+    plan->ctx = ctx;
+    plan->interp = interp_method;
+    plan->has_hess = base_hess != nullptr;
+    adr::CurveTables& t = plan->base;
+    const std::string err = adr::build_curve_tables(K, P, times, base_dfs, base_jac, base_hess, t);
+    if (!err.empty()) { delete plan; return fail(ADR_ERR_INVALID, "adr_curve_plan_create: " + err); }
+    const size_t lds = adr::general_kernel_lds_bytes(t.K, t.Kc);
+    if (lds > kLdsBudget || adr::bootstrap_kernel_lds_bytes(K, P) > kLdsBudget) {
+        delete plan;
+        return fail(ADR_ERR_UNSUPPORTED, "adr_curve_plan_create: curve tables exceed the 160 KiB LDS of a CU");
+    }
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) { delete plan; return fail_hip(e, "hipSetDevice"); }
+
+    std::vector<double> acc_v(acc, acc + K);
+    std::vector<int32_t> pil_v(pillar, pillar + K), prev_v(prev_idx, prev_idx + K);
+    std::vector<int16_t> first16(t.first_of.begin(), t.first_of.end()), comp16(t.compact_of.begin(), t.compact_of.end());
+    std::vector<int32_t> core_pillars;
+    for (int p = 0; p < P; ++p)
+        if (t.packed_ok && t.pillar_to_core[p] < t.Pc) core_pillars.push_back(p);
+    double *d_acc = nullptr, *d_x = nullptr, *d_invx = nullptr;
+    int32_t *d_pil = nullptr, *d_prev = nullptr, *d_kidx = nullptr, *d_core = nullptr;
+    int16_t *d_first = nullptr, *d_comp = nullptr, *d_class = nullptr, *d_p2c = nullptr, *d_omap = nullptr;
+    uint8_t* d_pq = nullptr;
+    auto track = [&](hipError_t r, void* p) { if (p) plan->allocations.push_back(p); if (e == hipSuccess) e = r; };
+    track(upload(acc_v, &d_acc), d_acc);
+    track(upload(pil_v, &d_pil), d_pil);
+    track(upload(prev_v, &d_prev), d_prev);
+    track(upload(t.knot_index, &d_kidx), d_kidx);
+    track(upload(t.x, &d_x), d_x);
+    track(upload(t.inv_x, &d_invx), d_invx);
+    track(upload(first16, &d_first), d_first);
+    track(upload(comp16, &d_comp), d_comp);
+    if (t.packed_ok) {
+        track(upload(core_pillars, &d_core), d_core);
+        track(upload(t.knot_class, &d_class), d_class);
+        track(upload(t.pillar_to_core, &d_p2c), d_p2c);
+        track(upload(t.out_map, &d_omap), d_omap);
+        track(upload(t.ent_pq, &d_pq), d_pq);
+    }
+    if (e != hipSuccess) { adr_free_curve_plan(plan); return fail_hip(e, "adr_curve_plan_create: copying tables"); }
+
+    adr::CurveBuildPlanDev& d = plan->dev;
+    d.K = K; d.P = P; d.Kc = t.Kc; d.acc = d_acc; d.pillar = d_pil; d.prev_idx = d_prev; d.knot_index = d_kidx;
+    d.packed_ok = (t.packed_ok && t.P == adr::kPillarPad) ? 1 : 0;
+    d.Pc = t.Pc; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Kcore = t.Kcore; d.n_mini = t.n_mini;
+    d.knot_class = d_class; d.core_pillars = d_core; d.ent_pq = d_pq;
+
+    adr::CurveDev& c = plan->shared;
+    c.K = t.K; c.Kc = t.Kc; c.P = t.P; c.method = interp_method;
+    c.x = d_x; c.inv_x = d_invx; c.first_of = d_first; c.compact_of = d_comp;
+    c.packed_ok = d.packed_ok;
+    c.Pc = t.Pc; c.pc_pad = t.pc_pad; c.Ec = t.Ec; c.Eu = t.Eu; c.epl = t.epl; c.Kcore = t.Kcore; c.n_mini = t.n_mini;
+    c.knot_class = d_class; c.pillar_to_core = d_p2c; c.out_map = d_omap; c.ent_pq = d_pq;
+    size_t fast_lds = 0;
+    if (c.packed_ok) {
+        fast_lds = adr::fast_kernel_lds_bytes(c, plan->has_hess);
+        if (fast_lds > kLdsBudget) { c.packed_ok = 0; d.packed_ok = 0; fast_lds = 0; }
+    }
+    e = adr::set_kernel_lds_limits(lds, std::max(fast_lds, lds));
+    if (e != hipSuccess) { adr_free_curve_plan(plan); return fail_hip(e, "hipFuncSetAttribute(LDS)"); }
+    *out = plan;
+    return ADR_OK;
+}
+
+void adr_free_curve_set(adr_curve_set* set) {
+    if (!set) return;
+    if (set->ctx) hipSetDevice(set->ctx->device);
+    for (void* p : set->allocations) hipFree(p);
+    delete set;
+}
+
+int adr_curve_set_size(const adr_curve_set* set) { return set ? set->n : 0; }
+
+const adr_curve* adr_curve_set_get(const adr_curve_set* set, int i) {
+    if (!set || i < 0 || i >= set->n) { fail(ADR_ERR_INVALID, "adr_curve_set_get: index out of range"); return nullptr; }
+    return &set->curves[static_cast<size_t>(i)];
+}
+
+int adr_curve_set_build(adr_ctx* ctx, const adr_curve_plan* plan, int n_scen, const double* rates,
+                        adr_curve_set** out) {
+    if (!ctx || !plan || !out) return fail(ADR_ERR_INVALID, "adr_curve_set_build: null ctx/plan/out");
+    *out = nullptr;
+    if (n_scen < 0 || (n_scen > 0 && !rates)) return fail(ADR_ERR_INVALID, "adr_curve_set_build: bad scenario count / null rates");
+    const adr::CurveTables& t = plan->base;
+    const size_t S = static_cast<size_t>(n_scen), K = t.K, P = t.P, Kc = t.Kc;
+    for (size_t i = 0; i < S * P; ++i)
+        if (!std::isfinite(rates[i])) return fail(ADR_ERR_INVALID, "adr_curve_set_build: par rates must be finite");
+    ADR_HIP(hipSetDevice(ctx->device));
+    adr_curve_set* set = new (std::nothrow) adr_curve_set();
+    if (!set) return fail(ADR_ERR_NOMEM, "adr_curve_set_build: out of memory");
+    set->ctx = ctx; set->plan = plan; set->n = n_scen;
+    if (n_scen == 0) { *out = set; return ADR_OK; }
+
+    hipError_t e = hipSuccess;
+    auto alloc = [&](size_t bytes, bool zero) -> void* {
+        if (bytes == 0 || e != hipSuccess) return nullptr;
+        void* p = nullptr;
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return nullptr;
+        set->allocations.push_back(p);
+        if (zero) e = hipMemsetAsync(p, 0, bytes, ctx->stream);
+        return p;
+    };
+    const bool hs = plan->has_hess, packed = plan->dev.packed_ok != 0;
+    double* d_rates = static_cast<double*>(alloc(sizeof(double) * S * P, false));
+    set->dfs = static_cast<double*>(alloc(sizeof(double) * S * K, false));
+    set->jac = static_cast<double*>(alloc(sizeof(double) * S * K * P, false));
+    set->hess = hs ? static_cast<double*>(alloc(sizeof(double) * S * K * P * P, false)) : nullptr;
+    adr::CurvePackOut po{};
+    po.log_df = static_cast<double*>(alloc(sizeof(double) * S * Kc, false));
+    po.lj = static_cast<double*>(alloc(sizeof(double) * S * Kc * adr::kPillarPad, false));
+    po.lc_lanes = hs ? static_cast<double*>(alloc(sizeof(double) * S * Kc * 64 * adr::kGammaPerLane, false)) : nullptr;
+    const size_t ljc_n = static_cast<size_t>(t.Kcore + 1) * t.pc_pad, lcc_n = static_cast<size_t>(t.Kcore + 1) * (t.Ec + 1);
+    if (packed) {
+        po.ljc = static_cast<double*>(alloc(sizeof(double) * S * ljc_n, true));
+        po.lcc = hs ? static_cast<double*>(alloc(sizeof(double) * S * lcc_n, true)) : nullptr;
+        po.mini = static_cast<adr::MiniKnot*>(alloc(sizeof(adr::MiniKnot) * S * std::max(1, t.n_mini), false));
+    }
+    // scratch of the scan's second-derivative state; released once the build has run
+    double* d_scratch = nullptr;
+    if (hs && e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_scratch), sizeof(double) * S * K * P * P);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rates, rates, sizeof(double) * S * P, hipMemcpyHostToDevice, ctx->stream);
+    if (packed && t.n_mini > 0)
+        for (size_t s = 0; s < S && e == hipSuccess; ++s)   // pillar / entry fields of the short-end records
+            e = hipMemcpyAsync(po.mini + s * t.n_mini, t.mini.data(), sizeof(adr::MiniKnot) * t.n_mini,
+                               hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = adr::launch_curve_build(plan->dev, n_scen, d_rates, set->dfs, set->jac, set->hess, d_scratch, po, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (d_scratch) hipFree(d_scratch);
+    if (e != hipSuccess) { adr_free_curve_set(set); return fail_hip(e, "adr_curve_set_build"); }
+
+    set->curves.resize(S);
+    for (size_t s = 0; s < S; ++s) {
+        adr_curve& c = set->curves[s];
+        c.ctx = ctx;
+        c.dev = plan->shared;
+        c.dev.log_df = po.log_df + s * Kc;
+        c.dev.lj = po.lj + s * Kc * adr::kPillarPad;
+        c.dev.lc_lanes = hs ? po.lc_lanes + s * Kc * 64 * adr::kGammaPerLane : nullptr;
+        if (packed) {
+            c.dev.ljc = po.ljc + s * ljc_n;
+            c.dev.lcc = hs ? po.lcc + s * lcc_n : nullptr;
+            c.dev.mini = po.mini + s * t.n_mini;
+        }
+    }
+    *out = set;
+    return ADR_OK;
+}
+
+int adr_curve_set_download(const adr_curve_set* set, int i, double* dfs, double* jac, double* hess) {
+    if (!set || i < 0 || i >= set->n) return fail(ADR_ERR_INVALID, "adr_curve_set_download: index out of range");
+    const size_t K = set->plan->base.K, P = set->plan->base.P, s = static_cast<size_t>(i);
+    ADR_HIP(hipSetDevice(set->ctx->device));
+    if (dfs) ADR_HIP(hipMemcpy(dfs, set->dfs + s * K, sizeof(double) * K, hipMemcpyDeviceToHost));
+    if (jac) ADR_HIP(hipMemcpy(jac, set->jac + s * K * P, sizeof(double) * K * P, hipMemcpyDeviceToHost));
+    if (hess) {
+        if (!set->hess) return fail(ADR_ERR_INVALID, "adr_curve_set_download: the plan was created without hess");
+        ADR_HIP(hipMemcpy(hess, set->hess + s * K * P * P, sizeof(double) * K * P * P, hipMemcpyDeviceToHost));
+    }
     return ADR_OK;
 }
 

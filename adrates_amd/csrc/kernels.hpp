@@ -95,6 +95,34 @@ struct OutputsDev {
     unsigned long long* stamps;  // diagnostic builds only (ADR_STAMPS): [grid*waves][8] cycle sums per phase
 };
 
+// Device-side curve builder (curve_build.hip): the scan description of one knot grid plus the gather maps of
+// its table layout (both independent of the par rates), and where a batch of scenarios' tables go.
+struct CurveBuildPlanDev {
+    int K, P, Kc;
+    const double* acc;            // [K] accrual fraction of the knot's coupon period
+    const int32_t* pillar;        // [K] calibration swap (= par rate) of the knot
+    const int32_t* prev_idx;      // [K] knot holding the PV01 the knot builds on, -1 for none
+    const int32_t* knot_index;    // [Kc] knots a query can reach (curve_tables.hpp)
+    int packed_ok, Pc, pc_pad, Ec, Kcore, n_mini;
+    const int16_t* knot_class;    // [Kc]
+    const int32_t* core_pillars;  // [Pc]
+    const uint8_t* ent_pq;        // [Eu][2]
+};
+
+struct CurvePackOut {             // every array has a leading scenario axis
+    double* log_df;               // [S][Kc]
+    double* lj;                   // [S][Kc][32]
+    double* lc_lanes;             // [S][Kc][64][16] or null
+    double* ljc;                  // [S][Kcore + 1][pc_pad], zero-initialised
+    double* lcc;                  // [S][Kcore + 1][Ec + 1], zero-initialised, or null
+    MiniKnot* mini;               // [S][n_mini], pillar / entry fields pre-filled
+};
+
+size_t bootstrap_kernel_lds_bytes(int K, int P);
+hipError_t launch_curve_build(const CurveBuildPlanDev& plan, int n_scen, const double* rates_dev, double* dfs,
+                              double* jac, double* hess, double* d2pv_scratch, const CurvePackOut& out,
+                              hipStream_t stream);
+
 size_t general_kernel_lds_bytes(int K, int Kc);
 size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma);
 int fast_kernel_groups();

@@ -29,6 +29,11 @@ class EngineCurve:
     jac: np.ndarray              # [K, P]    d dfs / d par rates
     hess: np.ndarray | None      # [K, P, P] d2 dfs / d par rates2
     key_collisions: List[Tuple[float, float, float]] = field(default_factory=list)
+    # the rate-independent description of the scan (what a device-side rebuild under other rates needs)
+    acc: np.ndarray | None = None        # [K] accrual fraction of the period ending at the knot
+    pillar: np.ndarray | None = None     # [K] calibration swap of the knot
+    prev_idx: np.ndarray | None = None   # [K] knot whose PV01 the knot builds on, -1 for none
+    rates: np.ndarray | None = None      # [P] par rates the values were built with
 
     @property
     def n_knots(self) -> int:
@@ -129,4 +134,5 @@ def build_engine_curve(swap_rates, swap_times, year_fracs, with_hessian: bool = 
             hess[i] = d2d
             d2pv01[i] = a * d2d if d2Pp is None else d2Pp + a * d2d
 
-    return EngineCurve(times=times, dfs=dfs, jac=jac, hess=hess, key_collisions=collisions)
+    return EngineCurve(times=times, dfs=dfs, jac=jac, hess=hess, key_collisions=collisions,
+                       acc=acc, pillar=pillar, prev_idx=prev_idx, rates=rates)

@@ -34,6 +34,8 @@ extern "C" {
 typedef struct adr_ctx adr_ctx;
 typedef struct adr_curve adr_curve;
 typedef struct adr_trades adr_trades;
+typedef struct adr_curve_plan adr_curve_plan;
+typedef struct adr_curve_set adr_curve_set;
 
 typedef enum adr_status {
     ADR_OK = 0,
@@ -103,6 +105,46 @@ int adr_curve_tables_host(int K, int P, const double* times, const double* dfs,
  */
 int adr_curve_layout_host(int K, int P, const double* times, const double* dfs,
                           const double* jac, const double* hess, int64_t* info);
+
+/*
+ * Curve builder on the device, for batches of par-rate scenarios on one knot grid.  It replaces
+ * Engine.build_curve_ad (engine.py:2246-2360: the lax.scan d = (1 - r PV01_prev) / (1 + r acc)) and the
+ * jacrev / hessian of Engine._cached_curve (engine.py:2388-2389) for the case the reference handles by
+ * rebuilding a Model per shock (Model.scenario, cavour/models/models.py:507-557): the par rates change,
+ * the schedules - hence the knot grid - do not.
+ *
+ * A plan holds what does not depend on the rates: the scan description of the K sorted bootstrap points
+ * (engine.py:2283-2334) -
+ *   times[K]     knot times (as for adr_curve_upload),
+ *   acc[K]       accrual fraction of the coupon period ending at the knot (0 for the t = 0 point),
+ *   pillar[K]    index of the calibration swap whose par rate the knot uses,
+ *   prev_idx[K]  knot whose PV01 the knot builds on (first sorted point with the previous coupon's
+ *                round(t, 2) key), -1 for a swap's first period,
+ * and the table layout, taken from the base curve (base_dfs/base_jac/base_hess as for adr_curve_upload;
+ * base_hess NULL = no gamma for any curve of the plan).  Curves built from a plan point into it: free
+ * the sets before the plan.
+ */
+int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P,
+                          const double* times, const double* acc,
+                          const int32_t* pillar, const int32_t* prev_idx,
+                          const double* base_dfs, const double* base_jac, const double* base_hess,
+                          adr_curve_plan** out);
+void adr_free_curve_plan(adr_curve_plan* plan);
+
+/*
+ * Bootstrap n_scen curves (rates: host array [n_scen * P] of par rates, decimal) with their first and -
+ * when the plan has hess - second par-rate derivatives on the GPU and convert them to the kernels' tables.
+ * Blocks until the curves are ready.  adr_curve_set_get returns a curve owned by the set (do not free it)
+ * that adr_price / adr_price_dev accept like an uploaded one.
+ */
+int adr_curve_set_build(adr_ctx* ctx, const adr_curve_plan* plan, int n_scen, const double* rates,
+                        adr_curve_set** out);
+int adr_curve_set_size(const adr_curve_set* set);
+const adr_curve* adr_curve_set_get(const adr_curve_set* set, int i);
+/* Copy scenario i's dense arrays back (any pointer may be NULL): dfs[K], jac[K*P], hess[K*P*P] - the
+ * contents of the reference's cache dict for that scenario. */
+int adr_curve_set_download(const adr_curve_set* set, int i, double* dfs, double* jac, double* hess);
+void adr_free_curve_set(adr_curve_set* set);
 
 /*
  * A batch of OIS trades in CSR form - the per-trade arrays the reference engine
