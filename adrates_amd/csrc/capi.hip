@@ -189,8 +189,8 @@ int adr_curve_layout_host(int K, int P, const double* times, const double* dfs, 
     const std::string err = adr::build_curve_tables(K, P, times, dfs, jac, hess, t);
     if (!err.empty()) return fail(ADR_ERR_INVALID, "adr_curve_layout_host: " + err);
     adr::CurveDev d{};
-    d.K = t.K; d.Kc = t.Kc; d.Kcore = t.Kcore; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Eu = t.Eu; d.epl = t.epl; d.n_mini = t.n_mini;
-    info[0] = t.packed_ok ? 1 : 0; info[1] = t.Pc; info[2] = t.Ec; info[3] = t.Eu; info[4] = t.epl;
+    d.K = t.K; d.Kc = t.Kc; d.Kcore = t.Kcore; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Eu = t.Eu; d.epg = t.epg; d.cpg = t.cpg; d.n_mini = t.n_mini;
+    info[0] = t.packed_ok ? 1 : 0; info[1] = t.Pc; info[2] = t.Ec; info[3] = t.Eu; info[4] = t.epg;
     info[5] = t.Kcore; info[6] = t.n_mini;
     info[7] = t.packed_ok ? static_cast<int64_t>(adr::fast_kernel_lds_bytes(d, t.has_hess)) : 0;
     return ADR_OK;
@@ -257,7 +257,7 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     c->dev.first_of = d_first; c->dev.compact_of = d_comp;
     // the fast kernels write whole 32-wide rows; curves with fewer pillars use the general kernel
     c->dev.packed_ok = (t.packed_ok && t.P == adr::kPillarPad) ? 1 : 0;
-    c->dev.Pc = t.Pc; c->dev.pc_pad = t.pc_pad; c->dev.Ec = t.Ec; c->dev.Eu = t.Eu; c->dev.epl = t.epl;
+    c->dev.Pc = t.Pc; c->dev.pc_pad = t.pc_pad; c->dev.Ec = t.Ec; c->dev.Eu = t.Eu; c->dev.epg = t.epg; c->dev.cpg = t.cpg;
     c->dev.Kcore = t.Kcore; c->dev.n_mini = t.n_mini;
     c->dev.ljc = d_ljc; c->dev.lcc = d_lcc; c->dev.mini = d_mini; c->dev.knot_class = d_class;
     c->dev.pillar_to_core = d_p2c; c->dev.out_map = d_omap; c->dev.ent_pq = d_pq;
@@ -349,7 +349,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     c.K = t.K; c.Kc = t.Kc; c.P = t.P; c.method = interp_method;
     c.x = d_x; c.inv_x = d_invx; c.first_of = d_first; c.compact_of = d_comp;
     c.packed_ok = d.packed_ok;
-    c.Pc = t.Pc; c.pc_pad = t.pc_pad; c.Ec = t.Ec; c.Eu = t.Eu; c.epl = t.epl; c.Kcore = t.Kcore; c.n_mini = t.n_mini;
+    c.Pc = t.Pc; c.pc_pad = t.pc_pad; c.Ec = t.Ec; c.Eu = t.Eu; c.epg = t.epg; c.cpg = t.cpg; c.Kcore = t.Kcore; c.n_mini = t.n_mini;
     c.knot_class = d_class; c.pillar_to_core = d_p2c; c.out_map = d_omap; c.ent_pq = d_pq;
     size_t fast_lds = 0;
     if (c.packed_ok) {

@@ -112,7 +112,7 @@ bool build_packed_layout(CurveTables& t) {
         }
     const int Ec = t.Ec = Pc * (Pc + 1) / 2;
 
-    // packed entries: core pairs first (in packed_index order), then fringe pairs as discovered
+    // packed entries: core pairs first (in packed_index order), then padding, then the fringe pairs
     std::vector<int> entry_of(kPillarPad * kPillarPad, -1);   // [p*32+q], p <= q
     t.ent_pq.clear();
     for (int i = 0; i < Pc; ++i)
@@ -121,17 +121,15 @@ bool build_packed_layout(CurveTables& t) {
             t.ent_pq.push_back(static_cast<uint8_t>(core_pillars[i]));
             t.ent_pq.push_back(static_cast<uint8_t>(core_pillars[j]));
         }
-    // Fringe entries start on a 64-entry boundary so that no lane slot mixes core pairs (whose convexity
-    // rows are read as contiguous 64-wide slices) with fringe pairs; the entries in between are unused.
-    while ((t.ent_pq.size() / 2) % 64 != 0) { t.ent_pq.push_back(0); t.ent_pq.push_back(0); }
+    std::vector<std::pair<int, int>> fringe;
+    std::vector<char> seen(kPillarPad * kPillarPad, 0);
     auto add_pairs = [&](uint32_t S) {
         for (int p = 0; p < P; ++p) {
             if (!(S & (1u << p))) continue;
             for (int q = p; q < P; ++q) {
-                if (!(S & (1u << q)) || entry_of[p * kPillarPad + q] >= 0) continue;
-                entry_of[p * kPillarPad + q] = static_cast<int>(t.ent_pq.size() / 2);
-                t.ent_pq.push_back(static_cast<uint8_t>(p));
-                t.ent_pq.push_back(static_cast<uint8_t>(q));
+                if (!(S & (1u << q)) || entry_of[p * kPillarPad + q] >= 0 || seen[p * kPillarPad + q]) continue;
+                seen[p * kPillarPad + q] = 1;
+                fringe.emplace_back(p, q);
             }
         }
     };
@@ -140,9 +138,27 @@ bool build_packed_layout(CurveTables& t) {
         if (c + 1 < Kc && t.x[t.knot_index[c]] != t.x[t.knot_index[c + 1]])
             add_pairs(support[c] | support[c + 1]);             // (last of a run, first of the next run)
     }
-    const int Eu = t.Eu = static_cast<int>(t.ent_pq.size() / 2);
-    if (Eu > 64 * 9) return false;
-    t.epl = Eu <= 64 * 3 ? 3 : Eu <= 64 * 4 ? 4 : Eu <= 64 * 6 ? 6 : 9;
+    // A group lane (32 lanes per trade) holds entries l + 32*i.  Fringe entries start on a 32-entry boundary
+    // so that no lane slot mixes core pairs (whose convexity rows are read as contiguous 32-wide slices)
+    // with fringe pairs.  The kernels exist for epg = 7, 8, 12, 18 slots per lane with the last two slots
+    // fringe-only ("exact": core slots = epg - 2) or with every slot treated as core ("universal").
+    const int core_slots_min = (Ec + kGroupLanes - 1) / kGroupLanes;
+    const int n_fringe = static_cast<int>(fringe.size());
+    static const int kEpgChoices[] = {7, 8, 12, 18};
+    t.epg = 0;
+    for (int epg : kEpgChoices) {
+        if (n_fringe <= 2 * kGroupLanes && core_slots_min <= epg - 2) { t.epg = epg; t.cpg = epg - 2; break; }
+        if (core_slots_min * kGroupLanes + n_fringe <= epg * kGroupLanes) { t.epg = epg; t.cpg = epg; break; }
+    }
+    if (t.epg == 0) return false;
+    const int fringe_start = (t.cpg < t.epg ? t.cpg : core_slots_min) * kGroupLanes;
+    while (static_cast<int>(t.ent_pq.size() / 2) < fringe_start) { t.ent_pq.push_back(0); t.ent_pq.push_back(0); }
+    for (const auto& pq : fringe) {
+        entry_of[pq.first * kPillarPad + pq.second] = static_cast<int>(t.ent_pq.size() / 2);
+        t.ent_pq.push_back(static_cast<uint8_t>(pq.first));
+        t.ent_pq.push_back(static_cast<uint8_t>(pq.second));
+    }
+    t.Eu = static_cast<int>(t.ent_pq.size() / 2);
 
     t.out_map.assign(kPillarPad * kPillarPad, -1);
     for (int r = 0; r < P; ++r)

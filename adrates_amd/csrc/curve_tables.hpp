@@ -22,6 +22,7 @@ namespace adr {
 
 constexpr int kPillarPad = 32;                                  // ladders are padded to this on chip
 constexpr int kGammaPerLane = kPillarPad * kPillarPad / 64;     // 16 gamma entries per lane (4x4 block)
+constexpr int kGroupLanes = 32;                                 // lanes per trade in the fast kernel
 
 // A knot whose log-DF depends on at most two par rates (single-period calibration swaps of the short
 // end): its whole first/second-derivative information is 2 + 3 numbers.
@@ -54,8 +55,9 @@ struct CurveTables {
     int Pc = 0;                        // pillars in the core set
     int pc_pad = 0;                    // row stride of ljc: >= Pc + 1 (column Pc is all zero), even
     int Ec = 0;                        // Pc*(Pc+1)/2 core x core pairs = the first Ec packed entries
-    int Eu = 0;                        // all packed entries: core pairs, padding to a multiple of 64, fringe pairs
-    int epl = 0;                       // packed entries per lane the kernel is instantiated for (Eu <= 64*epl)
+    int Eu = 0;                        // all packed entries: core pairs, padding to a multiple of 32, fringe pairs
+    int epg = 0;                       // packed entries per group lane the kernel is instantiated for (Eu <= 32*epg)
+    int cpg = 0;                       // of which slots that read convexity rows: epg - 2 (exact) or epg (universal)
     int Kcore = 0;                     // rows of ljc / lcc
     int n_mini = 0;                    // knots with at most two pillars outside the core
     std::vector<int16_t> pillar_to_core;   // [32]   core column of pillar p; Pc (the zero column) outside the core

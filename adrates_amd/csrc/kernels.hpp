@@ -76,7 +76,7 @@ struct CurveDev {
     const double* lj;            // [Kc][32]
     const double* lc_lanes;      // [Kc][64][16], null without gamma
     // fast kernels: packed layout (curve_tables.hpp), valid when packed_ok
-    int packed_ok, Pc, pc_pad, Ec, Eu, epl, Kcore, n_mini;
+    int packed_ok, Pc, pc_pad, Ec, Eu, epg, cpg, Kcore, n_mini;
     const double* ljc;           // [Kcore][pc_pad]
     const double* lcc;           // [Kcore][Ec + 1] (last entry of every row is 0), null without gamma
     const MiniKnot* mini;        // [n_mini]

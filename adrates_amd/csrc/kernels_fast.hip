@@ -149,22 +149,25 @@ __device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
 }
 
 // Doubles of LDS per wavefront (see the carve-up in the kernel).
-__host__ __device__ constexpr int slot_doubles(bool gamma, int epl, int groups) {
+__host__ __device__ constexpr int slot_doubles(bool gamma, int epg, int groups) {
+    const int epl = (epg * (64 / groups) + 63) / 64;   // 64-entry slices of the packed ladder
     const int hand_off = 64 * 4 + (gamma ? groups * kPillarPad : 0);
     const int staging = gamma ? 64 * epl : 0;
     return hand_off > staging ? hand_off : staging;
 }
 
-// DELTA/GAMMA: what to compute; EPL: packed entries / 64 and CS: how many of those 64-entry slots hold core
-// pairs (both curve dependent; compile-time so that the loops below have no branches); G: trades per wavefront.
-// CS == EPL is the universal variant: it reads a convexity slice for every slot and zeroes the coefficient of
+// DELTA/GAMMA: what to compute; STORE: per-trade gamma matrices are written; EPG_: packed entries per group
+// lane (entry l + L*i, i < EPG_) and CPG_: how many of those slots hold core pairs and read a convexity slice
+// (both curve dependent; compile-time so that the loops below have no branches); G: trades per wavefront.
+// CPG_ == EPG_ is the universal variant: it reads a convexity slice for every slot and zeroes the coefficient of
 // the slots that are not core pairs at run time.
-template <bool DELTA, bool GAMMA, bool STORE, int EPL, int CS, int G>
+template <bool DELTA, bool GAMMA, bool STORE, int EPG_, int CPG_, int G>
 __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
     constexpr int L = 64 / G;                          // lanes per trade
     constexpr int PPL = kPillarPad / L;                // pillars per lane: l + L*k
-    constexpr int EPG = GAMMA ? 64 * EPL / L : 1;      // packed entries per lane: l + L*i
-    constexpr int CPG = GAMMA ? 64 * CS / L : 0;       // of which core pairs (convexity rows are read for these)
+    constexpr int EPG = GAMMA ? EPG_ : 1;              // packed entries per lane: l + L*i
+    constexpr int CPG = GAMMA ? CPG_ : 0;              // of which core pairs (convexity rows are read for these)
+    constexpr int EPL = GAMMA ? (EPG * L + 63) / 64 : 1;   // 64-entry slices of the packed ladder (staging, totals)
     static_assert(kPillarPad % L == 0 && PPL >= 1, "a group must cover the pillars evenly");
     static_assert(L == kRowSlots, "one lane per cash-flow slot of a row");
     constexpr unsigned long long kGroupMask = (L == 64) ? ~0ull : ((1ull << L) - 1);
@@ -174,13 +177,13 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     const int ec_stride = cv.Ec + 1;
     const int n_ljc = (cv.Kcore + 1) * cv.pc_pad;            // + the all-zero row
     const int n_lcc = GAMMA ? (cv.Kcore + 1) * ec_stride : 0;
-    // zeros behind the last row: a row is read 64*CS entries wide; CS < EPL means CS = ceil(Ec / 64)
-    const int n_slack = GAMMA ? (CS < EPL ? 64 : 64 * EPL) : 0;
+    // zeros behind the last row: a row has Ec + 1 entries and is read L*CPG entries wide
+    const int n_slack = GAMMA ? (L * CPG > cv.Ec + 1 ? L * CPG - (cv.Ec + 1) : 0) : 0;
     // per-wave slot: the lanes' node scalars (omega, ba, bb: 3 x 64 doubles; packed knot classes: 64 ints),
     // then (gamma) the groups' v hand-off buffers; the front is reused as the packed-ladder staging area at
     // output time
     constexpr int kRecDoubles = 64 * 4;
-    constexpr int kSlotDoubles = slot_doubles(GAMMA, EPL, G);
+    constexpr int kSlotDoubles = slot_doubles(GAMMA, EPG, G);
     MiniKnot* s_mini = reinterpret_cast<MiniKnot*>(smem_raw);
     double* s_x = reinterpret_cast<double*>(s_mini + cv.n_mini);
     double* s_log = s_x + cv.K;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     const int P = cv.P;
     const int bi = lane >> 3, bj = lane & 7;
     const int zero_row = cv.Kcore;
-    const int core_entries = GAMMA ? (((cv.Ec + 63) >> 6) * 64) / L : 0;   // entries i < this are core pairs
+    const int core_entries = GAMMA ? (cv.Ec + L - 1) / L : 0;   // slots i < this hold core pairs
 
     // per-lane constants
     int col[PPL];                                 // ljc column of pillar l + L*k
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < CPG; ++i) {
-                const bool core = CS < EPL || i < core_entries;
+                const bool core = CPG < EPG || i < core_entries;
                 acc[i] = fma(core ? w : 0.0, lr[i], acc[i]);
             }
         };
@@ -484,6 +487,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                         double uu[kBatch], vv[kBatch], la[kBatch];
 #pragma unroll
                         for (int i = 0; i < kBatch; ++i) {
+                            if (i0 + i >= EPG) continue;
 #ifndef ADR_ABLATE_RANK1
                             uu[i] = vbuf[up[i0 + i]];
                             vv[i] = vbuf[vq[i0 + i]];
@@ -500,9 +504,10 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int i = 0; i < kBatch; ++i) {
+                            if (i0 + i >= EPG) continue;
                             double gsum = fma(om * uu[i], vv[i], acc[i0 + i]);
                             if (i0 + i < CPG) {
-                                const bool core = CS < EPL || (i0 + i) < core_entries;   // compile-time true unless universal
+                                const bool core = CPG < EPG || (i0 + i) < core_entries;   // compile-time true unless universal
                                 gsum = fma(core ? coa : 0.0, la[i], gsum);
                             }
                             acc[i0 + i] = gsum;
@@ -689,25 +694,23 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* part
 
 constexpr int kGroups = ADR_FAST_GROUPS;
 
-// Kernel variant for a curve: (EPL, CS) with CS = EPL - 1 (one fringe slot, the usual case), CS = EPL (no fringe
-// entries) or, for anything else, the universal variant (EPL, EPL).
+// Kernel variant for a curve: (epg, cpg) as chosen by build_packed_layout - epg in {7, 8, 12, 18} slots per
+// group lane, with cpg = epg - 2 (the last two slots hold the fringe pairs) or cpg = epg (universal).
 using KernelFn = void (*)(CurveDev, TradesDev, OutputsDev);
 
-template <int EPL, bool STORE>
-KernelFn gamma_kernel(int core_slots) {
-    if (core_slots == EPL - 1 && EPL > 1)
-        return &price_fast_kernel<true, true, STORE, EPL, (EPL > 1 ? EPL - 1 : 1), kGroups>;
-    return &price_fast_kernel<true, true, STORE, EPL, EPL, kGroups>;
+template <int EPG, bool STORE>
+KernelFn gamma_kernel(int cpg) {
+    if (cpg == EPG - 2) return &price_fast_kernel<true, true, STORE, EPG, EPG - 2, kGroups>;
+    return &price_fast_kernel<true, true, STORE, EPG, EPG, kGroups>;
 }
 
 template <bool STORE>
 KernelFn gamma_kernel_for(const CurveDev& cv) {
-    const int core_slots = (cv.Ec + 63) >> 6;
-    switch (cv.epl) {
-        case 3: return gamma_kernel<3, STORE>(core_slots);
-        case 4: return gamma_kernel<4, STORE>(core_slots);
-        case 6: return gamma_kernel<6, STORE>(core_slots);
-        default: return gamma_kernel<9, STORE>(core_slots);
+    switch (cv.epg) {
+        case 7: return gamma_kernel<7, STORE>(cv.cpg);
+        case 8: return gamma_kernel<8, STORE>(cv.cpg);
+        case 12: return gamma_kernel<12, STORE>(cv.cpg);
+        default: return gamma_kernel<18, STORE>(cv.cpg);
     }
 }
 
@@ -723,9 +726,10 @@ KernelFn pick_kernel(const CurveDev& cv, bool want_delta, bool want_gamma, bool 
 int fast_kernel_groups() { return kGroups; }
 
 size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
-    const size_t slot = slot_doubles(gamma, cv.epl, kGroups);
+    const size_t slot = slot_doubles(gamma, cv.epg, kGroups);
+    const size_t slack = kGroupLanes * cv.cpg > cv.Ec + 1 ? kGroupLanes * cv.cpg - (cv.Ec + 1) : 0;
     size_t doubles = static_cast<size_t>(cv.K) + 2 * cv.Kc + static_cast<size_t>(cv.Kcore + 1) * cv.pc_pad +
-                     (gamma ? static_cast<size_t>(cv.Kcore + 1) * (cv.Ec + 1) + (((cv.Ec + 63) >> 6) == cv.epl - 1 && cv.epl > 1 ? 64 : 64 * cv.epl) : 0);
+                     (gamma ? static_cast<size_t>(cv.Kcore + 1) * (cv.Ec + 1) + slack : 0);
     doubles += doubles & 1;   // the slots start on a 16-byte boundary
     doubles += kWavesPerBlock * slot;
     size_t tables = sizeof(MiniKnot) * cv.n_mini + sizeof(double) * doubles +
@@ -756,14 +760,14 @@ hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes) {
     hipError_t e = set_general_kernel_lds_limit(general_bytes);
     if (e != hipSuccess) return e;
     const void* fns[] = {
-        reinterpret_cast<const void*>(gamma_kernel<3, true>(2)), reinterpret_cast<const void*>(gamma_kernel<3, true>(3)),
-        reinterpret_cast<const void*>(gamma_kernel<4, true>(3)), reinterpret_cast<const void*>(gamma_kernel<4, true>(4)),
-        reinterpret_cast<const void*>(gamma_kernel<6, true>(5)), reinterpret_cast<const void*>(gamma_kernel<6, true>(6)),
-        reinterpret_cast<const void*>(gamma_kernel<9, true>(8)), reinterpret_cast<const void*>(gamma_kernel<9, true>(9)),
-        reinterpret_cast<const void*>(gamma_kernel<3, false>(2)), reinterpret_cast<const void*>(gamma_kernel<3, false>(3)),
-        reinterpret_cast<const void*>(gamma_kernel<4, false>(3)), reinterpret_cast<const void*>(gamma_kernel<4, false>(4)),
-        reinterpret_cast<const void*>(gamma_kernel<6, false>(5)), reinterpret_cast<const void*>(gamma_kernel<6, false>(6)),
-        reinterpret_cast<const void*>(gamma_kernel<9, false>(8)), reinterpret_cast<const void*>(gamma_kernel<9, false>(9)),
+        reinterpret_cast<const void*>(gamma_kernel<7, true>(5)), reinterpret_cast<const void*>(gamma_kernel<7, true>(7)),
+        reinterpret_cast<const void*>(gamma_kernel<8, true>(6)), reinterpret_cast<const void*>(gamma_kernel<8, true>(8)),
+        reinterpret_cast<const void*>(gamma_kernel<12, true>(10)), reinterpret_cast<const void*>(gamma_kernel<12, true>(12)),
+        reinterpret_cast<const void*>(gamma_kernel<18, true>(16)), reinterpret_cast<const void*>(gamma_kernel<18, true>(18)),
+        reinterpret_cast<const void*>(gamma_kernel<7, false>(5)), reinterpret_cast<const void*>(gamma_kernel<7, false>(7)),
+        reinterpret_cast<const void*>(gamma_kernel<8, false>(6)), reinterpret_cast<const void*>(gamma_kernel<8, false>(8)),
+        reinterpret_cast<const void*>(gamma_kernel<12, false>(10)), reinterpret_cast<const void*>(gamma_kernel<12, false>(12)),
+        reinterpret_cast<const void*>(gamma_kernel<18, false>(16)), reinterpret_cast<const void*>(gamma_kernel<18, false>(18)),
         reinterpret_cast<const void*>(&price_fast_kernel<true, false, false, 1, 1, kGroups>),
         reinterpret_cast<const void*>(&price_fast_kernel<false, false, false, 1, 1, kGroups>),
     };
