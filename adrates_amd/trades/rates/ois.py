@@ -75,6 +75,47 @@ class OIS:
         from ...market.position.position import Position
         return Position(self, model)
 
+    def value(self, value_dt: Date, ois_curve=None, discount_curve=None, xccy_discount_curve=None,
+              spot_fx: float = None, collateral_type=None, first_fixing_rate=None):
+        """Swap PV off the curves' own nodes, non-AD (cavour/trades/rates/ois.py:209-273).  With no
+        ``discount_curve`` and no ``collateral_type`` the OIS curve discounts (single curve); a collateral
+        currency other than the swap's needs ``xccy_discount_curve`` and ``spot_fx`` and returns PV / spot_fx."""
+        from ...utils.global_types import collateral_to_currency
+        if discount_curve is None and collateral_type is None:
+            discount_curve = ois_curve
+        cross = False
+        if collateral_type is not None:
+            cross = collateral_to_currency(collateral_type) != self._currency
+            if cross:
+                if xccy_discount_curve is None or spot_fx is None:
+                    raise ValueError(f"xccy_discount_curve and spot_fx required for {self._currency.name} swap "
+                                     f"with {collateral_to_currency(collateral_type).name} collateral")
+                discount_curve = xccy_discount_curve
+            else:
+                discount_curve = ois_curve
+        value = (self._fixed_leg.value(value_dt, discount_curve)
+                 + self._float_leg.value(value_dt, discount_curve, ois_curve, first_fixing_rate))
+        if cross and spot_fx is not None:
+            value = value / spot_fx
+        return value
+
+    def pv01(self, value_dt, discount_curve):
+        """Value of a 1 bp coupon on the fixed leg, always positive (ois.py:277-285)."""
+        pv = self._fixed_leg.value(value_dt, discount_curve)
+        return abs(pv / self._fixed_leg._cpn / self._fixed_leg._notional * 100)
+
+    def ir01(self, value_dt, discount_curve):
+        """PV change per 1 bp parallel shift of the curve's zero rates (ois.py:289-300)."""
+        down = self.value(value_dt, discount_curve.bump(-0.001))
+        up = self.value(value_dt, discount_curve.bump(0.001))
+        return (up - down) / 10 / 2
+
+    def swap_rate(self, value_dt, ois_curve, first_fixing_rate=None):
+        """Fixed coupon that makes the swap worth zero (ois.py:304-320)."""
+        pv01 = self.pv01(value_dt, ois_curve)
+        float_leg_value = self._float_leg.value(value_dt, ois_curve, ois_curve, first_fixing_rate)
+        return float_leg_value / pv01 / self._fixed_leg._notional
+
     def __repr__(self):
         s = label_to_string("OBJECT TYPE", type(self).__name__)
         s += self._fixed_leg.__repr__() + "\n" + self._float_leg.__repr__()

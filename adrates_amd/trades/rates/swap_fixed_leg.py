@@ -93,6 +93,31 @@ class SwapFixedLeg:
             self._payments.append(alpha * self._notional * self._cpn)
         self._adjusted_fixed_dts = list(self._payment_dts)
 
+    def value(self, value_dt: Date, discount_curve):
+        """Leg PV off a curve's own nodes (`curve.df`), non-AD (cavour/trades/rates/swap_fixed_leg.py:200-246):
+        payments strictly after ``value_dt``, each discounted with ``df(payment) / df(value_dt)`` on the leg's
+        day count; the per-payment tables of the last valuation are kept for inspection."""
+        self._payment_dfs, self._payment_pvs, self._cumulative_pvs = [], [], []
+        df_value = discount_curve.df(value_dt, self._dc_type)
+        leg_pv, df_pmnt, pmnt_dt = 0.0, 0.0, None
+        for pmnt_dt, amount in zip(self._payment_dts, self._payments):
+            if pmnt_dt > value_dt:
+                df_pmnt = discount_curve.df(pmnt_dt, self._dc_type) / df_value
+                leg_pv += amount * df_pmnt
+                self._payment_dfs.append(df_pmnt)
+                self._payment_pvs.append(amount * df_pmnt)
+                self._cumulative_pvs.append(leg_pv)
+            else:
+                self._payment_dfs.append(0.0)
+                self._payment_pvs.append(0.0)
+                self._cumulative_pvs.append(0.0)
+        if pmnt_dt is not None and pmnt_dt > value_dt:
+            principal_pv = self._principal * df_pmnt * self._notional
+            self._payment_pvs[-1] += principal_pv
+            leg_pv += principal_pv
+            self._cumulative_pvs[-1] = leg_pv
+        return -leg_pv if self._leg_type == SwapTypes.PAY else leg_pv
+
     def __repr__(self):
         s = label_to_string("OBJECT TYPE", type(self).__name__)
         s += label_to_string("START DATE", self._effective_dt)

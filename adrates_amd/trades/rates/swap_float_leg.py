@@ -95,6 +95,58 @@ class SwapFloatLeg:
             self._year_fracs.append(alpha)
             self._accrued_days.append(days)
 
+    def value(self, value_dt: Date, discount_curve, index_curve=None, first_fixing_rate: float = None):
+        """Leg PV off the curves' own nodes, non-AD (cavour/trades/rates/swap_float_leg.py:190-352): forward
+        rates from ``index_curve.df`` at the accrual dates over the INDEX curve's day-count fraction, coupons
+        on the leg's accrual fraction, discounting as for the fixed leg; optional notional exchange
+        (-N at the effective date, +N at maturity).  Unlike the reference, the exchange does not mutate the
+        leg's schedule arrays (the reference inserts a zero-accrual flow into `_payment_dts` on first use)."""
+        if discount_curve is None:
+            raise LibError("Discount curve is None")
+        if index_curve is None:
+            index_curve = discount_curve
+        self._rates, self._payments, self._payment_dfs, self._payment_pvs, self._cumulative_pvs = [], [], [], [], []
+        df_value = discount_curve.df(value_dt, self._dc_type)
+        n = len(self._payment_dts)
+        notionals = list(self._notional_array) if len(self._notional_array) else [self._notional] * n
+        if len(notionals) < n:
+            notionals = [self._notional] * (n - len(notionals)) + notionals
+        notionals = notionals[:n]
+        index_counter = DayCount(index_curve._dc_type)
+        leg_pv, df_pmnt, pmnt_dt, first_done = 0.0, 0.0, None, False
+        for i, pmnt_dt in enumerate(self._payment_dts):
+            if pmnt_dt > value_dt:
+                start, end = self._start_accrued_dts[i], self._end_accrued_dts[i]
+                index_alpha = index_counter.year_frac(start, end)[0]
+                if not first_done and first_fixing_rate is not None:
+                    fwd_rate, first_done = first_fixing_rate, True
+                else:
+                    fwd_rate = (index_curve.df(start, self._dc_type) / index_curve.df(end, self._dc_type) - 1.0) / index_alpha
+                amount = (fwd_rate + self._spread) * self._year_fracs[i] * notionals[i]
+                df_pmnt = discount_curve.df(pmnt_dt, self._dc_type) / df_value
+                leg_pv += amount * df_pmnt
+                self._rates.append(fwd_rate)
+                self._payments.append(amount)
+                self._payment_dfs.append(df_pmnt)
+                self._payment_pvs.append(amount * df_pmnt)
+            else:
+                self._rates.append(0.0)
+                self._payments.append(0.0)
+                self._payment_dfs.append(0.0)
+                self._payment_pvs.append(0.0)
+            self._cumulative_pvs.append(leg_pv)
+        if pmnt_dt is not None and pmnt_dt > value_dt:
+            principal_pv = self._principal * df_pmnt * notionals[-1]
+            self._payment_pvs[-1] += principal_pv
+            leg_pv += principal_pv
+            self._cumulative_pvs[-1] = leg_pv
+        if self._notional_exchange:
+            if self._effective_dt >= value_dt:
+                leg_pv += float(-self._notional * (discount_curve.df(self._effective_dt, self._dc_type) / df_value))
+            if self._maturity_dt >= value_dt and len(self._payments) > 0:
+                leg_pv += float(self._notional * (discount_curve.df(self._maturity_dt, self._dc_type) / df_value))
+        return -leg_pv if self._leg_type == SwapTypes.PAY else leg_pv
+
     def __repr__(self):
         s = label_to_string("OBJECT TYPE", type(self).__name__)
         s += label_to_string("START DATE", self._effective_dt)
