@@ -21,10 +21,10 @@ from typing import Any, Dict
 import numpy as np
 
 from ... import _native
-from ...requests.results import AnalyticsResult, Delta, Gamma, Valuation
+from ...requests.results import AnalyticsResult, CashflowItem, Cashflows, Delta, Gamma, Valuation
 from ...trades.compiler import compile_ois
 from ...utils.error import LibError
-from ...utils.global_types import InstrumentTypes, InterpTypes, RequestTypes, collateral_to_currency
+from ...utils.global_types import InstrumentTypes, InterpTypes, RequestTypes, SwapTypes, collateral_to_currency
 from ...utils.helpers import to_tenor
 from ..curves.curve_tables import build_engine_curve
 
@@ -77,9 +77,45 @@ class Engine:
 
     def _compute_ois_natural(self, derivative, reqs):
         ir_model = getattr(self.model.curves, derivative._floating_index.name)
-        res = price_batch(self, ir_model, [derivative], reqs, per_trade=True, aggregate=False)
-        return wrap_result(res, 0, reqs, ir_model_tenors=res["tenors"], currency=derivative._currency,
-                           curve_type=derivative._floating_index)
+        out = AnalyticsResult()
+        if reqs & {RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA}:
+            res = price_batch(self, ir_model, [derivative], reqs, per_trade=True, aggregate=False)
+            out = wrap_result(res, 0, reqs, ir_model_tenors=res["tenors"], currency=derivative._currency,
+                              curve_type=derivative._floating_index)
+        if RequestTypes.CASHFLOWS in reqs:
+            out = AnalyticsResult(value=out.value, risk=out.risk, gamma=out.gamma,
+                                  cashflows=self._ois_cashflows(derivative, ir_model))
+        return out
+
+    # --------------------------------------------------------------- cash flows
+    @staticmethod
+    def _extract_leg_cashflows(leg, leg_type_str: str) -> list:
+        """Cash-flow items of a leg that has just been valued (engine.py:34-87)."""
+        if not getattr(leg, "_payment_dfs", None):
+            return []
+        sign = -1.0 if "Pay" in leg_type_str else 1.0
+        items = []
+        for i, pay_dt in enumerate(leg._payment_dts):
+            notionals = getattr(leg, "_notional_array", None)
+            notional = float(notionals[i]) if notionals and i < len(notionals) else float(leg._notional)
+            amount = float(leg._payments[i])
+            items.append(CashflowItem(payment_date=pay_dt, notional=notional,
+                                      payment_fraction=amount / notional if notional != 0 else 0.0,
+                                      accrual_period=float(leg._year_fracs[i]), amount=sign * amount,
+                                      discount_factor=float(leg._payment_dfs[i]),
+                                      discounted_amount=sign * float(leg._payment_pvs[i]),
+                                      leg_type=leg_type_str))
+        return items
+
+    def _ois_cashflows(self, derivative, ir_model):
+        """CASHFLOWS request (engine.py:191-213): the legs are valued off the curve's OWN node set
+        (`OISCurve.df`, not the engine's knot grid) and their payment tables are reported."""
+        derivative._fixed_leg.value(ir_model._value_dt, ir_model)
+        derivative._float_leg.value(ir_model._value_dt, ir_model, ir_model)
+        pay_fixed = derivative._fixed_leg._leg_type == SwapTypes.PAY
+        items = self._extract_leg_cashflows(derivative._fixed_leg, "Fixed_Pay" if pay_fixed else "Fixed_Rec")
+        items += self._extract_leg_cashflows(derivative._float_leg, "Float_Rec" if pay_fixed else "Float_Pay")
+        return Cashflows(items, derivative._currency)
 
 
 def price_batch(engine: Engine, ir_model, derivatives, reqs, per_trade=True, aggregate=False):

@@ -251,6 +251,91 @@ class Risk:
         return f"Risk({', '.join(parts)})"
 
 
+@dataclass(frozen=True)
+class CashflowItem:
+    """One payment of a leg as last valued (cavour/requests/results.py:946-995): ``amount`` and
+    ``discounted_amount`` are signed from the holder's side (pay legs negative), ``payment_fraction`` is
+    the unsigned leg amount per unit notional, ``discount_factor`` is relative to the valuation date."""
+    payment_date: Any
+    notional: float
+    payment_fraction: float
+    accrual_period: float
+    amount: float
+    discount_factor: float
+    discounted_amount: float
+    leg_type: str          # "Fixed_Pay", "Fixed_Rec", "Float_Pay", "Float_Rec", "Notional_..."
+
+    def to_dict(self) -> Dict[str, Any]:
+        d = {k: float(getattr(self, k)) for k in ("notional", "payment_fraction", "accrual_period", "amount",
+                                                  "discount_factor", "discounted_amount")}
+        return {"payment_date": str(self.payment_date), **d, "leg_type": self.leg_type}
+
+
+class Cashflows:
+    """The cash flows of a trade with filters and totals (cavour/requests/results.py:998-1121)."""
+
+    def __init__(self, cashflows: List[CashflowItem], currency: CurrencyTypes):
+        self.cashflows = cashflows
+        self.currency = currency
+
+    def validate(self) -> bool:
+        if not isinstance(self.cashflows, list):
+            raise ValueError("cashflows must be a list")
+        if not all(isinstance(cf, CashflowItem) for cf in self.cashflows):
+            raise ValueError("All items must be CashflowItem instances")
+        return True
+
+    @property
+    def total_amount(self) -> float:
+        return sum(cf.amount for cf in self.cashflows)
+
+    @property
+    def total_pv(self) -> float:
+        return sum(cf.discounted_amount for cf in self.cashflows)
+
+    def _where(self, tag: str) -> "Cashflows":
+        return Cashflows([cf for cf in self.cashflows if tag in cf.leg_type], self.currency)
+
+    def fixed(self) -> "Cashflows":
+        return self._where("Fixed")
+
+    def floating(self) -> "Cashflows":
+        return self._where("Float")
+
+    def pay(self) -> "Cashflows":
+        return self._where("Pay")
+
+    def receive(self) -> "Cashflows":
+        return self._where("Rec")
+
+    def notional_exchange(self) -> "Cashflows":
+        return self._where("Notional")
+
+    def sum(self) -> Valuation:
+        return Valuation(amount=self.total_pv, currency=self.currency)
+
+    def to_dict(self) -> Dict[str, Any]:
+        return {"currency": self.currency.name, "cashflows": [cf.to_dict() for cf in self.cashflows],
+                "total_amount": float(self.total_amount), "total_pv": float(self.total_pv),
+                "count": len(self.cashflows)}
+
+    def to_json(self, indent: Optional[int] = 2) -> str:
+        return json.dumps(self.to_dict(), indent=indent)
+
+    @property
+    def df(self):
+        import pandas as pd
+        if not self.cashflows:
+            return pd.DataFrame()
+        return pd.DataFrame([cf.to_dict() for cf in self.cashflows]).set_index("payment_date")
+
+    def __len__(self) -> int:
+        return len(self.cashflows)
+
+    def __repr__(self) -> str:
+        return f"Cashflows(count={len(self.cashflows)}, total_pv={self.total_pv:,.2f} {self.currency.name})"
+
+
 class AnalyticsResult:
     """What ``compute`` returns: ``.value`` (Valuation), ``.risk`` (a `Delta`
     for a natural-currency OIS, cavour/market/position/engine.py:215), ``.gamma``

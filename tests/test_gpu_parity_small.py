@@ -35,3 +35,15 @@ def test_readme_curve_mixed_trades(gpu_ctx, interp):
     assert np.allclose(got["agg_delta"], got["delta"].sum(0), rtol=1e-12, atol=1e-9)
     assert np.allclose(got["agg_gamma"], got["gamma"].sum(0), rtol=1e-12, atol=1e-12)
     print("worst", worst)
+
+
+def test_cashflows_next_to_gpu_requests(gpu_ctx):
+    """VALUE/DELTA come from the kernels (engine knot grid), CASHFLOWS from the curve's own nodes; the two
+    curve constructions agree on the calibration instruments, so the totals are close but not identical."""
+    from adrates_amd.utils import RequestTypes
+    vd = F.README_VALUE_DT
+    model = F.gbp_model(vd)
+    swap = F.make_swap(vd, "10Y", 0.045, 1e7)
+    res = swap.position(model).compute([RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.CASHFLOWS])
+    assert res.gamma is None and len(res.cashflows) == 20 and len(res.risk.risk_ladder) == 32
+    assert abs(res.cashflows.total_pv - res.value.amount) < 1e-4 * swap._notional
