@@ -9,8 +9,8 @@ notional and leg signs.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-from typing import Iterable
+from dataclasses import dataclass, field
+from typing import Iterable, Sequence, Union
 
 import numpy as np
 
@@ -80,3 +80,131 @@ def compile_ois(swaps: Iterable, value_dt) -> TradeBatch:
     return TradeBatch(np.array(fix_off, dtype=np.int64), np.array(flt_off, dtype=np.int64),
                       f64(fix_tp), f64(fix_pay), f64(flt_tp), f64(flt_ts), f64(flt_te), f64(flt_al),
                       f64(notional), f64(spread), f64(fix_sign), f64(flt_sign))
+
+
+# --------------------------------------------------------------------------------------------------------
+# Vectorised path: trades given by their economic terms, no per-trade objects
+# (SURVEY.md section 8(f) row 4).  Every Python `Date` / `Schedule` / `DayCount` call of the object path
+# (cavour/utils/schedule.py:163-270, swap_fixed_leg.py:131-196, swap_float_leg.py:130-186) depends only on
+# the schedule-defining terms, so one template swap is built per DISTINCT combination of those terms and
+# the per-trade arrays are gathered from the templates with NumPy.  The result is bit-identical to
+# `compile_ois` on the corresponding `OIS` objects.
+# --------------------------------------------------------------------------------------------------------
+@dataclass
+class OISTerms:
+    """Economic terms of n OIS trades.  Scalars broadcast; sequences must have length n.
+
+    ``effective_dt``: a `Date`, a sequence of `Date`, or integer Excel serials (`int(Date.excel_dt())`);
+    ``tenor``: tenor strings ("18M", "10Y"); the remaining fields are the `OIS` constructor arguments of
+    the same names (adrates_amd/trades/rates/ois.py)."""
+    effective_dt: object
+    tenor: object
+    coupon: object
+    notional: object
+    pay_fixed: object
+    fixed_freq_type: object
+    fixed_dc_type: object
+    floating_index: object
+    currency: object
+    float_freq_type: object = None        # None: same as the fixed leg
+    float_dc_type: object = None
+    float_spread: object = 0.0
+    payment_lag: object = 0
+    bd_type: object = None                # None: the OIS constructor's default
+    cal_type: object = None
+    dg_type: object = None
+
+
+def _column(value, n, kind):
+    """Broadcast a scalar or validate a sequence; enums/dates become small integers for `numpy.unique`."""
+    seq = isinstance(value, (list, tuple, np.ndarray))
+    if seq and len(value) != n:
+        raise LibError("OISTerms: every per-trade sequence must have one entry per trade")
+    if kind == "float":
+        return np.broadcast_to(np.asarray(value, dtype=np.float64), (n,)).copy() if not seq else np.asarray(value, dtype=np.float64)
+    if kind == "int":
+        return np.broadcast_to(np.asarray(value, dtype=np.int64), (n,)).copy() if not seq else np.asarray(value, dtype=np.int64)
+    if kind == "bool":
+        return np.broadcast_to(np.asarray(value, dtype=bool), (n,)).copy() if not seq else np.asarray(value, dtype=bool)
+    if kind == "date":     # -> Excel serials
+        if seq:
+            return np.array([v if isinstance(v, (int, np.integer)) else int(v.excel_dt()) for v in value], dtype=np.int64)
+        return np.full(n, value if isinstance(value, (int, np.integer)) else int(value.excel_dt()), dtype=np.int64)
+    # enums and strings: codes into a table of distinct objects
+    items = list(value) if seq else [value]
+    table, codes = [], np.empty(len(items), dtype=np.int64)
+    index = {}
+    for i, v in enumerate(items):
+        k = index.get(v)
+        if k is None:
+            k = index[v] = len(table)
+            table.append(v)
+        codes[i] = k
+    return (codes if seq else np.full(n, codes[0], dtype=np.int64)), table
+
+
+def compile_ois_terms(terms: OISTerms, value_dt) -> TradeBatch:
+    """`TradeBatch` for the trades described by ``terms`` as of ``value_dt``."""
+    from ..utils.date import Date
+    from .rates.ois import OIS
+
+    notional = np.asarray(terms.notional, dtype=np.float64).reshape(-1)
+    n = notional.shape[0]
+    coupon = _column(terms.coupon, n, "float")
+    spread = _column(terms.float_spread, n, "float")
+    pay_fixed = _column(terms.pay_fixed, n, "bool")
+    lag = _column(terms.payment_lag, n, "int")
+    eff = _column(terms.effective_dt, n, "date")
+    float_freq = terms.fixed_freq_type if terms.float_freq_type is None else terms.float_freq_type
+    float_dc = terms.fixed_dc_type if terms.float_dc_type is None else terms.float_dc_type
+    coded = {}
+    for name, value in (("tenor", terms.tenor), ("fixed_freq", terms.fixed_freq_type), ("float_freq", float_freq),
+                        ("fixed_dc", terms.fixed_dc_type), ("float_dc", float_dc), ("bd", terms.bd_type),
+                        ("cal", terms.cal_type), ("dg", terms.dg_type), ("index", terms.floating_index),
+                        ("ccy", terms.currency)):
+        coded[name] = _column(value, n, "code")
+    key_cols = [eff, lag] + [coded[k][0] for k in coded]
+    keys, inverse = np.unique(np.stack(key_cols, axis=1), axis=0, return_inverse=True)
+    inverse = inverse.reshape(-1)
+
+    # one unit-coupon, unit-notional template per distinct schedule
+    names = list(coded)
+    templates = []
+    for row in keys:
+        kw = {k: coded[k][1][int(row[2 + j])] for j, k in enumerate(names)}
+        optional = {}
+        if kw["bd"] is not None:
+            optional["bd_type"] = kw["bd"]
+        if kw["cal"] is not None:
+            optional["cal_type"] = kw["cal"]
+        if kw["dg"] is not None:
+            optional["dg_type"] = kw["dg"]
+        swap = OIS(effective_dt=Date._from_serial(int(row[0])), term_dt_or_tenor=kw["tenor"],
+                   fixed_leg_type=SwapTypes.PAY, fixed_coupon=1.0, fixed_freq_type=kw["fixed_freq"],
+                   fixed_dc_type=kw["fixed_dc"], floating_index=kw["index"], currency=kw["ccy"], notional=1.0,
+                   float_freq_type=kw["float_freq"], float_dc_type=kw["float_dc"], payment_lag=int(row[1]),
+                   **optional)
+        templates.append(compile_ois([swap], value_dt))
+
+    n_fix = np.array([t.fix_tp.shape[0] for t in templates], dtype=np.int64)
+    n_flt = np.array([t.flt_tp.shape[0] for t in templates], dtype=np.int64)
+
+    def gather(counts, fld):
+        lens = counts[inverse]
+        off = np.concatenate(([0], np.cumsum(lens)))
+        cat = np.concatenate([getattr(t, fld) for t in templates]) if templates else np.zeros(0)
+        starts = np.concatenate(([0], np.cumsum(counts)))[:-1]
+        idx = np.repeat(starts[inverse] - off[:-1], lens) + np.arange(off[-1])
+        return off.astype(np.int64), cat[idx], lens
+
+    fix_off, fix_tp, fix_len = gather(n_fix, "fix_tp")
+    _, fix_alpha, _ = gather(n_fix, "fix_pay")          # unit notional * unit coupon = the accrual fraction
+    flt_off, flt_tp, _ = gather(n_flt, "flt_tp")
+    _, flt_ts, _ = gather(n_flt, "flt_ts")
+    _, flt_te, _ = gather(n_flt, "flt_te")
+    _, flt_alpha, _ = gather(n_flt, "flt_alpha")
+    # payment = year_frac * notional * coupon, in the leg's evaluation order (swap_fixed_leg.py:190)
+    fix_pay = fix_alpha * np.repeat(notional, fix_len) * np.repeat(coupon, fix_len)
+    sign_fix = np.where(pay_fixed, -1.0, 1.0)
+    return TradeBatch(fix_off, flt_off, fix_tp, fix_pay, flt_tp, flt_ts, flt_te, flt_alpha,
+                      notional.copy(), spread, sign_fix, -sign_fix)

@@ -1,0 +1,79 @@
+"""Vectorised trade compiler (trades/compiler.py::compile_ois_terms) == the object path, bit for bit."""
+import time
+
+import numpy as np
+import pytest
+
+from adrates_amd.trades.compiler import OISTerms, compile_ois, compile_ois_terms
+from adrates_amd.trades.rates.ois import OIS
+from adrates_amd.utils import (BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes,
+                               SwapTypes)
+from adrates_amd.utils.error import LibError
+
+from . import _fixtures as F
+
+FIELDS = ("fix_off", "flt_off", "fix_tp", "fix_pay", "flt_tp", "flt_ts", "flt_te", "flt_alpha", "notional",
+          "spread", "fix_sign", "flt_sign")
+
+
+def _same(a, b):
+    for f in FIELDS:
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+
+def test_mixed_terms_match_objects():
+    vd = F.README_VALUE_DT
+    rng = np.random.default_rng(5)
+    n = 300
+    effs = [vd, vd.add_weekdays(2), vd.add_months(3)]
+    eff = [effs[i] for i in rng.integers(0, 3, n)]
+    tenors = [["1W", "3M", "18M", "2Y", "87M", "10Y", "30Y"][i] for i in rng.integers(0, 7, n)]
+    ffreq = [[FrequencyTypes.ANNUAL, FrequencyTypes.SEMI_ANNUAL][i] for i in rng.integers(0, 2, n)]
+    lfreq = [[FrequencyTypes.ANNUAL, FrequencyTypes.QUARTERLY][i] for i in rng.integers(0, 2, n)]
+    fdc = [[DayCountTypes.ACT_365F, DayCountTypes.ACT_360][i] for i in rng.integers(0, 2, n)]
+    lag = rng.integers(0, 3, n)
+    coupon = rng.uniform(0.01, 0.07, n)
+    notional = np.round(rng.uniform(1e6, 5e7, n), -5)
+    pay = rng.random(n) < 0.5
+    spread = np.where(rng.random(n) < 0.3, 0.0025, 0.0)
+    terms = OISTerms(effective_dt=eff, tenor=tenors, coupon=coupon, notional=notional, pay_fixed=pay,
+                     fixed_freq_type=ffreq, fixed_dc_type=fdc, floating_index=CurveTypes.GBP_OIS_SONIA,
+                     currency=CurrencyTypes.GBP, float_freq_type=lfreq, float_dc_type=DayCountTypes.ACT_365F,
+                     float_spread=spread, payment_lag=lag, bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
+    swaps = [OIS(effective_dt=eff[i], term_dt_or_tenor=tenors[i],
+                 fixed_leg_type=SwapTypes.PAY if pay[i] else SwapTypes.RECEIVE, fixed_coupon=float(coupon[i]),
+                 fixed_freq_type=ffreq[i], fixed_dc_type=fdc[i], floating_index=CurveTypes.GBP_OIS_SONIA,
+                 currency=CurrencyTypes.GBP, notional=float(notional[i]), payment_lag=int(lag[i]),
+                 float_spread=float(spread[i]), float_freq_type=lfreq[i], float_dc_type=DayCountTypes.ACT_365F,
+                 bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING) for i in range(n)]
+    _same(compile_ois_terms(terms, vd), compile_ois(swaps, vd))
+
+
+def test_scalars_broadcast_serial_dates_and_defaults():
+    vd = F.README_VALUE_DT
+    terms = OISTerms(effective_dt=int(vd.excel_dt()), tenor=["5Y", "5Y", "2Y"], coupon=0.04, notional=[1e6, 2e6, 3e6],
+                     pay_fixed=True, fixed_freq_type=FrequencyTypes.ANNUAL, fixed_dc_type=DayCountTypes.ACT_360,
+                     floating_index=CurveTypes.USD_OIS_SOFR, currency=CurrencyTypes.USD)
+    swaps = [OIS(vd, t, SwapTypes.PAY, 0.04, FrequencyTypes.ANNUAL, DayCountTypes.ACT_360, CurveTypes.USD_OIS_SOFR,
+                 CurrencyTypes.USD, notional=nn, float_freq_type=FrequencyTypes.ANNUAL,
+                 float_dc_type=DayCountTypes.ACT_360) for t, nn in (("5Y", 1e6), ("5Y", 2e6), ("2Y", 3e6))]
+    _same(compile_ois_terms(terms, vd), compile_ois(swaps, vd))
+    with pytest.raises(LibError):
+        compile_ois_terms(OISTerms(vd, ["5Y"], 0.04, [1e6, 2e6], True, FrequencyTypes.ANNUAL, DayCountTypes.ACT_360,
+                                   CurveTypes.USD_OIS_SOFR, CurrencyTypes.USD), vd)
+
+
+def test_large_batch_is_fast():
+    """1e5 trades over 360 distinct schedules: seconds, where the object path needs minutes."""
+    vd = F.README_VALUE_DT
+    rng = np.random.default_rng(1)
+    n = 100_000
+    months = rng.integers(1, 361, n)
+    names = {m: f"{m}M" for m in range(1, 361)}
+    t0 = time.perf_counter()
+    b = compile_ois_terms(OISTerms(vd, [names[int(m)] for m in months], rng.uniform(0.01, 0.07, n),
+                                   np.full(n, 1e6), rng.random(n) < 0.5, FrequencyTypes.ANNUAL,
+                                   DayCountTypes.ACT_365F, CurveTypes.GBP_OIS_SONIA, CurrencyTypes.GBP,
+                                   float_freq_type=FrequencyTypes.ANNUAL, float_dc_type=DayCountTypes.ACT_365F,
+                                   bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING), vd)
+    assert b.n_trades == n and time.perf_counter() - t0 < 30.0
