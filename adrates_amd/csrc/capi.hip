@@ -189,7 +189,7 @@ int adr_curve_layout_host(int K, int P, const double* times, const double* dfs, 
     const std::string err = adr::build_curve_tables(K, P, times, dfs, jac, hess, t);
     if (!err.empty()) return fail(ADR_ERR_INVALID, "adr_curve_layout_host: " + err);
     adr::CurveDev d{};
-    d.K = t.K; d.Kc = t.Kc; d.Kcore = t.Kcore; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Eu = t.Eu; d.epg = t.epg; d.cpg = t.cpg; d.n_mini = t.n_mini;
+    d.K = t.K; d.Kc = t.Kc; d.Kcore = t.Kcore; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Eu = t.Eu; d.epg = t.epg; d.cpg = t.cpg; d.hub = t.hub ? 1 : 0; d.n_mini = t.n_mini;
     info[0] = t.packed_ok ? 1 : 0; info[1] = t.Pc; info[2] = t.Ec; info[3] = t.Eu; info[4] = t.epg;
     info[5] = t.Kcore; info[6] = t.n_mini;
     info[7] = t.packed_ok ? static_cast<int64_t>(adr::fast_kernel_lds_bytes(d, t.has_hess)) : 0;
@@ -232,6 +232,7 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     double *d_ljc = nullptr, *d_lcc = nullptr;
     int16_t *d_first = nullptr, *d_comp = nullptr, *d_class = nullptr, *d_p2c = nullptr, *d_omap = nullptr;
     uint8_t* d_pq = nullptr;
+    int16_t* d_cpos = nullptr;
     adr::MiniKnot* d_mini = nullptr;
     hipError_t e = hipSuccess;
     auto track = [&](hipError_t r, void* p) { if (p) c->allocations.push_back(p); if (e == hipSuccess) e = r; };
@@ -249,6 +250,7 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
         track(upload(t.pillar_to_core, &d_p2c), d_p2c);
         track(upload(t.out_map, &d_omap), d_omap);
         track(upload(t.ent_pq, &d_pq), d_pq);
+        track(upload(t.core_pos, &d_cpos), d_cpos);
         track(upload(t.mini, &d_mini), d_mini);
     }
     if (e != hipSuccess) { adr_free_curve(c); return fail_hip(e, "adr_curve_upload: copying tables"); }
@@ -257,10 +259,10 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     c->dev.first_of = d_first; c->dev.compact_of = d_comp;
     // the fast kernels write whole 32-wide rows; curves with fewer pillars use the general kernel
     c->dev.packed_ok = (t.packed_ok && t.P == adr::kPillarPad) ? 1 : 0;
-    c->dev.Pc = t.Pc; c->dev.pc_pad = t.pc_pad; c->dev.Ec = t.Ec; c->dev.Eu = t.Eu; c->dev.epg = t.epg; c->dev.cpg = t.cpg;
+    c->dev.Pc = t.Pc; c->dev.pc_pad = t.pc_pad; c->dev.Ec = t.Ec; c->dev.Eu = t.Eu; c->dev.epg = t.epg; c->dev.cpg = t.cpg; c->dev.hub = t.hub ? 1 : 0;
     c->dev.Kcore = t.Kcore; c->dev.n_mini = t.n_mini;
     c->dev.ljc = d_ljc; c->dev.lcc = d_lcc; c->dev.mini = d_mini; c->dev.knot_class = d_class;
-    c->dev.pillar_to_core = d_p2c; c->dev.out_map = d_omap; c->dev.ent_pq = d_pq;
+    c->dev.pillar_to_core = d_p2c; c->dev.out_map = d_omap; c->dev.ent_pq = d_pq; c->dev.core_pos = d_cpos;
     // the packed tables must fit the LDS of a CU next to the search arrays, else the general kernel serves all
     size_t fast_lds = 0;
     if (c->dev.packed_ok) {
@@ -320,7 +322,8 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     double *d_acc = nullptr, *d_x = nullptr, *d_invx = nullptr;
     int32_t *d_pil = nullptr, *d_prev = nullptr, *d_kidx = nullptr, *d_core = nullptr;
     int16_t *d_first = nullptr, *d_comp = nullptr, *d_class = nullptr, *d_p2c = nullptr, *d_omap = nullptr;
-    uint8_t* d_pq = nullptr;
+    uint8_t *d_pq = nullptr, *d_lccpq = nullptr;
+    int16_t* d_cpos = nullptr;
     auto track = [&](hipError_t r, void* p) { if (p) plan->allocations.push_back(p); if (e == hipSuccess) e = r; };
     track(upload(acc_v, &d_acc), d_acc);
     track(upload(pil_v, &d_pil), d_pil);
@@ -336,6 +339,8 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
         track(upload(t.pillar_to_core, &d_p2c), d_p2c);
         track(upload(t.out_map, &d_omap), d_omap);
         track(upload(t.ent_pq, &d_pq), d_pq);
+        track(upload(t.lcc_pq, &d_lccpq), d_lccpq);
+        track(upload(t.core_pos, &d_cpos), d_cpos);
     }
     if (e != hipSuccess) { adr_free_curve_plan(plan); return fail_hip(e, "adr_curve_plan_create: copying tables"); }
 
@@ -343,14 +348,14 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     d.K = K; d.P = P; d.Kc = t.Kc; d.acc = d_acc; d.pillar = d_pil; d.prev_idx = d_prev; d.knot_index = d_kidx;
     d.packed_ok = (t.packed_ok && t.P == adr::kPillarPad) ? 1 : 0;
     d.Pc = t.Pc; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Kcore = t.Kcore; d.n_mini = t.n_mini;
-    d.knot_class = d_class; d.core_pillars = d_core; d.ent_pq = d_pq;
+    d.knot_class = d_class; d.core_pillars = d_core; d.lcc_pq = d_lccpq;
 
     adr::CurveDev& c = plan->shared;
     c.K = t.K; c.Kc = t.Kc; c.P = t.P; c.method = interp_method;
     c.x = d_x; c.inv_x = d_invx; c.first_of = d_first; c.compact_of = d_comp;
     c.packed_ok = d.packed_ok;
-    c.Pc = t.Pc; c.pc_pad = t.pc_pad; c.Ec = t.Ec; c.Eu = t.Eu; c.epg = t.epg; c.cpg = t.cpg; c.Kcore = t.Kcore; c.n_mini = t.n_mini;
-    c.knot_class = d_class; c.pillar_to_core = d_p2c; c.out_map = d_omap; c.ent_pq = d_pq;
+    c.Pc = t.Pc; c.pc_pad = t.pc_pad; c.Ec = t.Ec; c.Eu = t.Eu; c.epg = t.epg; c.cpg = t.cpg; c.hub = t.hub ? 1 : 0; c.Kcore = t.Kcore; c.n_mini = t.n_mini;
+    c.knot_class = d_class; c.pillar_to_core = d_p2c; c.out_map = d_omap; c.ent_pq = d_pq; c.core_pos = d_cpos;
     size_t fast_lds = 0;
     if (c.packed_ok) {
         fast_lds = adr::fast_kernel_lds_bytes(c, plan->has_hess);

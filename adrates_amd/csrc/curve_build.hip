@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kBuildThreads) void pack_kernel(CurveBuildPlanDev p
         if (hk) {
             double* lcc = out.lcc + (static_cast<size_t>(scen) * (plan.Kcore + 1) + cls) * (plan.Ec + 1);
             for (int e = t; e < plan.Ec; e += kBuildThreads) {
-                const int p = plan.ent_pq[2 * e], q = plan.ent_pq[2 * e + 1];
+                const int p = plan.lcc_pq[2 * e], q = plan.lcc_pq[2 * e + 1];
                 lcc[e] = hk[p * P + q] / d - s_lj[p] * s_lj[q];
             }
         }

@@ -70,6 +70,98 @@ std::string build_curve_tables(int K, int P, const double* times, const double* 
     return std::string();
 }
 
+// Hub layout of the core pairs: every group lane's `cpg` core slots hold pairs that share one pillar (the
+// lane's hub), so the kernel fetches the hub's value once instead of once per pair.  Each core pair {a, b} is
+// given to one of its two pillars (a "star decomposition" of the complete graph on the core pillars, loops
+// (a, a) staying with a); hub h gets k_h lanes, i.e. room for cpg * k_h pairs, the k_h as even as 32 lanes allow.
+// The assignment is a bipartite matching with capacities, found with augmenting paths.  Returns false (layout
+// untouched) when the pairs do not fit.
+static bool hub_layout(int Pc, const std::vector<int>& core_pillars, int cpg, CurveTables& t) {
+    if (Pc < 1 || Pc > kGroupLanes) return false;
+    std::vector<int> lanes_of(Pc, kGroupLanes / Pc);
+    for (int h = 0; h < kGroupLanes % Pc; ++h) ++lanes_of[h];
+    std::vector<int> cap(Pc);
+    for (int h = 0; h < Pc; ++h) cap[h] = cpg * lanes_of[h] - 1;   // one slot is the loop (h, h)
+    struct Edge { int a, b, at; };
+    std::vector<Edge> edges;
+    for (int a = 0; a < Pc; ++a)
+        for (int b = a + 1; b < Pc; ++b) edges.push_back({a, b, -1});
+    std::vector<int> load(Pc, 0);
+    std::vector<std::vector<int>> held(Pc);                        // edges currently assigned to a hub
+    std::vector<char> visited(Pc);
+    // try to make room at hub h by moving one of its edges to that edge's other end (recursively)
+    auto make_room = [&](auto&& self, int h) -> bool {
+        if (load[h] < cap[h]) return true;
+        if (visited[h]) return false;
+        visited[h] = 1;
+        for (size_t k = 0; k < held[h].size(); ++k) {
+            const int ei = held[h][k];
+            const int other = edges[ei].a == h ? edges[ei].b : edges[ei].a;
+            if (self(self, other)) {
+                held[h].erase(held[h].begin() + static_cast<long>(k));
+                --load[h];
+                edges[ei].at = other;
+                held[other].push_back(ei);
+                ++load[other];
+                return true;
+            }
+        }
+        return false;
+    };
+    for (size_t ei = 0; ei < edges.size(); ++ei) {
+        bool placed = false;
+        for (int h : {edges[ei].a, edges[ei].b}) {
+            std::fill(visited.begin(), visited.end(), 0);
+            if (make_room(make_room, h)) {
+                edges[ei].at = h;
+                held[h].push_back(static_cast<int>(ei));
+                ++load[h];
+                placed = true;
+                break;
+            }
+        }
+        if (!placed) return false;
+    }
+
+    const int n_core_entries = cpg * kGroupLanes, Ec = Pc * (Pc + 1) / 2;
+    std::vector<uint8_t> pq(2 * static_cast<size_t>(n_core_entries));
+    std::vector<char> real(n_core_entries, 0);
+    int lane = 0;
+    for (int h = 0; h < Pc; ++h) {
+        std::vector<int> partners{h};                              // the loop first
+        for (int ei : held[h]) partners.push_back(edges[ei].a == h ? edges[ei].b : edges[ei].a);
+        for (size_t k = 0; k < partners.size(); k += static_cast<size_t>(cpg), ++lane) {
+            if (lane >= kGroupLanes) return false;
+            for (int i = 0; i < cpg; ++i) {
+                const int e = lane + kGroupLanes * i;
+                const bool on = k + static_cast<size_t>(i) < partners.size();
+                pq[2 * e] = static_cast<uint8_t>(core_pillars[h]);
+                pq[2 * e + 1] = static_cast<uint8_t>(core_pillars[on ? partners[k + static_cast<size_t>(i)] : h]);
+                real[e] = on;
+            }
+        }
+    }
+    for (; lane < kGroupLanes; ++lane)                             // idle lanes: padding on the first core pillar
+        for (int i = 0; i < cpg; ++i) {
+            const int e = lane + kGroupLanes * i;
+            pq[2 * e] = pq[2 * e + 1] = static_cast<uint8_t>(core_pillars[0]);
+        }
+    // compact row positions, slot-major, so that the lanes of one slot read (nearly) consecutive addresses
+    t.core_pos.assign(n_core_entries, static_cast<int16_t>(Ec));   // Ec = the row's trailing zero
+    t.lcc_pq.assign(2 * static_cast<size_t>(Ec), 0);
+    int pos = 0;
+    for (int e = 0; e < n_core_entries; ++e)
+        if (real[e]) {
+            t.core_pos[e] = static_cast<int16_t>(pos);
+            t.lcc_pq[2 * pos] = pq[2 * e];
+            t.lcc_pq[2 * pos + 1] = pq[2 * e + 1];
+            ++pos;
+        }
+    if (pos != Ec) return false;
+    t.ent_pq.assign(pq.begin(), pq.end());
+    return true;
+}
+
 // Pillar-support analysis for the fast kernels.
 //
 // A bootstrapped knot DF depends only on the par rates of the swaps in its bootstrap chain, so most of
@@ -152,6 +244,20 @@ bool build_packed_layout(CurveTables& t) {
     }
     if (t.epg == 0) return false;
     const int fringe_start = (t.cpg < t.epg ? t.cpg : core_slots_min) * kGroupLanes;
+
+    // position of a core pair in a convexity row: packed_index order unless the hub layout rearranges it
+    t.lcc_pq.assign(t.ent_pq.begin(), t.ent_pq.end());
+    t.core_pos.clear();
+    t.hub = false;
+    if (t.cpg < t.epg && hub_layout(Pc, core_pillars, t.cpg, t)) {
+        // ent_pq / core_pos / lcc_pq now describe the star decomposition; redo entry_of for the core pairs
+        for (int e = 0; e < t.cpg * kGroupLanes; ++e) {
+            if (t.core_pos[e] >= Ec) continue;
+            const int p = t.ent_pq[2 * e], q = t.ent_pq[2 * e + 1];
+            entry_of[std::min(p, q) * kPillarPad + std::max(p, q)] = e;
+        }
+        t.hub = true;
+    }
     while (static_cast<int>(t.ent_pq.size() / 2) < fringe_start) { t.ent_pq.push_back(0); t.ent_pq.push_back(0); }
     for (const auto& pq : fringe) {
         entry_of[pq.first * kPillarPad + pq.second] = static_cast<int>(t.ent_pq.size() / 2);
@@ -204,10 +310,9 @@ bool build_packed_layout(CurveTables& t) {
         for (int i = 0; i < Pc; ++i)
             t.ljc[static_cast<size_t>(row) * t.pc_pad + i] = t.lj[static_cast<size_t>(c) * kPillarPad + core_pillars[i]];
         if (!t.has_hess) continue;
-        for (int i = 0; i < Pc; ++i)
-            for (int j = i; j < Pc; ++j)
-                t.lcc[static_cast<size_t>(row) * (Ec + 1) + packed_index(i, j, Pc)] =
-                    t.lc[(static_cast<size_t>(c) * P + core_pillars[i]) * P + core_pillars[j]];
+        for (int pos = 0; pos < Ec; ++pos)
+            t.lcc[static_cast<size_t>(row) * (Ec + 1) + pos] =
+                t.lc[(static_cast<size_t>(c) * P + t.lcc_pq[2 * pos]) * P + t.lcc_pq[2 * pos + 1]];
     }
     return true;
 }

@@ -64,7 +64,10 @@ struct CurveTables {
     std::vector<int16_t> knot_class;       // [Kc]   >= 0: core row; -2: all-zero knot; <= -3: mini record -3 - m
     std::vector<double> ljc;               // [Kcore + 1][pc_pad]  LJ on the core pillars; last row all zero
     std::vector<double> lcc;               // [Kcore + 1][Ec + 1]  LC on the packed core pairs, then a 0; last row zero
-    std::vector<uint8_t> ent_pq;           // [Eu][2]          pillars (p <= q) of packed entry e
+    std::vector<uint8_t> ent_pq;           // [Eu][2]          pillars of packed entry e (hub layout: hub first)
+    bool hub = false;                      // core slots of a lane share their first pillar (see hub_layout)
+    std::vector<int16_t> core_pos;         // [32*cpg]         hub layout: position of core entry e in a lcc row (Ec: none)
+    std::vector<uint8_t> lcc_pq;           // [Ec][2]          pillars of the pair stored at position pos of a lcc row
     std::vector<int16_t> out_map;          // [32*32]          packed entry feeding gamma[r][c], -1 if none
     std::vector<MiniKnot> mini;            // [n_mini]
 };

@@ -76,7 +76,7 @@ struct CurveDev {
     const double* lj;            // [Kc][32]
     const double* lc_lanes;      // [Kc][64][16], null without gamma
     // fast kernels: packed layout (curve_tables.hpp), valid when packed_ok
-    int packed_ok, Pc, pc_pad, Ec, Eu, epg, cpg, Kcore, n_mini;
+    int packed_ok, Pc, pc_pad, Ec, Eu, epg, cpg, hub, Kcore, n_mini;
     const double* ljc;           // [Kcore][pc_pad]
     const double* lcc;           // [Kcore][Ec + 1] (last entry of every row is 0), null without gamma
     const MiniKnot* mini;        // [n_mini]
@@ -84,6 +84,7 @@ struct CurveDev {
     const int16_t* pillar_to_core;  // [32]
     const int16_t* out_map;      // [32*32]
     const uint8_t* ent_pq;       // [Eu][2]
+    const int16_t* core_pos;     // [32*cpg] hub layout only: row position of core entry e
 };
 
 struct OutputsDev {
@@ -106,7 +107,7 @@ struct CurveBuildPlanDev {
     int packed_ok, Pc, pc_pad, Ec, Kcore, n_mini;
     const int16_t* knot_class;    // [Kc]
     const int32_t* core_pillars;  // [Pc]
-    const uint8_t* ent_pq;        // [Eu][2]
+    const uint8_t* lcc_pq;        // [Ec][2] pillars of the pair at each position of a lcc row
 };
 
 struct CurvePackOut {             // every array has a leading scenario axis

@@ -237,6 +237,9 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     int col[PPL];                                 // ljc column of pillar l + L*k
 #pragma unroll
     for (int k = 0; k < PPL; ++k) col[k] = cv.pillar_to_core[l + L * k];
+    // Exact variants (CPG < EPG) use the hub layout: the CPG core pairs of a lane share their first pillar,
+    // whose v is read once per node; their convexity values sit at per-lane positions of the compact row.
+    constexpr bool HUB = GAMMA && CPG < EPG;
     int up[EPG], vq[EPG];                         // the two pillars of packed entry l + L*i (0, 0 if none)
 #pragma unroll
     for (int i = 0; i < EPG; ++i) {
@@ -245,6 +248,10 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
         up[i] = on ? cv.ent_pq[2 * e] : 0;
         vq[i] = on ? cv.ent_pq[2 * e + 1] : 0;
     }
+    const int hub_p = HUB ? up[0] : 0;            // == up[i] for every core slot i < CPG
+    int pos[CPG > 0 ? CPG : 1];                   // position of core entry l + L*i in a convexity row
+#pragma unroll
+    for (int i = 0; i < CPG; ++i) pos[i] = HUB ? cv.core_pos[l + L * i] : l + L * i;
 
     // Output map of this lane: it writes elements 2*lane, 2*lane + 1 of each 128-element band (4 rows of 32) of
     // a trade's matrix, so every store instruction covers 1 KB of consecutive addresses; two int16 packed
@@ -355,10 +362,16 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
         int carry_row = zero_row;
         double carry_w = 0.0;
         auto lc_row_pass = [&](int row, double w) {
-            const double* src = c.lcc + row * c.ec_stride + l;
             double lr[CPG > 0 ? CPG : 1];
+            if (HUB) {
+                const double* src = c.lcc + row * c.ec_stride;
 #pragma unroll
-            for (int i = 0; i < CPG; ++i) lr[i] = src[L * i];
+                for (int i = 0; i < CPG; ++i) lr[i] = src[pos[i]];
+            } else {
+                const double* src = c.lcc + row * c.ec_stride + l;
+#pragma unroll
+                for (int i = 0; i < CPG; ++i) lr[i] = src[L * i];
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < CPG; ++i) {
@@ -475,28 +488,30 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                         lc_row_pass(flush ? carry_row : zero_row, flush ? carry_w : 0.0);
                         if (flush) { carry_row = zero_row; carry_w = 0.0; }
                     }
-                    const double* rowa = c.lcc + ra * c.ec_stride + l;
+                    const double* rowa = c.lcc + ra * c.ec_stride + (HUB ? 0 : l);
                     const double coa = om * wa + (carry_row == ra ? carry_w : 0.0), cob = om * wb;
                     carry_row = rb; carry_w = cob;
                     // All operands of a batch of entries are fetched before any of them is used: the
                     // scheduling barrier keeps the compiler from pairing each LDS read with its FMA (which
                     // would expose one LDS round trip per entry).
                     constexpr int kBatch = EPG < ADR_FAST_BATCH ? EPG : ADR_FAST_BATCH;
+                    double hub_v = 0.0;
 #pragma unroll
                     for (int i0 = 0; i0 < EPG; i0 += kBatch) {
                         double uu[kBatch], vv[kBatch], la[kBatch];
+                        if (HUB && i0 == 0) hub_v = vbuf[hub_p];
 #pragma unroll
                         for (int i = 0; i < kBatch; ++i) {
                             if (i0 + i >= EPG) continue;
 #ifndef ADR_ABLATE_RANK1
-                            uu[i] = vbuf[up[i0 + i]];
+                            if (!(HUB && i0 + i < CPG)) uu[i] = vbuf[up[i0 + i]];
                             vv[i] = vbuf[vq[i0 + i]];
 #else
                             uu[i] = om; vv[i] = wa;
 #endif
-                            // convexity rows: entry l + L*i of a row sits at row[l + L*i]
+                            // convexity rows: entry l + L*i of a row sits at row[l + L*i] (hub layout: row[pos[i]])
 #ifndef ADR_ABLATE_LC
-                            if (i0 + i < CPG) la[i] = rowa[L * (i0 + i)];
+                            if (i0 + i < CPG) la[i] = HUB ? rowa[pos[i0 + i]] : rowa[L * (i0 + i)];
 #else
                             if (i0 + i < CPG) la[i] = wb;
 #endif
@@ -505,7 +520,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 #pragma unroll
                         for (int i = 0; i < kBatch; ++i) {
                             if (i0 + i >= EPG) continue;
-                            double gsum = fma(om * uu[i], vv[i], acc[i0 + i]);
+                            const double u_i = (HUB && i0 + i < CPG) ? hub_v : uu[i];
+                            double gsum = fma(om * u_i, vv[i], acc[i0 + i]);
                             if (i0 + i < CPG) {
                                 const bool core = CPG < EPG || (i0 + i) < core_entries;   // compile-time true unless universal
                                 gsum = fma(core ? coa : 0.0, la[i], gsum);
