@@ -9,7 +9,7 @@
 #define ADR_FAST_THREADS 768
 #endif
 #ifndef ADR_FAST_BATCH
-#define ADR_FAST_BATCH 2    // packed entries whose LDS operands are fetched together
+#define ADR_FAST_BATCH 4    // packed entries whose LDS operands are fetched together
 #endif
 #ifndef ADR_FAST_GROUPS
 #define ADR_FAST_GROUPS 2   // trades per wavefront in the fast kernel (rows have 64 / 2 = 32 slots)

@@ -47,3 +47,36 @@ def test_cashflows_next_to_gpu_requests(gpu_ctx):
     res = swap.position(model).compute([RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.CASHFLOWS])
     assert res.gamma is None and len(res.cashflows) == 20 and len(res.risk.risk_ladder) == 32
     assert abs(res.cashflows.total_pv - res.value.amount) < 1e-4 * swap._notional
+
+
+@pytest.mark.parametrize("shape", ["core21_epg12", "core16_epg7"])
+def test_other_curve_shapes_use_other_kernel_variants(gpu_ctx, shape):
+    """32-pillar curves whose long end is longer / shorter than the README curve's: a different core size picks a
+    different instantiation of the fast kernel (12 or 7 packed entries per lane; hub layout with 10 or 5 core
+    slots).  Same parity bar."""
+    from adrates_amd import _native
+    from adrates_amd.market.curves.curve_tables import build_engine_curve
+    vd = F.README_VALUE_DT
+    if shape == "core21_epg12":
+        tenors = ["1W", "2W", "1M", "2M", "3M", "4M", "5M", "6M", "7M", "8M", "9M", "1Y"] \
+            + [f"{y}Y" for y in range(2, 19)] + ["20Y", "25Y", "30Y"]
+        px = [5.20 - 0.02 * i for i in range(12)] + [4.6 - 0.03 * i for i in range(20)]
+        want = (21, 12)
+    else:
+        tenors = ["1W", "2W", "1M", "2M", "3M", "4M", "5M", "6M", "7M", "8M", "9M", "10M", "11M", "1Y", "15M",
+                  "18M", "21M"] + [f"{y}Y" for y in range(2, 13)] + ["15Y", "20Y", "25Y", "30Y"]
+        px = [5.20 - 0.02 * i for i in range(17)] + [4.6 - 0.03 * i for i in range(15)]
+        want = (16, 7)
+    model = F.gbp_model(vd, px=px, tenors=tenors)
+    curve = model.curves.GBP_OIS_SONIA
+    host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    info = _native.curve_layout_host(host.times, host.dfs, host.jac, host.hess)
+    assert info["packed_ok"] == 1 and (info["core_pillars"], info["entries_per_lane"]) == want
+    assert info["lds_bytes"] <= 160 * 1024
+    swaps = [F.make_swap(vd, "10Y", 0.045, 1e7), F.make_swap(vd, "87M", 0.04, 1e7, pay=False),
+             F.make_swap(vd, "3M", 0.05, 2e6), F.make_swap(vd, "29Y", 0.039, 5e6),
+             F.make_swap(vd, "14M", 0.05, 3e6, pay=False), F.make_swap(vd, "17Y", 0.04, 1e6, spread=0.002),
+             F.make_swap(vd, "5Y", 0.04, 1e6, fixed_freq=FrequencyTypes.SEMI_ANNUAL)]
+    got = gpu_price(gpu_ctx, curve, swaps, vd, aggregate=True)
+    assert_parity(got, oracle_price(curve, swaps, vd), [s._notional for s in swaps])
+    assert np.allclose(got["agg_gamma"], got["gamma"].sum(0), rtol=1e-12, atol=1e-12)
