@@ -11,9 +11,6 @@
 #ifndef ADR_FAST_BATCH
 #define ADR_FAST_BATCH 4    // packed entries whose LDS operands are fetched together
 #endif
-#ifndef ADR_FAST_GROUPS
-#define ADR_FAST_GROUPS 2   // trades per wavefront in the fast kernel (rows have 64 / 2 = 32 slots)
-#endif
 
 namespace adr {
 

@@ -40,8 +40,7 @@
 // as 1 KB-contiguous stores.  No atomics; the aggregate is a fixed-order reduction.
 //
 // The kernel is bound by the CU's LDS pipe (about 28 LDS instructions per node pair) at 3 waves/SIMD - the
-// tables fill the 160 KB of LDS, so there is one 768-thread block per CU.  ADR_ABLATE_* (diagnostic builds,
-// results are wrong) remove one class of LDS operations each to price it; see DESIGN.md section 7.
+// tables fill the 160 KB of LDS, so there is one 768-thread block per CU; see DESIGN.md section 7.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -53,9 +52,6 @@ namespace adr {
 
 namespace {
 
-#ifndef ADR_LDS_FENCE
-#define ADR_LDS_FENCE 0
-#endif
 constexpr int kBlockThreads = kFastThreads;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 
@@ -66,15 +62,9 @@ __device__ __forceinline__ double shfl_d(double x, int src) { return __shfl(x, s
 // retire; all that is needed is that the compiler keeps the program order of the accesses (it does for
 // may-aliasing LDS accesses; the empty asm is a belt-and-braces compiler barrier with no instructions).
 __device__ __forceinline__ void wave_lds_sync() {
-#if ADR_LDS_FENCE
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
-#endif
 }
 
 #ifdef ADR_STAMPS
@@ -179,9 +169,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     const int n_lcc = GAMMA ? (cv.Kcore + 1) * ec_stride : 0;
     // zeros behind the last row: a row has Ec + 1 entries and is read L*CPG entries wide
     const int n_slack = GAMMA ? (L * CPG > cv.Ec + 1 ? L * CPG - (cv.Ec + 1) : 0) : 0;
-    // per-wave slot: the lanes' node scalars (omega, ba, bb: 3 x 64 doubles; packed knot classes: 64 ints),
-    // then (gamma) the groups' v hand-off buffers; the front is reused as the packed-ladder staging area at
-    // output time
+    // per-wave slot: the lanes' 32-byte node records {omega, ba, bb, packed knot classes}, then (gamma) the
+    // groups' v hand-off buffers; the front is reused as the packed-ladder staging area at output time
     constexpr int kRecDoubles = 64 * 4;
     constexpr int kSlotDoubles = slot_doubles(GAMMA, EPG, G);
     MiniKnot* s_mini = reinterpret_cast<MiniKnot*>(smem_raw);
@@ -226,7 +215,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     const int g = lane / L, l = lane % L;
     const int gbase = g * L;                      // first lane of this lane's group
     double* slot = s_slot + wave * kSlotDoubles;
-    double* rec = slot;                           // node scalars: omega[64], ba[64], bb[64]
+    double* rec = slot;                           // node records, 4 doubles per lane
     double* vbuf = slot + kRecDoubles + g * kPillarPad;       // this group's v, 32 doubles
     const int P = cv.P;
     const int bi = lane >> 3, bj = lane & 7;
@@ -403,9 +392,9 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             if (!DELTA) continue;
             const bool greeks = qon && !(cls_a == -2 && cls_b == -2);
             if (!greeks) { omega = 0.0; cls_a = -2; cls_b = -2; }
-            // ---- consume: the groups walk their nodes in lockstep.  Every lane leaves its node's three doubles
-            // in LDS; node n of a group is then two broadcast reads plus one ds_bpermute for the packed knot
-            // classes (instead of eight ds_bpermute), issued one node ahead so that the round trip hides
+            // ---- consume: the groups walk their nodes in lockstep.  Every lane leaves its node as a 32-byte
+            // record {omega, ba, bb, packed knot classes} in LDS; node n of a group is then two broadcast
+            // b128 reads (instead of eight ds_bpermute), issued one node ahead so that the round trip hides
             // behind the previous node's work.
             const int classes = (cls_a & 0xffff) | (cls_b << 16);
             __builtin_amdgcn_wave_barrier();
@@ -444,11 +433,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                     const double* lja = c.ljc + ra * c.pc_pad;
                     const double* ljb = c.ljc + rb * c.pc_pad;
 #pragma unroll
-#ifndef ADR_ABLATE_V
                     for (int k = 0; k < PPL; ++k) v[k] = fma(wb, ljb[col[k]], wa * lja[col[k]]);
-#else
-                    for (int k = 0; k < PPL; ++k) v[k] = wb * ra + wa * rb;
-#endif
                 }
                 // ... plus the short-end knots' one or two entries
                 if (any_mini) {
@@ -474,10 +459,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                 if (GAMMA) {
                     // rank-1 part: omega * v v^T through the group's LDS slot
                     __builtin_amdgcn_wave_barrier();
-#ifndef ADR_ABLATE_UVWRITE
 #pragma unroll
                     for (int k = 0; k < PPL; ++k) vbuf[l + L * k] = v[k];
-#endif
                     wave_lds_sync();
                     // Convexity rows.  Consecutive nodes of a swap usually share a knot (the right neighbour of
                     // one payment time is the left neighbour of the next), so the right-hand row is not read
@@ -503,18 +486,10 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 #pragma unroll
                         for (int i = 0; i < kBatch; ++i) {
                             if (i0 + i >= EPG) continue;
-#ifndef ADR_ABLATE_RANK1
                             if (!(HUB && i0 + i < CPG)) uu[i] = vbuf[up[i0 + i]];
                             vv[i] = vbuf[vq[i0 + i]];
-#else
-                            uu[i] = om; vv[i] = wa;
-#endif
                             // convexity rows: entry l + L*i of a row sits at row[l + L*i] (hub layout: row[pos[i]])
-#ifndef ADR_ABLATE_LC
                             if (i0 + i < CPG) la[i] = HUB ? rowa[pos[i0 + i]] : rowa[L * (i0 + i)];
-#else
-                            if (i0 + i < CPG) la[i] = wb;
-#endif
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -708,7 +683,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* part
     if (lane == 0) agg[i] = s;
 }
 
-constexpr int kGroups = ADR_FAST_GROUPS;
+constexpr int kGroups = 2;   // trades per wavefront: the row table has 64 / 2 = 32 slots per row
 
 // Kernel variant for a curve: (epg, cpg) as chosen by build_packed_layout - epg in {7, 8, 12, 18} slots per
 // group lane, with cpg = epg - 2 (the last two slots hold the fringe pairs) or cpg = epg (universal).
