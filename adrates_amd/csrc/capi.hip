@@ -231,6 +231,7 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     double *d_x = nullptr, *d_log = nullptr, *d_invx = nullptr, *d_lj = nullptr, *d_lc = nullptr;
     double *d_ljc = nullptr, *d_lcc = nullptr;
     int16_t *d_first = nullptr, *d_comp = nullptr, *d_class = nullptr, *d_p2c = nullptr, *d_omap = nullptr;
+    int16_t* d_smap = nullptr;
     uint8_t* d_pq = nullptr;
     int16_t* d_cpos = nullptr;
     adr::MiniKnot* d_mini = nullptr;
@@ -249,6 +250,7 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
         track(upload(t.knot_class, &d_class), d_class);
         track(upload(t.pillar_to_core, &d_p2c), d_p2c);
         track(upload(t.out_map, &d_omap), d_omap);
+        track(upload(t.store_map, &d_smap), d_smap);
         track(upload(t.ent_pq, &d_pq), d_pq);
         track(upload(t.core_pos, &d_cpos), d_cpos);
         track(upload(t.mini, &d_mini), d_mini);
@@ -257,12 +259,12 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     c->dev.K = t.K; c->dev.Kc = t.Kc; c->dev.P = t.P; c->dev.method = interp_method;
     c->dev.x = d_x; c->dev.log_df = d_log; c->dev.inv_x = d_invx; c->dev.lj = d_lj; c->dev.lc_lanes = d_lc;
     c->dev.first_of = d_first; c->dev.compact_of = d_comp;
-    // the fast kernels write whole 32-wide rows; curves with fewer pillars use the general kernel
-    c->dev.packed_ok = (t.packed_ok && t.P == adr::kPillarPad) ? 1 : 0;
+    // the fast kernels store the [P][P] matrices as 16-byte pairs of the flat array: P must be even
+    c->dev.packed_ok = (t.packed_ok && t.P % 2 == 0) ? 1 : 0;
     c->dev.Pc = t.Pc; c->dev.pc_pad = t.pc_pad; c->dev.Ec = t.Ec; c->dev.Eu = t.Eu; c->dev.epg = t.epg; c->dev.cpg = t.cpg; c->dev.hub = t.hub ? 1 : 0;
     c->dev.Kcore = t.Kcore; c->dev.n_mini = t.n_mini;
     c->dev.ljc = d_ljc; c->dev.lcc = d_lcc; c->dev.mini = d_mini; c->dev.knot_class = d_class;
-    c->dev.pillar_to_core = d_p2c; c->dev.out_map = d_omap; c->dev.ent_pq = d_pq; c->dev.core_pos = d_cpos;
+    c->dev.pillar_to_core = d_p2c; c->dev.out_map = d_omap; c->dev.store_map = d_smap; c->dev.ent_pq = d_pq; c->dev.core_pos = d_cpos;
     // the packed tables must fit the LDS of a CU next to the search arrays, else the general kernel serves all
     size_t fast_lds = 0;
     if (c->dev.packed_ok) {
@@ -322,6 +324,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     double *d_acc = nullptr, *d_x = nullptr, *d_invx = nullptr;
     int32_t *d_pil = nullptr, *d_prev = nullptr, *d_kidx = nullptr, *d_core = nullptr;
     int16_t *d_first = nullptr, *d_comp = nullptr, *d_class = nullptr, *d_p2c = nullptr, *d_omap = nullptr;
+    int16_t* d_smap = nullptr;
     uint8_t *d_pq = nullptr, *d_lccpq = nullptr;
     int16_t* d_cpos = nullptr;
     auto track = [&](hipError_t r, void* p) { if (p) plan->allocations.push_back(p); if (e == hipSuccess) e = r; };
@@ -338,6 +341,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
         track(upload(t.knot_class, &d_class), d_class);
         track(upload(t.pillar_to_core, &d_p2c), d_p2c);
         track(upload(t.out_map, &d_omap), d_omap);
+        track(upload(t.store_map, &d_smap), d_smap);
         track(upload(t.ent_pq, &d_pq), d_pq);
         track(upload(t.lcc_pq, &d_lccpq), d_lccpq);
         track(upload(t.core_pos, &d_cpos), d_cpos);
@@ -346,7 +350,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
 
     adr::CurveBuildPlanDev& d = plan->dev;
     d.K = K; d.P = P; d.Kc = t.Kc; d.acc = d_acc; d.pillar = d_pil; d.prev_idx = d_prev; d.knot_index = d_kidx;
-    d.packed_ok = (t.packed_ok && t.P == adr::kPillarPad) ? 1 : 0;
+    d.packed_ok = (t.packed_ok && t.P % 2 == 0) ? 1 : 0;
     d.Pc = t.Pc; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Kcore = t.Kcore; d.n_mini = t.n_mini;
     d.knot_class = d_class; d.core_pillars = d_core; d.lcc_pq = d_lccpq;
 
@@ -355,7 +359,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     c.x = d_x; c.inv_x = d_invx; c.first_of = d_first; c.compact_of = d_comp;
     c.packed_ok = d.packed_ok;
     c.Pc = t.Pc; c.pc_pad = t.pc_pad; c.Ec = t.Ec; c.Eu = t.Eu; c.epg = t.epg; c.cpg = t.cpg; c.hub = t.hub ? 1 : 0; c.Kcore = t.Kcore; c.n_mini = t.n_mini;
-    c.knot_class = d_class; c.pillar_to_core = d_p2c; c.out_map = d_omap; c.ent_pq = d_pq; c.core_pos = d_cpos;
+    c.knot_class = d_class; c.pillar_to_core = d_p2c; c.out_map = d_omap; c.store_map = d_smap; c.ent_pq = d_pq; c.core_pos = d_cpos;
     size_t fast_lds = 0;
     if (c.packed_ok) {
         fast_lds = adr::fast_kernel_lds_bytes(c, plan->has_hess);

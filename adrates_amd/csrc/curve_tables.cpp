@@ -271,6 +271,11 @@ bool build_packed_layout(CurveTables& t) {
         for (int q = 0; q < P; ++q)
             t.out_map[r * kPillarPad + q] = static_cast<int16_t>(entry_of[std::min(r, q) * kPillarPad + std::max(r, q)]);
 
+    // the same map by flat index r*P + c of the caller's [P][P] matrix (what the store loop walks); -2 beyond it
+    t.store_map.assign(kPillarPad * kPillarPad, -2);
+    for (int r = 0; r < P; ++r)
+        for (int q = 0; q < P; ++q) t.store_map[r * P + q] = t.out_map[r * kPillarPad + q];
+
     t.knot_class.assign(Kc, -2);
     t.Kcore = 0;
     t.mini.clear();

@@ -79,7 +79,8 @@ struct CurveDev {
     const MiniKnot* mini;        // [n_mini]
     const int16_t* knot_class;   // [Kc]
     const int16_t* pillar_to_core;  // [32]
-    const int16_t* out_map;      // [32*32]
+    const int16_t* out_map;      // [32*32] packed entry of gamma[r][c], rows 32 wide (aggregate)
+    const int16_t* store_map;    // [32*32] packed entry by flat index r*P + c of the caller's matrix; -2 beyond P*P
     const uint8_t* ent_pq;       // [Eu][2]
     const int16_t* core_pos;     // [32*cpg] hub layout only: row position of core entry e
 };

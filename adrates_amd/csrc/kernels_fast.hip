@@ -242,14 +242,15 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 #pragma unroll
     for (int i = 0; i < CPG; ++i) pos[i] = HUB ? cv.core_pos[l + L * i] : l + L * i;
 
-    // Output map of this lane: it writes elements 2*lane, 2*lane + 1 of each 128-element band (4 rows of 32) of
-    // a trade's matrix, so every store instruction covers 1 KB of consecutive addresses; two int16 packed
-    // entry indices per band, -1 where the matrix is structurally zero.
+    // Output map of this lane: it writes elements 2*lane, 2*lane + 1 of each 128-element band of a trade's
+    // flat [P][P] matrix (4 rows when P = 32), so every store instruction covers 1 KB of consecutive addresses;
+    // two int16 packed entry indices per band, -1 where the matrix is structurally zero, -2 beyond P*P (P is
+    // even, so a pair never straddles the end; such pairs are stored to the sink).
     int mm[GAMMA ? 8 : 1];
     if (GAMMA) {
 #pragma unroll
         for (int band = 0; band < 8; ++band)
-            mm[band] = *reinterpret_cast<const int*>(cv.out_map + 2 * lane + band * 128);
+            mm[band] = *reinterpret_cast<const int*>(cv.store_map + 2 * lane + band * 128);
     }
 
     // running portfolio sums of this wave: pv per group (lane l == 0), delta per group lane/pillar,
@@ -571,7 +572,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                 }
                 wave_lds_sync();
                 // LDS reads of a trade in two batches: the running-total slice + bands 0-3, then bands 4-7
-                double* gm = (tt >= 0 ? out.gamma + static_cast<int64_t>(tt) * (kPillarPad * kPillarPad) : out.dump) + 2 * lane;
+                double* gm = (tt >= 0 ? out.gamma + static_cast<int64_t>(tt) * (P * P) : out.dump) + 2 * lane;
+                double* sink = out.dump + 2 * lane;            // pairs beyond a P < 32 matrix go here
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     double ts_[EPL], gv[8];
@@ -602,7 +604,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                             const int m0 = static_cast<int16_t>(mb & 0xffff), m1 = mb >> 16;
                             const double g0 = m0 >= 0 ? gv[2 * b] * 1e-8 : 0.0;
                             const double g1 = m1 >= 0 ? gv[2 * b + 1] * 1e-8 : 0.0;
-                            *reinterpret_cast<double2*>(gm + band * 128) = make_double2(g0, g1);
+                            *reinterpret_cast<double2*>((m0 == -2 ? sink : gm) + band * 128) = make_double2(g0, g1);
                         }
                     }
                 }

@@ -80,3 +80,27 @@ def test_other_curve_shapes_use_other_kernel_variants(gpu_ctx, shape):
     got = gpu_price(gpu_ctx, curve, swaps, vd, aggregate=True)
     assert_parity(got, oracle_price(curve, swaps, vd), [s._notional for s in swaps])
     assert np.allclose(got["agg_gamma"], got["gamma"].sum(0), rtol=1e-12, atol=1e-12)
+
+
+def test_even_pillar_count_below_32_uses_the_fast_kernel(gpu_ctx):
+    """A 20-pillar curve: [20][20] matrices stored as 16-byte pairs of the flat array, the rest of each
+    1 KB band goes to the sink.  An odd pillar count (tests/test_gpu_parity_batch.py, 5 pillars) stays on the
+    general kernel."""
+    from adrates_amd import _native
+    from adrates_amd.market.curves.curve_tables import build_engine_curve
+    vd = F.README_VALUE_DT
+    tenors = ["1W", "1M", "2M", "3M", "6M", "9M", "1Y", "18M"] + [f"{y}Y" for y in range(2, 11)] + ["15Y", "20Y", "30Y"]
+    px = [5.20 - 0.02 * i for i in range(8)] + [4.7 - 0.04 * i for i in range(12)]
+    curve = F.gbp_model(vd, px=px, tenors=tenors).curves.GBP_OIS_SONIA
+    host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    info = _native.curve_layout_host(host.times, host.dfs, host.jac, host.hess)
+    assert host.n_pillars == 20 and info["packed_ok"] == 1
+    swaps = [F.make_swap(vd, "10Y", 0.045, 1e7), F.make_swap(vd, "87M", 0.04, 1e7, pay=False),
+             F.make_swap(vd, "3M", 0.05, 2e6), F.make_swap(vd, "29Y", 0.039, 5e6),
+             F.make_swap(vd, "14M", 0.05, 3e6, pay=False), F.make_swap(vd, "35Y", 0.04, 1e6),
+             F.make_swap(vd, "4Y", 0.04, 1e6, payment_lag=2)]                 # general kernel, same batch
+    got = gpu_price(gpu_ctx, curve, swaps, vd, aggregate=True)
+    assert got["gamma"].shape == (7, 20, 20) and got["delta"].shape == (7, 20)
+    assert_parity(got, oracle_price(curve, swaps, vd), [s._notional for s in swaps])
+    assert np.allclose(got["agg_gamma"], got["gamma"].sum(0), rtol=1e-12, atol=1e-12)
+    assert np.allclose(got["agg_delta"], got["delta"].sum(0), rtol=1e-12, atol=1e-9)
