@@ -202,3 +202,39 @@ def test_full_size_properties(gpu_ctx, n):
                          batch.flt_sign)
     pv3, de3, ga3, _ = run(doubled)
     assert torch.equal(pv3, 2.0 * pv) and torch.equal(de3, 2.0 * de) and torch.equal(ga3, 2.0 * ga)
+
+
+@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES])
+def test_payment_lag_portfolio_vs_c_oracle(gpu_ctx, interp):
+    """Payment-lag trades (accrual end != payment time: ratio terms) and more-than-32-coupon trades go to the
+    general kernel, the rest of the same batch to the fast kernel; both launches write into the same outputs."""
+    from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
+    from adrates_amd.utils import BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes
+    vd = F.README_VALUE_DT
+    curve = F.gbp_model(vd, interp).curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    rng = np.random.default_rng(12)
+    n = 6000
+    months = rng.integers(1, 361, n)
+    lag = rng.choice([0, 1, 2, 5], size=n, p=[0.2, 0.3, 0.4, 0.1])
+    ffreq = [[FrequencyTypes.ANNUAL, FrequencyTypes.SEMI_ANNUAL, FrequencyTypes.QUARTERLY][i]
+             for i in rng.choice(3, size=n, p=[0.7, 0.2, 0.1])]
+    terms = OISTerms(effective_dt=vd, tenor=[f"{int(m)}M" for m in months], coupon=rng.uniform(0.01, 0.07, n),
+                     notional=np.round(rng.uniform(1e6, 5e7, n), -5), pay_fixed=rng.random(n) < 0.5,
+                     fixed_freq_type=FrequencyTypes.ANNUAL, fixed_dc_type=DayCountTypes.ACT_365F,
+                     floating_index=CurveTypes.GBP_OIS_SONIA, currency=CurrencyTypes.GBP, float_freq_type=ffreq,
+                     float_dc_type=DayCountTypes.ACT_365F, float_spread=np.where(rng.random(n) < 0.3, 0.0015, 0.0),
+                     payment_lag=lag, bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
+    batch = compile_ois_terms(terms, vd)
+    n_flt = np.diff(batch.flt_off)
+    assert (n_flt > 32).any() and ((lag > 0) & (n_flt <= 32)).sum() > 3000 and (lag == 0).sum() > 500
+    got = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), aggregate=True)
+    ref = port.price(interp.value, host.times, host.dfs, host.jac, host.hess, batch)
+    worst = assert_batch_parity(got, ref, batch.notional)
+    assert np.allclose(got["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+    assert np.allclose(got["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
+    assert np.allclose(got["agg_pv"], ref["pv"].sum(), rtol=1e-10, atol=1e-3)
+    # value-only request: same PVs from the small kernels
+    assert np.array_equal(_native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), want_delta=False,
+                                        want_gamma=False)["pv"], got["pv"])
+    print(f"{interp.name}: worst error {worst:.2e}")
