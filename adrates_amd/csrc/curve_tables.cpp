@@ -147,17 +147,22 @@ static bool hub_layout(int Pc, const std::vector<int>& core_pillars, int cpg, Cu
             pq[2 * e] = pq[2 * e + 1] = static_cast<uint8_t>(core_pillars[0]);
         }
     // compact row positions, slot-major, so that the lanes of one slot read (nearly) consecutive addresses
-    t.core_pos.assign(n_core_entries, static_cast<int16_t>(Ec));   // Ec = the row's trailing zero
+    // A padding slot reads the position of the next real entry (the row's trailing zero at the very end): its
+    // accumulator is never output, and an address shared with a neighbouring lane costs no LDS bank conflict,
+    // where a common "zero" position would collide with whichever lane reads the same bank.
+    t.core_pos.assign(n_core_entries, static_cast<int16_t>(Ec));
     t.lcc_pq.assign(2 * static_cast<size_t>(Ec), 0);
     int pos = 0;
-    for (int e = 0; e < n_core_entries; ++e)
+    for (int e = 0; e < n_core_entries; ++e) {
+        t.core_pos[e] = static_cast<int16_t>(pos);                 // pos <= Ec
         if (real[e]) {
-            t.core_pos[e] = static_cast<int16_t>(pos);
             t.lcc_pq[2 * pos] = pq[2 * e];
             t.lcc_pq[2 * pos + 1] = pq[2 * e + 1];
             ++pos;
         }
+    }
     if (pos != Ec) return false;
+    t.core_real.assign(real.begin(), real.end());
     t.ent_pq.assign(pq.begin(), pq.end());
     return true;
 }
@@ -252,7 +257,7 @@ bool build_packed_layout(CurveTables& t) {
     if (t.cpg < t.epg && hub_layout(Pc, core_pillars, t.cpg, t)) {
         // ent_pq / core_pos / lcc_pq now describe the star decomposition; redo entry_of for the core pairs
         for (int e = 0; e < t.cpg * kGroupLanes; ++e) {
-            if (t.core_pos[e] >= Ec) continue;
+            if (!t.core_real[e]) continue;
             const int p = t.ent_pq[2 * e], q = t.ent_pq[2 * e + 1];
             entry_of[std::min(p, q) * kPillarPad + std::max(p, q)] = e;
         }

@@ -66,7 +66,8 @@ struct CurveTables {
     std::vector<double> lcc;               // [Kcore + 1][Ec + 1]  LC on the packed core pairs, then a 0; last row zero
     std::vector<uint8_t> ent_pq;           // [Eu][2]          pillars of packed entry e (hub layout: hub first)
     bool hub = false;                      // core slots of a lane share their first pillar (see hub_layout)
-    std::vector<int16_t> core_pos;         // [32*cpg]         hub layout: position of core entry e in a lcc row (Ec: none)
+    std::vector<int16_t> core_pos;         // [32*cpg]         hub layout: position of core entry e in a lcc row
+    std::vector<char> core_real;           // [32*cpg]         hub layout: entry e is a real pair (not padding)
     std::vector<uint8_t> lcc_pq;           // [Ec][2]          pillars of the pair stored at position pos of a lcc row
     std::vector<int16_t> out_map;          // [32*32]          packed entry feeding gamma[r][c] (32-wide rows), -1 if none
     std::vector<int16_t> store_map;        // [32*32]          the same by flat index r*P + c; -2 beyond P*P
