@@ -104,3 +104,20 @@ def test_even_pillar_count_below_32_uses_the_fast_kernel(gpu_ctx):
     assert_parity(got, oracle_price(curve, swaps, vd), [s._notional for s in swaps])
     assert np.allclose(got["agg_gamma"], got["gamma"].sum(0), rtol=1e-12, atol=1e-12)
     assert np.allclose(got["agg_delta"], got["delta"].sum(0), rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES])
+def test_seasoned_and_expired_trades(gpu_ctx, interp):
+    """Trades that started before the value date: past payments are masked (float: payment time >= 0, fixed:
+    > 0, engine.py:2437, :2695), the running coupon's accrual start lies left of the first knot, and a fully
+    expired trade is worth nothing."""
+    vd = F.README_VALUE_DT
+    curve = F.gbp_model(vd, interp).curves.GBP_OIS_SONIA
+    swaps = [F.make_swap(vd.add_months(-6), "5Y", 0.04, 1e7),
+             F.make_swap(vd.add_months(-18), "3Y", 0.045, 5e6, pay=False, spread=0.001),
+             F.make_swap(vd.add_years(-5), "12Y", 0.03, 2e6, float_freq=FrequencyTypes.SEMI_ANNUAL),
+             F.make_swap(vd.add_months(-30), "10Y", 0.035, 1e6, payment_lag=2),     # general kernel
+             F.make_swap(vd.add_years(-3), "2Y", 0.05, 1e6)]                        # expired
+    got = gpu_price(gpu_ctx, curve, swaps, vd)
+    assert_parity(got, oracle_price(curve, swaps, vd), [s._notional for s in swaps])
+    assert got["pv"][4] == 0.0 and not got["delta"][4].any() and not got["gamma"][4].any()
