@@ -89,11 +89,13 @@ struct adr_trades {
     adr::TradesDev dev{};
     int64_t n_fix_flows = 0, n_flt_flows = 0;
     // Trades with a coupon whose accrual end differs from its payment time (payment lag) need the general
-    // kernel (list_general, null when there are none).  list_fast holds the others sorted by coupon
+    // kernel (list_general, null when there are none), and so do legs of more than kMaxChain * 32 coupons.
+    // list_fast holds the trades of at most 32 coupons per leg sorted by coupon
     // count, so that the trades sharing a wavefront in the fast kernel have similar lengths.
-    int64_t n_fast = 0, n_general = 0;
-    const int32_t* list_fast = nullptr;
+    int64_t n_fast = 0, n_long = 0, n_general = 0;
     const int32_t* list_general = nullptr;
+    adr::TradesDev chained{};        // row table of the longer trades as chains of 32-coupon rows (fast kernel, LONG)
+    int chained_blocks = 0;          // the grid the chains were laid out for
     std::vector<void*> allocations;
 };
 
@@ -503,13 +505,18 @@ int adr_trades_upload(adr_ctx* ctx, int64_t n, const int64_t* fix_off, const int
         return fail(ADR_ERR_INVALID, "adr_trades_upload: null cash-flow array");
 
     std::vector<adr::TradeHeader> hdr(static_cast<size_t>(n));
-    std::vector<int32_t> list_fast, list_general;
+    std::vector<int32_t> list_fast, list_long, list_general;
     if (n > INT32_MAX) return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^31 trades in one batch");
+    constexpr int64_t kMaxChain = 4;     // rows per trade in the chained table: legs of up to 128 coupons
+    auto rows_of = [&](int64_t t) {
+        const int64_t m = std::max(flt_off[t + 1] - flt_off[t], fix_off[t + 1] - fix_off[t]);
+        return std::max<int64_t>(1, (m + adr::kRowSlots - 1) / adr::kRowSlots);
+    };
     for (int64_t t = 0; t < n; ++t) {
-        bool general = flt_off[t + 1] - flt_off[t] > adr::kRowSlots || fix_off[t + 1] - fix_off[t] > adr::kRowSlots;
+        bool general = rows_of(t) > kMaxChain;
         for (int64_t j = flt_off[t]; j < flt_off[t + 1] && !general; ++j)
             general = flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j];       // payment lag: ratio terms
-        (general ? list_general : list_fast).push_back(static_cast<int32_t>(t));
+        (general ? list_general : rows_of(t) > 1 ? list_long : list_fast).push_back(static_cast<int32_t>(t));
     }
     for (int64_t t = 0; t < n; ++t) {
         const int64_t mf = fix_off[t + 1] - fix_off[t], ml = flt_off[t + 1] - flt_off[t];
@@ -557,38 +564,94 @@ int adr_trades_upload(adr_ctx* ctx, int64_t n, const int64_t* fix_off, const int
     tr->dev.list = nullptr;
     tr->dev.n_list = n;
     tr->n_fast = static_cast<int64_t>(list_fast.size());
+    tr->n_long = static_cast<int64_t>(list_long.size());
     tr->n_general = static_cast<int64_t>(list_general.size());
     std::stable_sort(list_fast.begin(), list_fast.end(), [&](int32_t a, int32_t b) {
         return hdr[static_cast<size_t>(a)].n_flt > hdr[static_cast<size_t>(b)].n_flt;
     });
-    tr->list_fast = static_cast<const int32_t*>(put(list_fast.data(), list_fast.size() * sizeof(int32_t)));
     tr->list_general = static_cast<const int32_t*>(put(list_general.data(), list_general.size() * sizeof(int32_t)));
-    {   // row table of the fast kernel (kernels.hpp): sorted rows, 32 zero-padded slots per array
-        const size_t rows = list_fast.size(), S = adr::kRowSlots;
+
+    // Row tables of the fast kernel (kernels.hpp): 32 zero-padded slots per row and array.  `pieces` lists, row
+    // by row, (trade or -1 for an empty row, first coupon of the piece, "the trade continues" flag).
+    struct Piece { int64_t trade; int64_t first; bool more; };
+    auto build_rows = [&](const std::vector<Piece>& pieces, adr::TradesDev& dst) {
+        const size_t rows = pieces.size(), S = adr::kRowSlots;
         std::vector<double> r_tp(rows * S, 0.0), r_ts(rows * S, 0.0), r_al(rows * S, 0.0), r_xtp(rows * S, 0.0),
-            r_xpay(rows * S, 0.0), r_n(rows), r_sp(rows);
-        std::vector<int32_t> r_meta(rows);
+            r_xpay(rows * S, 0.0), r_n(rows, 0.0), r_sp(rows, 0.0);
+        std::vector<int32_t> r_meta(rows, 0), r_trade(rows, -1);
         for (size_t r = 0; r < rows; ++r) {
-            const int64_t t = list_fast[r];
-            const int64_t l0 = flt_off[t], ml = flt_off[t + 1] - l0, f0 = fix_off[t], mf = fix_off[t + 1] - f0;
+            const int64_t t = pieces[r].trade;
+            r_meta[r] = pieces[r].more ? 0x40000 : 0;
+            if (t < 0) continue;
+            const int64_t l0 = flt_off[t] + pieces[r].first, f0 = fix_off[t] + pieces[r].first;
+            const int64_t ml = std::clamp<int64_t>(flt_off[t + 1] - l0, 0, adr::kRowSlots);
+            const int64_t mf = std::clamp<int64_t>(fix_off[t + 1] - f0, 0, adr::kRowSlots);
             for (int64_t j = 0; j < ml; ++j) {
                 r_tp[r * S + j] = flt_tp[l0 + j]; r_ts[r * S + j] = flt_ts[l0 + j]; r_al[r * S + j] = flt_alpha[l0 + j];
             }
             for (int64_t j = 0; j < mf; ++j) { r_xtp[r * S + j] = fix_tp[f0 + j]; r_xpay[r * S + j] = fix_pay[f0 + j]; }
             r_n[r] = notional[t]; r_sp[r] = spread[t];
-            r_meta[r] = static_cast<int32_t>(ml | (mf << 8) | ((flt_sign[t] < 0.0) ? 0x10000 : 0) |
-                                             ((fix_sign[t] < 0.0) ? 0x20000 : 0));
+            r_trade[r] = static_cast<int32_t>(t);
+            r_meta[r] |= static_cast<int32_t>(ml | (mf << 8) | ((flt_sign[t] < 0.0) ? 0x10000 : 0) |
+                                              ((fix_sign[t] < 0.0) ? 0x20000 : 0));
         }
-        tr->dev.n_rows = static_cast<int64_t>(rows);
-        tr->dev.row_tp = static_cast<const double*>(put(r_tp.data(), r_tp.size() * sizeof(double)));
-        tr->dev.row_ts = static_cast<const double*>(put(r_ts.data(), r_ts.size() * sizeof(double)));
-        tr->dev.row_alpha = static_cast<const double*>(put(r_al.data(), r_al.size() * sizeof(double)));
-        tr->dev.row_xtp = static_cast<const double*>(put(r_xtp.data(), r_xtp.size() * sizeof(double)));
-        tr->dev.row_xpay = static_cast<const double*>(put(r_xpay.data(), r_xpay.size() * sizeof(double)));
-        tr->dev.row_notional = static_cast<const double*>(put(r_n.data(), r_n.size() * sizeof(double)));
-        tr->dev.row_spread = static_cast<const double*>(put(r_sp.data(), r_sp.size() * sizeof(double)));
-        tr->dev.row_meta = static_cast<const int32_t*>(put(r_meta.data(), r_meta.size() * sizeof(int32_t)));
-        tr->dev.row_trade = tr->list_fast;
+        dst.n_rows = static_cast<int64_t>(rows);
+        dst.row_tp = static_cast<const double*>(put(r_tp.data(), r_tp.size() * sizeof(double)));
+        dst.row_ts = static_cast<const double*>(put(r_ts.data(), r_ts.size() * sizeof(double)));
+        dst.row_alpha = static_cast<const double*>(put(r_al.data(), r_al.size() * sizeof(double)));
+        dst.row_xtp = static_cast<const double*>(put(r_xtp.data(), r_xtp.size() * sizeof(double)));
+        dst.row_xpay = static_cast<const double*>(put(r_xpay.data(), r_xpay.size() * sizeof(double)));
+        dst.row_notional = static_cast<const double*>(put(r_n.data(), r_n.size() * sizeof(double)));
+        dst.row_spread = static_cast<const double*>(put(r_sp.data(), r_sp.size() * sizeof(double)));
+        dst.row_meta = static_cast<const int32_t*>(put(r_meta.data(), r_meta.size() * sizeof(int32_t)));
+        dst.row_trade = static_cast<const int32_t*>(put(r_trade.data(), r_trade.size() * sizeof(int32_t)));
+    };
+    {   // plain table: one row per trade, sorted by coupon count
+        std::vector<Piece> pieces(list_fast.size());
+        for (size_t r = 0; r < list_fast.size(); ++r) pieces[r] = {list_fast[r], 0, false};
+        tr->dev.rows_chained = 0;
+        build_rows(pieces, tr->dev);
+    }
+    tr->chained = tr->dev;
+    tr->chained.n_rows = 0;
+    if (!list_long.empty()) {
+        // Chained table.  The kernel's wave w walks units w, w + W, w + 2W, ... (W = waves of the launch), so the
+        // rows of a pair of trades (one per group of a wave) go to consecutive "rounds" of one wave column;
+        // pairs are dealt to the columns longest first, always to the shortest column.
+        std::stable_sort(list_long.begin(), list_long.end(), [&](int32_t a, int32_t b) { return rows_of(a) > rows_of(b); });
+        const int G = adr::fast_kernel_groups();
+        const int blocks = std::max(1, ctx->n_cu);
+        const int64_t W = static_cast<int64_t>(blocks) * (adr::kFastThreads / 64);
+        std::vector<std::vector<std::vector<Piece>>> column(static_cast<size_t>(W));   // [wave][round][group]
+        std::vector<int64_t> height(static_cast<size_t>(W), 0);
+        for (size_t i = 0; i < list_long.size(); i += static_cast<size_t>(G)) {
+            const size_t w = static_cast<size_t>(std::min_element(height.begin(), height.end()) - height.begin());
+            const int64_t len = rows_of(list_long[i]);                       // the longest of the pair (sorted)
+            for (int64_t j = 0; j < len; ++j) {
+                std::vector<Piece> unit(static_cast<size_t>(G), Piece{-1, 0, j + 1 < len});
+                for (int g = 0; g < G && i + static_cast<size_t>(g) < list_long.size(); ++g) {
+                    const int64_t t = list_long[i + static_cast<size_t>(g)];
+                    if (j < rows_of(t)) unit[static_cast<size_t>(g)].trade = t;
+                    unit[static_cast<size_t>(g)].first = j * adr::kRowSlots;
+                }
+                // results are written after the chain's last row, by the row's trade index: an empty
+                // padding row of the shorter trade still has to carry that index
+                for (int g = 0; g < G && i + static_cast<size_t>(g) < list_long.size(); ++g)
+                    if (unit[static_cast<size_t>(g)].trade < 0 && j + 1 == len)
+                        unit[static_cast<size_t>(g)] = Piece{list_long[i + static_cast<size_t>(g)], j * adr::kRowSlots, false};
+                column[w].push_back(unit);
+            }
+            height[w] += len;
+        }
+        const int64_t rounds = *std::max_element(height.begin(), height.end());
+        std::vector<Piece> pieces(static_cast<size_t>(rounds * W * G), Piece{-1, 0, false});
+        for (int64_t w = 0; w < W; ++w)
+            for (size_t r = 0; r < column[static_cast<size_t>(w)].size(); ++r)
+                for (int g = 0; g < G; ++g)
+                    pieces[static_cast<size_t>((static_cast<int64_t>(r) * W + w) * G + g)] = column[static_cast<size_t>(w)][r][static_cast<size_t>(g)];
+        tr->chained.rows_chained = 1;
+        tr->chained_blocks = blocks;
+        build_rows(pieces, tr->chained);
     }
     if (e != hipSuccess) { adr_free_trades(tr); return fail_hip(e, "adr_trades_upload: copying trades"); }
     *out = tr;
@@ -622,39 +685,47 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     o.delta = (req_mask & ADR_REQ_DELTA) ? delta_dev : nullptr;
     o.gamma = want_gamma ? gamma_dev : nullptr;
 
-    // One wavefront per trade, grid-stride.  Trades without payment lag go to the fast kernel when the
-    // curve has the packed layout; everything else to the general kernel.
+    // Trades without payment lag go to the fast kernel when the curve has the packed layout (those with more
+    // than 32 coupons per leg as chains of rows, in a launch of their own); everything else to the general kernel.
     const bool use_fast = curve->dev.packed_ok != 0;
-    adr::TradesDev fast = trades->dev, general = trades->dev;
+    adr::TradesDev fast = trades->dev, chained = trades->chained, general = trades->dev;
     if (use_fast) {
-        fast.n_list = trades->n_fast;        // = n_rows
         general.list = trades->list_general; general.n_list = trades->n_general;
     } else {
-        fast.n_list = 0;                     // general walks all n trades through the identity list
+        fast.n_rows = 0; chained.n_rows = 0;   // general walks all n trades through the identity list
     }
-    int blocks_fast = 0, blocks_general = 0;
-    if (fast.n_list > 0) {
+    int blocks_fast = 0, blocks_chained = 0, blocks_general = 0;
+    if (fast.n_rows > 0) {
         const size_t lds = adr::fast_kernel_lds_bytes(curve->dev, want_gamma);
         const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
-        const int64_t units = (fast.n_list + adr::fast_kernel_groups() - 1) / adr::fast_kernel_groups();
+        const int64_t units = (fast.n_rows + adr::fast_kernel_groups() - 1) / adr::fast_kernel_groups();
         const int64_t need = (units + adr::kFastThreads / 64 - 1) / (adr::kFastThreads / 64);
         blocks_fast = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * per_cu));
     }
+    if (chained.n_rows > 0) blocks_chained = trades->chained_blocks;   // the chains are laid out for this grid
     if (general.n_list > 0) {
         const int64_t need = (general.n_list + adr::kGeneralThreads / 64 - 1) / (adr::kGeneralThreads / 64);
         blocks_general = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * 4));
     }
-    if (blocks_fast + blocks_general > ctx->max_blocks) return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
+    if (blocks_fast + blocks_chained + blocks_general > ctx->max_blocks)
+        return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
+    auto partials_at = [&](int first_block) {
+        return agg_dev ? ctx->partials + static_cast<size_t>(first_block) * adr::kAggStride : nullptr;
+    };
     if (blocks_fast > 0) {
-        o.block_partials = agg_dev ? ctx->partials : nullptr;
+        o.block_partials = partials_at(0);
         ADR_HIP(adr::launch_price_fast(curve->dev, fast, o, want_delta, want_gamma, blocks_fast, stream));
     }
+    if (blocks_chained > 0) {
+        o.block_partials = partials_at(blocks_fast);
+        ADR_HIP(adr::launch_price_fast(curve->dev, chained, o, want_delta, want_gamma, blocks_chained, stream));
+    }
     if (blocks_general > 0) {
-        o.block_partials = agg_dev ? ctx->partials + static_cast<size_t>(blocks_fast) * adr::kAggStride : nullptr;
+        o.block_partials = partials_at(blocks_fast + blocks_chained);
         ADR_HIP(adr::launch_price_general(curve->dev, general, o, want_delta, want_gamma, blocks_general, stream));
     }
     if (agg_dev)
-        ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_fast + blocks_general, P, agg_dev, stream));
+        ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_fast + blocks_chained + blocks_general, P, agg_dev, stream));
     return ADR_OK;
 }
 

@@ -50,6 +50,7 @@ struct TradesDev {
     // Fast kernel: the eligible trades (no payment lag, at most kRowSlots coupons per leg) as a table of
     // n_rows rows sorted by coupon count, kRowSlots zero-padded slots per row and array.
     int64_t n_rows;
+    int rows_chained;            // rows are chains of 32-coupon pieces of longer trades (meta bit 18; see the kernel)
     const double* row_tp;        // [n_rows][kRowSlots] float payment times
     const double* row_ts;        //                     accrual start times
     const double* row_alpha;     //                     accrual fractions
@@ -57,7 +58,8 @@ struct TradesDev {
     const double* row_xpay;      //                     fixed payment amounts
     const double* row_notional;  // [n_rows]
     const double* row_spread;    // [n_rows]
-    const int32_t* row_meta;     // [n_rows] n_flt | n_fix << 8 | (float leg pays) << 16 | (fixed leg pays) << 17
+    const int32_t* row_meta;     // [n_rows] n_flt | n_fix << 8 | (float leg pays) << 16 | (fixed leg pays) << 17 |
+                                 //          (the trade continues in the group's next row) << 18
     const int32_t* row_trade;    // [n_rows] index of the trade in the batch (where its results go)
 };
 

@@ -45,6 +45,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "kernels.hpp"
 
@@ -151,7 +152,11 @@ __host__ __device__ constexpr int slot_doubles(bool gamma, int epg, int groups) 
 // (both curve dependent; compile-time so that the loops below have no branches); G: trades per wavefront.
 // CPG_ == EPG_ is the universal variant: it reads a convexity slice for every slot and zeroes the coefficient of
 // the slots that are not core pairs at run time.
-template <bool DELTA, bool GAMMA, bool STORE, int EPG_, int CPG_, int G>
+// LONG: the table holds trades with more than 32 coupons per leg as chains of rows (32 coupons each) that one
+// group walks in consecutive iterations; a row whose meta word has bit 18 set is followed by another row of
+// the same trade, and the results are written after the last one.  (Cutting a leg into rows only forgoes the
+// merge of a start node into the previous payment node at the cut - same nodes, same sums.)
+template <bool DELTA, bool GAMMA, bool STORE, bool LONG, int EPG_, int CPG_, int G>
 __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
     constexpr int L = 64 / G;                          // lanes per trade
     constexpr int PPL = kPillarPad / L;                // pillars per lane: l + L*k
@@ -300,7 +305,14 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     load_unit(unit);
     pin_next();
 
+    // LONG: the accumulators live across the iterations of a chain; otherwise they are per iteration
+    double pv_chain = 0.0, dacc_chain[PPL], acc_chain[EPG];
+    bool fresh = true;                         // LONG: false while a trade's chain of rows is being walked
     for (; unit < n_units; unit += wave_stride) {
+        double pv_unit = 0.0, dacc_unit[PPL], acc_unit[EPG];
+        double& pv = LONG ? pv_chain : pv_unit;
+        double (&dacc)[PPL] = LONG ? dacc_chain : dacc_unit;
+        double (&acc)[EPG] = LONG ? acc_chain : acc_unit;
         // ------------------------------------------------------------------ this group's trade
         const double tp = nx_tp, ts = nx_ts, al = nx_al, xtp = nx_xtp, xpay = nx_xpay;
         const double N = nx_N, spread = nx_spread;
@@ -308,14 +320,18 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
         const bool live = t >= 0;
         const int n_flt = nx_meta & 0xff, n_fix = (nx_meta >> 8) & 0xff;
         const double sl = (nx_meta & 0x10000) ? -1.0 : 1.0, sf = (nx_meta & 0x20000) ? -1.0 : 1.0;
+        // both groups' chains have the same length (the host pads the shorter one with empty rows)
+        const bool more = LONG && (__builtin_amdgcn_readfirstlane(nx_meta) & 0x40000) != 0;
         ADR_STAMP(0);   // waiting for the unit's inputs
         if (!GAMMA) load_unit(unit + wave_stride);   // small kernels have the registers to fetch a whole unit ahead
 
-        double pv = 0.0, dacc[PPL], acc[EPG];
+        if (!LONG || fresh) {
+            pv = 0.0;
 #pragma unroll
-        for (int k = 0; k < PPL; ++k) dacc[k] = 0.0;
+            for (int k = 0; k < PPL; ++k) dacc[k] = 0.0;
 #pragma unroll
-        for (int i = 0; i < EPG; ++i) acc[i] = 0.0;
+            for (int i = 0; i < EPG; ++i) acc[i] = 0.0;
+        }
 
         // ---- fold the coupons into nodes (lane l = coupon l of the group's trade)
         const bool in = live && l < n_flt;
@@ -534,6 +550,14 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             ADR_STAMP(3);   // node consumption
         }
         if (GAMMA && __ballot(carry_row != zero_row)) lc_row_pass(carry_row, carry_w);
+        if (LONG) {
+            fresh = !more;
+            if (more) {                        // the trade continues in this wave's next unit: no results yet
+                if (GAMMA) load_unit(unit + wave_stride);
+                pin_next();
+                continue;
+            }
+        }
 
         // ------------------------------------------------------------------ results
         // pv and delta first: after them nothing refers to the per-lane trade index any more, so the next
@@ -691,27 +715,38 @@ constexpr int kGroups = 2;   // trades per wavefront: the row table has 64 / 2 =
 // group lane, with cpg = epg - 2 (the last two slots hold the fringe pairs) or cpg = epg (universal).
 using KernelFn = void (*)(CurveDev, TradesDev, OutputsDev);
 
-template <int EPG, bool STORE>
+template <int EPG, bool STORE, bool LONG>
 KernelFn gamma_kernel(int cpg) {
-    if (cpg == EPG - 2) return &price_fast_kernel<true, true, STORE, EPG, EPG - 2, kGroups>;
-    return &price_fast_kernel<true, true, STORE, EPG, EPG, kGroups>;
+    if (cpg == EPG - 2) return &price_fast_kernel<true, true, STORE, LONG, EPG, EPG - 2, kGroups>;
+    return &price_fast_kernel<true, true, STORE, LONG, EPG, EPG, kGroups>;
 }
 
-template <bool STORE>
+template <bool STORE, bool LONG>
 KernelFn gamma_kernel_for(const CurveDev& cv) {
     switch (cv.epg) {
-        case 7: return gamma_kernel<7, STORE>(cv.cpg);
-        case 8: return gamma_kernel<8, STORE>(cv.cpg);
-        case 12: return gamma_kernel<12, STORE>(cv.cpg);
-        default: return gamma_kernel<18, STORE>(cv.cpg);
+        case 7: return gamma_kernel<7, STORE, LONG>(cv.cpg);
+        case 8: return gamma_kernel<8, STORE, LONG>(cv.cpg);
+        case 12: return gamma_kernel<12, STORE, LONG>(cv.cpg);
+        default: return gamma_kernel<18, STORE, LONG>(cv.cpg);
     }
 }
 
+template <bool LONG>
 KernelFn pick_kernel(const CurveDev& cv, bool want_delta, bool want_gamma, bool store_gamma) {
     if (!want_gamma)
-        return want_delta ? &price_fast_kernel<true, false, false, 1, 1, kGroups>
-                          : &price_fast_kernel<false, false, false, 1, 1, kGroups>;
-    return store_gamma ? gamma_kernel_for<true>(cv) : gamma_kernel_for<false>(cv);
+        return want_delta ? &price_fast_kernel<true, false, false, LONG, 1, 1, kGroups>
+                          : &price_fast_kernel<false, false, false, LONG, 1, 1, kGroups>;
+    return store_gamma ? gamma_kernel_for<true, LONG>(cv) : gamma_kernel_for<false, LONG>(cv);
+}
+
+template <bool STORE, bool LONG>
+void collect_gamma_kernels(std::vector<const void*>& fns) {
+    for (int universal : {0, 1}) {
+        fns.push_back(reinterpret_cast<const void*>(gamma_kernel<7, STORE, LONG>(universal ? 7 : 5)));
+        fns.push_back(reinterpret_cast<const void*>(gamma_kernel<8, STORE, LONG>(universal ? 8 : 6)));
+        fns.push_back(reinterpret_cast<const void*>(gamma_kernel<12, STORE, LONG>(universal ? 12 : 10)));
+        fns.push_back(reinterpret_cast<const void*>(gamma_kernel<18, STORE, LONG>(universal ? 18 : 16)));
+    }
 }
 
 }  // namespace
@@ -735,8 +770,9 @@ size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
 hipError_t launch_price_fast(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                              bool want_gamma, int n_blocks, hipStream_t stream) {
     const size_t lds = fast_kernel_lds_bytes(cv, want_gamma);
-    hipLaunchKernelGGL(pick_kernel(cv, want_delta, want_gamma, out.gamma != nullptr), dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv,
-                       tr, out);
+    const KernelFn fn = tr.rows_chained ? pick_kernel<true>(cv, want_delta, want_gamma, out.gamma != nullptr)
+                                        : pick_kernel<false>(cv, want_delta, want_gamma, out.gamma != nullptr);
+    hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out);
     return hipGetLastError();
 }
 
@@ -752,18 +788,15 @@ hipError_t set_general_kernel_lds_limit(size_t bytes);
 hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes) {
     hipError_t e = set_general_kernel_lds_limit(general_bytes);
     if (e != hipSuccess) return e;
-    const void* fns[] = {
-        reinterpret_cast<const void*>(gamma_kernel<7, true>(5)), reinterpret_cast<const void*>(gamma_kernel<7, true>(7)),
-        reinterpret_cast<const void*>(gamma_kernel<8, true>(6)), reinterpret_cast<const void*>(gamma_kernel<8, true>(8)),
-        reinterpret_cast<const void*>(gamma_kernel<12, true>(10)), reinterpret_cast<const void*>(gamma_kernel<12, true>(12)),
-        reinterpret_cast<const void*>(gamma_kernel<18, true>(16)), reinterpret_cast<const void*>(gamma_kernel<18, true>(18)),
-        reinterpret_cast<const void*>(gamma_kernel<7, false>(5)), reinterpret_cast<const void*>(gamma_kernel<7, false>(7)),
-        reinterpret_cast<const void*>(gamma_kernel<8, false>(6)), reinterpret_cast<const void*>(gamma_kernel<8, false>(8)),
-        reinterpret_cast<const void*>(gamma_kernel<12, false>(10)), reinterpret_cast<const void*>(gamma_kernel<12, false>(12)),
-        reinterpret_cast<const void*>(gamma_kernel<18, false>(16)), reinterpret_cast<const void*>(gamma_kernel<18, false>(18)),
-        reinterpret_cast<const void*>(&price_fast_kernel<true, false, false, 1, 1, kGroups>),
-        reinterpret_cast<const void*>(&price_fast_kernel<false, false, false, 1, 1, kGroups>),
-    };
+    std::vector<const void*> fns;
+    collect_gamma_kernels<true, false>(fns);
+    collect_gamma_kernels<false, false>(fns);
+    collect_gamma_kernels<true, true>(fns);
+    collect_gamma_kernels<false, true>(fns);
+    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<true, false, false, false, 1, 1, kGroups>));
+    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<false, false, false, false, 1, 1, kGroups>));
+    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<true, false, false, true, 1, 1, kGroups>));
+    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<false, false, false, true, 1, 1, kGroups>));
     for (const void* f : fns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(fast_bytes));
         if (e != hipSuccess) return e;

@@ -238,3 +238,37 @@ def test_payment_lag_portfolio_vs_c_oracle(gpu_ctx, interp):
     assert np.array_equal(_native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), want_delta=False,
                                         want_gamma=False)["pv"], got["pv"])
     print(f"{interp.name}: worst error {worst:.2e}")
+
+
+def test_long_legs_as_row_chains_vs_c_oracle(gpu_ctx):
+    """Legs of 33-128 coupons (quarterly / semi-annual floats, monthly fixed) run in the fast kernel as chains
+    of 32-coupon rows; odd counts leave one group of the last wave idle; 200-coupon legs stay general."""
+    from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
+    from adrates_amd.utils import BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes
+    vd = F.README_VALUE_DT
+    curve = F.readme_model().curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    rng = np.random.default_rng(21)
+    n = 3001
+    months = rng.integers(100, 361, n)
+    lfreq = [[FrequencyTypes.QUARTERLY, FrequencyTypes.SEMI_ANNUAL, FrequencyTypes.MONTHLY][i]
+             for i in rng.choice(3, size=n, p=[0.6, 0.3, 0.1])]
+    ffreq = [[FrequencyTypes.ANNUAL, FrequencyTypes.QUARTERLY][i] for i in rng.choice(2, size=n, p=[0.7, 0.3])]
+    terms = OISTerms(effective_dt=vd, tenor=[f"{int(m)}M" for m in months], coupon=rng.uniform(0.01, 0.07, n),
+                     notional=np.round(rng.uniform(1e6, 5e7, n), -5), pay_fixed=rng.random(n) < 0.5,
+                     fixed_freq_type=ffreq, fixed_dc_type=DayCountTypes.ACT_365F,
+                     floating_index=CurveTypes.GBP_OIS_SONIA, currency=CurrencyTypes.GBP, float_freq_type=lfreq,
+                     float_dc_type=DayCountTypes.ACT_365F, float_spread=np.where(rng.random(n) < 0.3, 0.002, 0.0),
+                     bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
+    batch = compile_ois_terms(terms, vd)
+    n_flt = np.diff(batch.flt_off)
+    assert ((n_flt > 32) & (n_flt <= 128)).sum() > 1500 and (n_flt > 128).any() and (n_flt <= 32).any()
+    got = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), aggregate=True)
+    ref = port.price(4, host.times, host.dfs, host.jac, host.hess, batch)
+    worst = assert_batch_parity(got, ref, batch.notional)
+    assert np.allclose(got["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+    assert np.allclose(got["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
+    assert np.allclose(got["agg_pv"], ref["pv"].sum(), rtol=1e-10, atol=1e-3)
+    only_d = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), want_gamma=False)
+    assert np.array_equal(only_d["delta"], got["delta"]) and np.array_equal(only_d["pv"], got["pv"])
+    print(f"long legs: worst error {worst:.2e}")

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Throughput on trades with more than 32 coupons per leg (quarterly floats, 10-30Y): fast kernel with chained
+rows vs what the general kernel did before (run with ADRATES_HIP_LIB pointing at an older build to compare)."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from adrates_amd import _native
+from adrates_amd.market.curves.curve_tables import build_engine_curve
+from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
+from adrates_amd.utils import BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes
+from tests._fixtures import README_VALUE_DT as vd, gbp_model
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+curve = gbp_model().curves.GBP_OIS_SONIA
+host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+ctx = _native.Context(0)
+dc = _native.DeviceCurve(ctx, 4, host.times, host.dfs, host.jac, host.hess)
+rng = np.random.default_rng(2)
+months = rng.integers(120, 361, n)
+terms = OISTerms(vd, [f"{int(m)}M" for m in months], rng.uniform(0.01, 0.07, n), np.round(rng.uniform(1e6, 5e7, n), -5),
+                 rng.random(n) < 0.5, FrequencyTypes.ANNUAL, DayCountTypes.ACT_365F, CurveTypes.GBP_OIS_SONIA,
+                 CurrencyTypes.GBP, float_freq_type=FrequencyTypes.QUARTERLY, float_dc_type=DayCountTypes.ACT_365F,
+                 bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
+batch = compile_ois_terms(terms, vd)
+dt = _native.DeviceTrades(ctx, batch)
+dev = torch.device("cuda", 0); P = 32
+pv = torch.empty(n, dtype=torch.float64, device=dev); de = torch.empty((n, P), dtype=torch.float64, device=dev)
+ga = torch.empty((n, P, P), dtype=torch.float64, device=dev); ag = torch.empty(1 + P + P * P, dtype=torch.float64, device=dev)
+s = torch.cuda.Stream(dev)
+with torch.cuda.stream(s):
+    for _ in range(2):
+        _native.price_dev(ctx, dc, dt, 7, pv.data_ptr(), de.data_ptr(), ga.data_ptr(), ag.data_ptr(), s.cuda_stream)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(s)
+    for _ in range(5):
+        _native.price_dev(ctx, dc, dt, 7, pv.data_ptr(), de.data_ptr(), ga.data_ptr(), ag.data_ptr(), s.cuda_stream)
+    b.record(s); s.synchronize()
+ms = a.elapsed_time(b) / 5
+print(json.dumps({"trades": n, "mean_float_coupons": float(np.diff(batch.flt_off).mean()), "ms": ms,
+                  "trades_per_s": n / ms * 1e3, "lib": os.environ.get("ADRATES_HIP_LIB", "default")}))
