@@ -11,6 +11,8 @@ python bench.py --kind ongrid --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}
 python bench.py --interp FLAT_FWD_RATES --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_flatfwd.json 2>/dev/null || exit 1
 python bench.py --trades 100000 --requests value,delta --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_config2_delta_100k.json 2>/dev/null || exit 1
 python tools/ablate.py > gpurun_out/ablate_$TAG.log 2>&1 || exit 1
+python tools/bench_long_legs.py > gpurun_out/bench_${TAG}_long_legs.json 2>/dev/null || exit 1
+python tools/bench_curve_build.py > gpurun_out/bench_${TAG}_curve_build.json 2>/dev/null || exit 1
 bash tools/profile.sh $TAG || exit 1
 bash tools/pmc.sh && python tools/pmc_summary.py > gpurun_out/pmc_$TAG.txt
 echo refresh-done
