@@ -33,13 +33,15 @@
 // (omega, the two weights, the two knot classes) as a 32-byte record in the wave's LDS slot and the groups
 // walk their nodes in lockstep: node n is two broadcast b128 reads issued one node ahead, lane l builds v
 // for pillar l, v goes to the group's LDS buffer, and every lane updates its packed gamma entries l + L*i -
-// the rank-1 term omega*v[p]*v[q] from two LDS reads, the convexity term from a contiguous slice of the
-// left knot's LC row (the right knot's weight is carried to the next node, whose left knot it usually is).
+// the rank-1 term omega*v[p]*v[q] from LDS reads of v (hub layout: the core entries of a lane share p, read
+// once), the convexity term from the left knot's LC row (the right knot's weight is carried to the next node,
+// whose left knot it usually is).
 // The short-end knots' one to three convexity numbers are added by the lanes that own those entries.  Each
-// trade's packed ladder is then expanded through the wave's LDS slot to the symmetric 32x32 matrix and written
-// as 1 KB-contiguous stores.  No atomics; the aggregate is a fixed-order reduction.
+// trade's packed ladder is then expanded through the wave's LDS slot to the symmetric P x P matrix and written
+// as 1 KB-contiguous stores.  No atomics; the aggregate is a fixed-order reduction.  Legs of 33-128 coupons are
+// walked as chains of rows (LONG variants).
 //
-// The kernel is bound by the CU's LDS pipe (about 28 LDS instructions per node pair) at 3 waves/SIMD - the
+// The kernel is bound by the CU's LDS pipe (about 20 LDS instructions per node pair) at 3 waves/SIMD - the
 // tables fill the 160 KB of LDS, so there is one 768-thread block per CU; see DESIGN.md section 7.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
