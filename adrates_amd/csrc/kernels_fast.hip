@@ -145,7 +145,7 @@ __device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
 __host__ __device__ constexpr int slot_doubles(bool gamma, int epg, int groups) {
     const int epl = (epg * (64 / groups) + 63) / 64;   // 64-entry slices of the packed ladder
     const int hand_off = 64 * 4 + (gamma ? groups * kPillarPad : 0);
-    const int staging = gamma ? 64 * epl : 0;
+    const int staging = gamma ? 64 * epl + 2 : 0;      // + the zero entry structural zeros are read from
     return hand_off > staging ? hand_off : staging;
 }
 
@@ -251,13 +251,19 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 
     // Output map of this lane: it writes elements 2*lane, 2*lane + 1 of each 128-element band of a trade's
     // flat [P][P] matrix (4 rows when P = 32), so every store instruction covers 1 KB of consecutive addresses;
-    // two int16 packed entry indices per band, -1 where the matrix is structurally zero, -2 beyond P*P (P is
-    // even, so a pair never straddles the end; such pairs are stored to the sink).
+    // two packed entry indices per band; structural zeros point at a staging entry that holds 0.0, pairs beyond
+    // P*P (P is even, so a pair never straddles the end) are flagged and stored to the sink.
+    constexpr int kZeroEntry = 64 * EPL;          // staging index that always holds 0.0
     int mm[GAMMA ? 8 : 1];
+    int beyond = 0;                               // bit b: band b's pair lies beyond the P x P matrix
     if (GAMMA) {
 #pragma unroll
-        for (int band = 0; band < 8; ++band)
-            mm[band] = *reinterpret_cast<const int*>(cv.store_map + 2 * lane + band * 128);
+        for (int band = 0; band < 8; ++band) {
+            const int raw = *reinterpret_cast<const int*>(cv.store_map + 2 * lane + band * 128);
+            const int m0 = static_cast<int16_t>(raw & 0xffff), m1 = raw >> 16;
+            if (m0 == -2) beyond |= 1 << band;
+            mm[band] = (m0 < 0 ? kZeroEntry : m0) | ((m1 < 0 ? kZeroEntry : m1) << 16);
+        }
     }
 
     // running portfolio sums of this wave: pv per group (lane l == 0), delta per group lane/pillar,
@@ -594,8 +600,9 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                 __builtin_amdgcn_wave_barrier();
                 if (g == gg) {
 #pragma unroll
-                    for (int i = 0; i < EPG; ++i) slot[l + L * i] = acc[i];
+                    for (int i = 0; i < EPG; ++i) slot[l + L * i] = acc[i] * 1e-8;     // per bp^2
                 }
+                if (lane == 0) slot[kZeroEntry] = 0.0;
                 wave_lds_sync();
                 // LDS reads of a trade in two batches: the running-total slice + bands 0-3, then bands 4-7
                 double* gm = (tt >= 0 ? out.gamma + static_cast<int64_t>(tt) * (P * P) : out.dump) + 2 * lane;
@@ -612,10 +619,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                     for (int b = 0; b < 4; ++b) mbs[b] = mm[4 * half + b];
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        const int mb = mbs[b];
-                        const int m0 = static_cast<int16_t>(mb & 0xffff), m1 = mb >> 16;
-                        gv[2 * b] = slot[m0 < 0 ? 0 : m0];
-                        gv[2 * b + 1] = slot[m1 < 0 ? 0 : m1];
+                        gv[2 * b] = slot[mbs[b] & 0xffff];
+                        gv[2 * b + 1] = slot[mbs[b] >> 16];
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (half == 0) {
@@ -626,11 +631,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 #pragma unroll
                         for (int b = 0; b < 4; ++b) {
                             const int band = 4 * half + b;
-                            const int mb = mbs[b];
-                            const int m0 = static_cast<int16_t>(mb & 0xffff), m1 = mb >> 16;
-                            const double g0 = m0 >= 0 ? gv[2 * b] * 1e-8 : 0.0;
-                            const double g1 = m1 >= 0 ? gv[2 * b + 1] * 1e-8 : 0.0;
-                            *reinterpret_cast<double2*>((m0 == -2 ? sink : gm) + band * 128) = make_double2(g0, g1);
+                            *reinterpret_cast<double2*>(((beyond >> band) & 1 ? sink : gm) + band * 128) =
+                                make_double2(gv[2 * b], gv[2 * b + 1]);
                         }
                     }
                 }
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 #pragma unroll
             for (int e = 0; e < kGammaPerLane; ++e) {
                 const int m = cv.out_map[(4 * bi + (e >> 2)) * kPillarPad + 4 * bj + (e & 3)];
-                blk_gamma[e] = m >= 0 ? slot[m] * 1e-8 : 0.0;
+                blk_gamma[e] = m >= 0 ? slot[m] : 0.0;            // already per bp^2
             }
         }
         // delta and pv: sum the groups (lanes l, l + L, ... hold the same pillar)
