@@ -378,11 +378,11 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
         auto lc_row_pass = [&](int row, double w) {
             double lr[CPG > 0 ? CPG : 1];
             if (HUB) {
-                const double* src = c.lcc + row * c.ec_stride;
+                const double* src = c.lcc + __mul24(row, c.ec_stride);
 #pragma unroll
                 for (int i = 0; i < CPG; ++i) lr[i] = src[pos[i]];
             } else {
-                const double* src = c.lcc + row * c.ec_stride + l;
+                const double* src = c.lcc + __mul24(row, c.ec_stride) + l;
 #pragma unroll
                 for (int i = 0; i < CPG; ++i) lr[i] = src[L * i];
             }
@@ -455,8 +455,9 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                 // v for this lane's pillars: core rows (the zero row for anything else) ...
                 double v[PPL];
                 {
-                    const double* lja = c.ljc + ra * c.pc_pad;
-                    const double* ljb = c.ljc + rb * c.pc_pad;
+                    // (24-bit multiplies: full rate, v_mul_lo_u32 is quarter rate)
+                    const double* lja = c.ljc + __mul24(ra, c.pc_pad);
+                    const double* ljb = c.ljc + __mul24(rb, c.pc_pad);
 #pragma unroll
                     for (int k = 0; k < PPL; ++k) v[k] = fma(wb, ljb[col[k]], wa * lja[col[k]]);
                 }
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                         lc_row_pass(flush ? carry_row : zero_row, flush ? carry_w : 0.0);
                         if (flush) { carry_row = zero_row; carry_w = 0.0; }
                     }
-                    const double* rowa = c.lcc + ra * c.ec_stride + (HUB ? 0 : l);
+                    const double* rowa = c.lcc + __mul24(ra, c.ec_stride) + (HUB ? 0 : l);
                     const double coa = om * wa + (carry_row == ra ? carry_w : 0.0), cob = om * wb;
                     carry_row = rb; carry_w = cob;
                     // All operands of a batch of entries are fetched before any of them is used: the
