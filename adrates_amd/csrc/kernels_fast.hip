@@ -418,15 +418,15 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             const bool greeks = qon && !(cls_a == -2 && cls_b == -2);
             if (!greeks) { omega = 0.0; cls_a = -2; cls_b = -2; }
             // ---- consume: the groups walk their nodes in lockstep.  Every lane leaves its node as a 32-byte
-            // record {omega, ba, bb, packed knot classes} in LDS; node n of a group is then two broadcast
+            // record {omega, ba, bb, the two knot classes} in LDS; node n of a group is then two broadcast
             // b128 reads (instead of eight ds_bpermute), issued one node ahead so that the round trip hides
             // behind the previous node's work.
-            const int classes = (cls_a & 0xffff) | (cls_b << 16);
             __builtin_amdgcn_wave_barrier();
             {
                 double2* wp = reinterpret_cast<double2*>(rec + lane * 4);
                 wp[0] = make_double2(omega, ba);
-                wp[1] = make_double2(bb, __hiloint2double(0, classes));
+                wp[1] = make_double2(bb, __hiloint2double(cls_b, cls_a));   // both words are read back: a dead
+                // half would be reused as a scratch register while the prefetch of the record is still in flight
             }
             wave_lds_sync();
             unsigned long long any_row = __ballot(greeks);
@@ -443,8 +443,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                 const int n_next = has_next ? __builtin_ctzll(any_row) : n;   // nothing left: read n again
                 any_row &= any_row - 1;
                 const double om = nx0.x, wa = nx0.y, wb = nx1.x;
-                const int nx_classes = __double2loint(nx1.y);
-                const int ca = static_cast<int16_t>(nx_classes & 0xffff), cb = nx_classes >> 16;
+                const int ca = __double2loint(nx1.y), cb = __double2hiint(nx1.y);
                 nx0 = rec_g[2 * n_next]; nx1 = rec_g[2 * n_next + 1];
                 n = n_next;
                 __builtin_amdgcn_sched_barrier(0);
