@@ -60,6 +60,19 @@ constexpr int kWavesPerBlock = kBlockThreads / 64;
 
 __device__ __forceinline__ double shfl_d(double x, int src) { return __shfl(x, src, 64); }
 
+// Neighbour lanes through DPP (VALU, not the LDS pipe): lane i receives lane i + 1 / i - 1 of the wavefront;
+// the last / first lane keeps its own value.
+__device__ __forceinline__ double from_next_lane(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), 0x130, 0xf, 0xf, false);   // wave_shl:1
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_prev_lane(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), 0x138, 0xf, 0xf, false);   // wave_shr:1
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // Same-wave LDS hand-off.  The DS instructions of one wavefront are executed in issue order, so data written
 // by one lane is visible to a later read of another lane of the same wave without waiting for the write to
 // retire; all that is needed is that the compiler keeps the program order of the accesses (it does for
@@ -343,8 +356,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 
         // ---- fold the coupons into nodes (lane l = coupon l of the group's trade)
         const bool in = live && l < n_flt;
-        const int up1 = lane < 63 ? lane + 1 : lane, dn1 = lane > 0 ? lane - 1 : lane;
-        const double ntp = shfl_d(tp, up1), nts = shfl_d(ts, up1), nal = shfl_d(al, up1), ptp = shfl_d(tp, dn1);
+        const double ntp = from_next_lane(tp), nts = from_next_lane(ts), nal = from_next_lane(al);
+        const double ptp = from_prev_lane(tp);
         const bool valid = in && tp >= 0.0;
         const bool accrues = al > 0.0;            // te == tp for every coupon of a fast-path trade
         // payment node P_l: -N(1 - spread*a) D(tp)   (N*spread*a*D(tp) when nothing accrues)
