@@ -244,6 +244,11 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     track(upload(t.inv_x, &d_invx), d_invx);
     track(upload(t.lj, &d_lj), d_lj);
     track(upload(t.lc_lanes, &d_lc), d_lc);
+    unsigned long long* d_lcmask = nullptr;
+    {
+        std::vector<unsigned long long> m(t.lc_block_mask.begin(), t.lc_block_mask.end());
+        track(upload(m, &d_lcmask), d_lcmask);
+    }
     track(upload(first16, &d_first), d_first);
     track(upload(comp16, &d_comp), d_comp);
     if (t.packed_ok) {
@@ -259,7 +264,7 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     }
     if (e != hipSuccess) { adr_free_curve(c); return fail_hip(e, "adr_curve_upload: copying tables"); }
     c->dev.K = t.K; c->dev.Kc = t.Kc; c->dev.P = t.P; c->dev.method = interp_method;
-    c->dev.x = d_x; c->dev.log_df = d_log; c->dev.inv_x = d_invx; c->dev.lj = d_lj; c->dev.lc_lanes = d_lc;
+    c->dev.x = d_x; c->dev.log_df = d_log; c->dev.inv_x = d_invx; c->dev.lj = d_lj; c->dev.lc_lanes = d_lc; c->dev.lc_block_mask = d_lcmask;
     c->dev.first_of = d_first; c->dev.compact_of = d_comp;
     // the fast kernels store the [P][P] matrices as 16-byte pairs of the flat array: P must be even
     c->dev.packed_ok = (t.packed_ok && t.P % 2 == 0) ? 1 : 0;
@@ -334,6 +339,11 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     track(upload(pil_v, &d_pil), d_pil);
     track(upload(prev_v, &d_prev), d_prev);
     track(upload(t.knot_index, &d_kidx), d_kidx);
+    unsigned long long* d_lcmask = nullptr;
+    {
+        std::vector<unsigned long long> m(t.lc_block_mask.begin(), t.lc_block_mask.end());
+        track(upload(m, &d_lcmask), d_lcmask);
+    }
     track(upload(t.x, &d_x), d_x);
     track(upload(t.inv_x, &d_invx), d_invx);
     track(upload(first16, &d_first), d_first);
@@ -358,7 +368,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
 
     adr::CurveDev& c = plan->shared;
     c.K = t.K; c.Kc = t.Kc; c.P = t.P; c.method = interp_method;
-    c.x = d_x; c.inv_x = d_invx; c.first_of = d_first; c.compact_of = d_comp;
+    c.x = d_x; c.inv_x = d_invx; c.first_of = d_first; c.compact_of = d_comp; c.lc_block_mask = d_lcmask;
     c.packed_ok = d.packed_ok;
     c.Pc = t.Pc; c.pc_pad = t.pc_pad; c.Ec = t.Ec; c.Eu = t.Eu; c.epg = t.epg; c.cpg = t.cpg; c.hub = t.hub ? 1 : 0; c.Kcore = t.Kcore; c.n_mini = t.n_mini;
     c.knot_class = d_class; c.pillar_to_core = d_p2c; c.out_map = d_omap; c.store_map = d_smap; c.ent_pq = d_pq; c.core_pos = d_cpos;

@@ -45,6 +45,7 @@ std::string build_curve_tables(int K, int P, const double* times, const double* 
     if (out.has_hess) {
         out.lc.assign(static_cast<size_t>(Kc) * P * P, 0.0);
         out.lc_lanes.assign(static_cast<size_t>(Kc) * 64 * kGammaPerLane, 0.0);
+        out.lc_block_mask.assign(Kc, 0);
     }
 
     for (int c = 0; c < Kc; ++c) {
@@ -60,11 +61,15 @@ std::string build_curve_tables(int K, int P, const double* times, const double* 
         for (int p = 0; p < P; ++p)
             for (int q = 0; q < P; ++q) lck[p * P + q] = hk[p * P + q] / d - ljrow[p] * ljrow[q];
         double* lanes = &out.lc_lanes[static_cast<size_t>(c) * 64 * kGammaPerLane];
+        uint64_t mask = 0;
         for (int lane = 0; lane < 64; ++lane)
             for (int e = 0; e < kGammaPerLane; ++e) {
                 const int r = gamma_row(lane, e), q = gamma_col(lane, e);
-                lanes[lane * kGammaPerLane + e] = (r < P && q < P) ? lck[r * P + q] : 0.0;
+                const double x = (r < P && q < P) ? lck[r * P + q] : 0.0;
+                lanes[lane * kGammaPerLane + e] = x;
+                if (x != 0.0) mask |= 1ull << lane;
             }
+        out.lc_block_mask[c] = mask;
     }
     out.packed_ok = build_packed_layout(out);
     return std::string();

@@ -50,6 +50,7 @@ struct CurveTables {
     std::vector<double> lj;            // [Kc][kPillarPad], zero padded
     std::vector<double> lc;            // [Kc][P][P] row-major (plain layout, for checking)
     std::vector<double> lc_lanes;      // [Kc][64][16] lane-major layout read by the general gamma kernel
+    std::vector<uint64_t> lc_block_mask;  // [Kc] bit l: lane l's 4x4 block of LC_k has a non-zero entry
 
     // ---- packed layout of the fast kernels (see build_packed_layout) ----
     int Pc = 0;                        // pillars in the core set

@@ -74,6 +74,7 @@ struct CurveDev {
     // general kernel: dense 32-wide tables
     const double* lj;            // [Kc][32]
     const double* lc_lanes;      // [Kc][64][16], null without gamma
+    const unsigned long long* lc_block_mask;  // [Kc] lanes whose 4x4 block of LC_k is not structurally zero
     // fast kernels: packed layout (curve_tables.hpp), valid when packed_ok
     int packed_ok, Pc, pc_pad, Ec, Eu, epg, cpg, hub, Kcore, n_mini;
     const double* ljc;           // [Kcore][pc_pad]

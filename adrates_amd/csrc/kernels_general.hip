@@ -138,6 +138,7 @@ struct Ladders {
 template <int NK, bool DELTA, bool GAMMA>
 __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k)[NK], const double (&b)[NK],
                                           double omega, const CurveLds& c, const double* __restrict__ lc_lanes,
+                                          const unsigned long long* __restrict__ lc_block_mask,
                                           double* vbuf, int lane, Ladders<GAMMA>& acc) {
     const int p = lane & 31;
     const int bi = lane >> 3, bj = lane & 7;
@@ -171,7 +172,9 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
 #pragma unroll
             for (int i = 0; i < NK; ++i) {
                 const double coef = om * bb[i];
-                if (coef != 0.0) {
+                // most 4x4 blocks of LC_k are structurally zero (a knot depends on its bootstrap chain's
+                // pillars only): the lanes holding such a block skip the tile read
+                if (coef != 0.0 && ((lc_block_mask[kk[i]] >> lane) & 1ull)) {
                     const double2* tile = reinterpret_cast<const double2*>(
                         lc_lanes + (static_cast<size_t>(kk[i]) * 64 + lane) * kGammaPerLane);
 #pragma unroll
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
     double* vbuf = s_vbuf + wave * kPillarPad;
     const int P = cv.P;
     const double* __restrict__ lc_lanes = cv.lc_lanes;
+    const unsigned long long* __restrict__ lc_block_mask = cv.lc_block_mask;
 
     Ladders<GAMMA> total;   // this wave's share of the portfolio aggregate
     total.clear();
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
                     omega = a_pay * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
                     acc.pv += omega;
                 }
-                add_nodes<2, DELTA, GAMMA>(__ballot(on), k, b, omega, c, lc_lanes, vbuf, lane, acc);
+                add_nodes<2, DELTA, GAMMA>(__ballot(on), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
             }
             {   // unmerged start nodes
                 int k[2]; double b[2]; double omega = 0.0;
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
                     omega = sl * N * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
                     acc.pv += omega;
                 }
-                add_nodes<2, DELTA, GAMMA>(__ballot(own_start), k, b, omega, c, lc_lanes, vbuf, lane, acc);
+                add_nodes<2, DELTA, GAMMA>(__ballot(own_start), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
             }
             const bool own_ratio = valid && ratio;
             if (__ballot(own_ratio)) {   // payment lag: N D(ts) D(tp) / D(te) keeps all three lookups
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
                     omega = sl * N * exp(l);
                     acc.pv += omega;
                 }
-                add_nodes<6, DELTA, GAMMA>(__ballot(own_ratio), k, b, omega, c, lc_lanes, vbuf, lane, acc);
+                add_nodes<6, DELTA, GAMMA>(__ballot(own_ratio), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
             }
         }
         // ---------------------------------------------------------------- fixed coupons not merged above
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
                 omega = a * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
                 acc.pv += omega;
             }
-            add_nodes<2, DELTA, GAMMA>(__ballot(on), k, b, omega, c, lc_lanes, vbuf, lane, acc);
+            add_nodes<2, DELTA, GAMMA>(__ballot(on), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
         }
 
         // ---------------------------------------------------------------- results of this trade

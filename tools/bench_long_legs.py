@@ -10,15 +10,17 @@ from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
 from adrates_amd.utils import BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes
 from tests._fixtures import README_VALUE_DT as vd, gbp_model
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+mode = sys.argv[2] if len(sys.argv) > 2 else "long"       # "long": quarterly 10-30Y; "lag": annual, 2-day payment lag
 curve = gbp_model().curves.GBP_OIS_SONIA
 host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
 ctx = _native.Context(0)
 dc = _native.DeviceCurve(ctx, 4, host.times, host.dfs, host.jac, host.hess)
 rng = np.random.default_rng(2)
-months = rng.integers(120, 361, n)
+months = rng.integers(120, 361, n) if mode == "long" else rng.integers(1, 361, n)
 terms = OISTerms(vd, [f"{int(m)}M" for m in months], rng.uniform(0.01, 0.07, n), np.round(rng.uniform(1e6, 5e7, n), -5),
                  rng.random(n) < 0.5, FrequencyTypes.ANNUAL, DayCountTypes.ACT_365F, CurveTypes.GBP_OIS_SONIA,
-                 CurrencyTypes.GBP, float_freq_type=FrequencyTypes.QUARTERLY, float_dc_type=DayCountTypes.ACT_365F,
+                 CurrencyTypes.GBP, float_freq_type=FrequencyTypes.QUARTERLY if mode == "long" else FrequencyTypes.ANNUAL,
+                 float_dc_type=DayCountTypes.ACT_365F, payment_lag=0 if mode == "long" else 2,
                  bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
 batch = compile_ois_terms(terms, vd)
 dt = _native.DeviceTrades(ctx, batch)
@@ -35,5 +37,5 @@ with torch.cuda.stream(s):
         _native.price_dev(ctx, dc, dt, 7, pv.data_ptr(), de.data_ptr(), ga.data_ptr(), ag.data_ptr(), s.cuda_stream)
     b.record(s); s.synchronize()
 ms = a.elapsed_time(b) / 5
-print(json.dumps({"trades": n, "mean_float_coupons": float(np.diff(batch.flt_off).mean()), "ms": ms,
+print(json.dumps({"mode": mode, "trades": n, "mean_float_coupons": float(np.diff(batch.flt_off).mean()), "ms": ms,
                   "trades_per_s": n / ms * 1e3, "lib": os.environ.get("ADRATES_HIP_LIB", "default")}))
