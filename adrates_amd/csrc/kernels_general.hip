@@ -309,6 +309,13 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
                     for (int i = 0; i < 6; ++i) l = fma(b[i], c.log_df[k[i]], l);
                     omega = sl * N * exp(l);
                     acc.pv += omega;
+                    // te and tp are a few days apart and usually bracketed by the same knots: fold the te weights
+                    // into the tp entries (zero-weight entries are skipped downstream)
+#pragma unroll
+                    for (int i = 2; i < 4; ++i)
+#pragma unroll
+                        for (int jx = 4; jx < 6; ++jx)
+                            if (b[i] != 0.0 && k[i] == k[jx]) { b[jx] += b[i]; b[i] = 0.0; }
                 }
                 add_nodes<6, DELTA, GAMMA>(__ballot(own_ratio), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
             }
