@@ -10,7 +10,8 @@ from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
 from adrates_amd.utils import BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes
 from tests._fixtures import README_VALUE_DT as vd, gbp_model
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
-mode = sys.argv[2] if len(sys.argv) > 2 else "long"       # "long": quarterly 10-30Y; "lag": annual, 2-day payment lag
+mode = sys.argv[2] if len(sys.argv) > 2 else "long"
+mask = int(sys.argv[3]) if len(sys.argv) > 3 else 7       # 1 value, 3 value+delta, 7 value+delta+gamma       # "long": quarterly 10-30Y; "lag": annual, 2-day payment lag
 curve = gbp_model().curves.GBP_OIS_SONIA
 host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
 ctx = _native.Context(0)
@@ -30,12 +31,12 @@ ga = torch.empty((n, P, P), dtype=torch.float64, device=dev); ag = torch.empty(1
 s = torch.cuda.Stream(dev)
 with torch.cuda.stream(s):
     for _ in range(2):
-        _native.price_dev(ctx, dc, dt, 7, pv.data_ptr(), de.data_ptr(), ga.data_ptr(), ag.data_ptr(), s.cuda_stream)
+        _native.price_dev(ctx, dc, dt, mask, pv.data_ptr(), de.data_ptr(), ga.data_ptr(), ag.data_ptr(), s.cuda_stream)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(s)
     for _ in range(5):
-        _native.price_dev(ctx, dc, dt, 7, pv.data_ptr(), de.data_ptr(), ga.data_ptr(), ag.data_ptr(), s.cuda_stream)
+        _native.price_dev(ctx, dc, dt, mask, pv.data_ptr(), de.data_ptr(), ga.data_ptr(), ag.data_ptr(), s.cuda_stream)
     b.record(s); s.synchronize()
 ms = a.elapsed_time(b) / 5
-print(json.dumps({"mode": mode, "trades": n, "mean_float_coupons": float(np.diff(batch.flt_off).mean()), "ms": ms,
+print(json.dumps({"mode": mode, "mask": mask, "trades": n, "mean_float_coupons": float(np.diff(batch.flt_off).mean()), "ms": ms,
                   "trades_per_s": n / ms * 1e3, "lib": os.environ.get("ADRATES_HIP_LIB", "default")}))
