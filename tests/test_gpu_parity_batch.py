@@ -272,3 +272,56 @@ def test_long_legs_as_row_chains_vs_c_oracle(gpu_ctx):
     only_d = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), want_gamma=False)
     assert np.array_equal(only_d["delta"], got["delta"]) and np.array_equal(only_d["pv"], got["pv"])
     print(f"long legs: worst error {worst:.2e}")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_curves_and_portfolios_vs_c_oracle(gpu_ctx, seed):
+    """Random quote sets on the README tenors (flat, steep, inverted, humped, sub-1% and 8% levels), both
+    interpolation schemes, mixed portfolios: frequencies, spreads, payment lags, seasoned and forward-starting
+    trades, pay and receive.  The device curve builder prices the same portfolio off the same quotes."""
+    from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
+    from adrates_amd.utils import BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes
+    rng = np.random.default_rng(100 + seed)
+    vd = F.README_VALUE_DT
+    base = F.readme_model()._curve_params_dict["GBP_OIS_SONIA"]
+    tenors = base["tenor_list"]
+    t_years = np.linspace(0.0, 1.0, len(tenors))
+    level = rng.uniform(0.6, 8.0)
+    slope = rng.uniform(-0.4, 0.6) * level
+    hump = rng.uniform(-0.2, 0.2) * level
+    px = np.maximum(level + slope * t_years + hump * np.sin(np.pi * t_years) + rng.normal(0, 0.01, len(tenors)), 0.05)
+    interp = InterpTypes.LINEAR_ZERO_RATES if seed % 2 else InterpTypes.FLAT_FWD_RATES
+    model = F.gbp_model(vd, interp, px=list(px), tenors=tenors)
+    curve = model.curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+
+    n = 2500
+    starts = [vd, vd.add_months(-7), vd.add_years(-2), vd.add_months(5), vd.add_weekdays(2)]
+    eff = [starts[i] for i in rng.choice(5, size=n, p=[0.5, 0.15, 0.1, 0.15, 0.1])]
+    months = rng.integers(1, 361, n)
+    lfreq = [[FrequencyTypes.ANNUAL, FrequencyTypes.SEMI_ANNUAL, FrequencyTypes.QUARTERLY][i]
+             for i in rng.choice(3, size=n, p=[0.6, 0.25, 0.15])]
+    ffreq = [[FrequencyTypes.ANNUAL, FrequencyTypes.SEMI_ANNUAL][i] for i in rng.choice(2, size=n, p=[0.8, 0.2])]
+    terms = OISTerms(effective_dt=eff, tenor=[f"{int(m)}M" for m in months], coupon=rng.uniform(0.0, 0.09, n),
+                     notional=np.round(rng.uniform(1e5, 9e7, n), -4), pay_fixed=rng.random(n) < 0.5,
+                     fixed_freq_type=ffreq, fixed_dc_type=DayCountTypes.ACT_365F,
+                     floating_index=CurveTypes.GBP_OIS_SONIA, currency=CurrencyTypes.GBP, float_freq_type=lfreq,
+                     float_dc_type=[[DayCountTypes.ACT_365F, DayCountTypes.ACT_360][i] for i in rng.integers(0, 2, n)],
+                     float_spread=np.where(rng.random(n) < 0.3, rng.uniform(-0.002, 0.004, n), 0.0),
+                     payment_lag=rng.choice([0, 0, 0, 1, 2], size=n), bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
+    batch = compile_ois_terms(terms, vd)
+    got = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), aggregate=True)
+    ref = port.price(interp.value, host.times, host.dfs, host.jac, host.hess, batch)
+    worst = assert_batch_parity(got, ref, batch.notional)
+    assert np.allclose(got["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+    assert np.all(np.isfinite(got["gamma"])) and np.all(np.isfinite(got["delta"]))
+
+    # the same quotes through the device curve builder: identical tables, hence (almost) identical prices
+    plan = _native.CurvePlan(gpu_ctx, interp.value, host)
+    cset = plan.build(np.array([curve.swap_rates]))
+    again = _native.price(gpu_ctx, cset[0], _native.DeviceTrades(gpu_ctx, batch))
+    for k in ("pv", "delta", "gamma"):
+        scale = np.maximum(np.abs(got[k]).max(), 1e-12)
+        assert np.max(np.abs(again[k] - got[k])) <= 1e-12 * scale
+    cset.close(); plan.close()
+    print(f"seed {seed} ({interp.name}, level {level:.2f}%): worst error {worst:.2e}")
