@@ -156,11 +156,16 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
         if (DELTA) acc.delta = fma(om, v, acc.delta);
         if (GAMMA) {
             // hand v[0..31] to every lane through the wave's LDS slot (same-wave LDS ops are ordered)
+            // (the DS instructions of one wavefront execute in issue order: a compiler barrier is all the
+            // hand-off needs, no wait for the write to retire)
             __builtin_amdgcn_wave_barrier();
             if (lane < 32) vbuf[lane] = v;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            asm volatile("" ::: "memory");
+            // gamma is symmetric: only the lanes holding a block on or above the diagonal accumulate (and read
+            // LC tiles); the mirror blocks are written from their registers at output time
+            if (bi > bj) continue;
             double vr[4], vc[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { vr[i] = om * vbuf[4 * bi + i]; vc[i] = vbuf[4 * bj + i]; }
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
                     gv[jx] = acc.gamma[i * 4 + jx] * 1e-8;
                     total.gamma[i * 4 + jx] += gv[jx];
                 }
-                if (g && r < P) {
+                if (g && r < P && bi <= bj) {
                     if (P == kPillarPad) {
                         double2* dst = reinterpret_cast<double2*>(g + r * kPillarPad + 4 * bj);
                         dst[0] = make_double2(gv[0], gv[1]);
@@ -375,6 +380,25 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
 #pragma unroll
                         for (int jx = 0; jx < 4; ++jx)
                             if (4 * bj + jx < P) g[r * P + 4 * bj + jx] = gv[jx];
+                    }
+                }
+            }
+            if (g && bi < bj) {          // the mirror block (bj, bi): rows 4*bj + jx hold column jx of this block
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    const int r = 4 * bj + jx;
+                    if (r >= P) continue;
+                    double gt[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gt[i] = acc.gamma[i * 4 + jx] * 1e-8;
+                    if (P == kPillarPad) {
+                        double2* dst = reinterpret_cast<double2*>(g + r * kPillarPad + 4 * bi);
+                        dst[0] = make_double2(gt[0], gt[1]);
+                        dst[1] = make_double2(gt[2], gt[3]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (4 * bi + i < P) g[r * P + 4 * bi + i] = gt[i];
                     }
                 }
             }
@@ -393,7 +417,9 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
 #pragma unroll
             for (int e = 0; e < kGammaPerLane; ++e) {
                 const int r = 4 * bi + (e >> 2), q = 4 * bj + (e & 3);
-                mine[1 + kPillarPad + r * kPillarPad + q] = GAMMA ? total.gamma[GAMMA ? e : 0] : 0.0;
+                const double x = GAMMA ? total.gamma[GAMMA ? e : 0] : 0.0;
+                if (bi <= bj) mine[1 + kPillarPad + r * kPillarPad + q] = x;
+                if (bi < bj) mine[1 + kPillarPad + q * kPillarPad + r] = x;     // lower blocks: mirrors
             }
         }
         __syncthreads();
