@@ -4,7 +4,8 @@
 TAG=${1:-run}
 OUT=/root/repo/gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 /root/repo/bench.py --steps 5 --warmup 1 --cpu-baseline-seconds 0"
+# the bench command itself (default steps / warmup), minus the CPU baseline leg
+CMD="python3 /root/repo/bench.py --cpu-baseline-seconds 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT.trace.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT.fetch.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT.write.log 2>&1

@@ -22,6 +22,15 @@ for r in csv.DictReader(open(stats)):
     if "price_fast" in r["Name"]:
         out["kernel"] = r["Name"].split("(")[0]
         out["avg_ns"] = float(r["AverageNs"]); out["calls"] = int(r["Calls"])
+        out["min_ns"] = float(r["MinNs"]); out["max_ns"] = float(r["MaxNs"])
+# bench.py's own HIP-event kernel time inside the profiled (kernel-trace) run: must agree with rocprofv3's average
+import re
+try:
+    m = re.search(r'"kernel_ms": ([0-9.]+)', open(f"{base}.trace.log").read())
+    if m:
+        out["bench_kernel_ms_in_profiled_run"] = float(m.group(1))
+except OSError:
+    pass
 rd = 2.0 * out.get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024
 wr = out.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
 out.update(read_bytes_corrected=rd, write_bytes=wr, hbm_bytes_per_launch=rd + wr,
