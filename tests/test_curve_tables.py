@@ -22,9 +22,15 @@ CURVES = {
 
 @pytest.mark.parametrize("name", list(CURVES))
 def test_closed_form_derivatives_match_ad(name):
+    import time
     curve = CURVES[name]()
+    t0 = time.perf_counter()
     host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    t1 = time.perf_counter()
     ref = O.cached_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    t2 = time.perf_counter()
+    # (the reference's method - AD through the scan - against the closed-form recurrences, for DESIGN.md section 5)
+    print(f"{name}: closed forms {1e3 * (t1 - t0):.1f} ms, torch.func jacrev + hessian of the scan {t2 - t1:.2f} s")
     assert np.array_equal(host.times, ref["times"])
     assert np.array_equal(host.dfs, ref["dfs"])                       # same arithmetic, same bits
     assert np.allclose(host.jac, ref["jac"], rtol=1e-12, atol=1e-14)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of the device curve builder: S shocked versions of the README
-curve, bootstrap + d/dr + d2/dr2 + table conversion, next to the host (numpy) builder and to the reference's
-own method (differentiating the scan: torch.func jacrev + hessian in the oracle) on the host cores."""
+curve, bootstrap + d/dr + d2/dr2 + table conversion, next to the host (numpy) builder on the host cores.  (The
+reference's own method - differentiating the scan - is timed by tests/test_curve_tables.py, which may use the
+oracle.)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -32,9 +33,4 @@ t0 = time.perf_counter()
 for i in range(3):
     build_engine_curve(list(np.array(curve.swap_rates) + 1e-4 * i), curve.swap_times, curve.year_fracs)
 out["host_numpy_curves_per_s"] = 3 / (time.perf_counter() - t0)
-if "--oracle" in sys.argv:
-    from oracle import cavour_oracle as O
-    t0 = time.perf_counter()
-    O.cached_curve(list(curve.swap_rates), curve.swap_times, curve.year_fracs, derivatives=True)
-    out["oracle_autodiff_curves_per_s"] = 1 / (time.perf_counter() - t0)
 print(json.dumps(out))
