@@ -1,0 +1,49 @@
+"""The native exchange step: adr_allreduce_agg over an RCCL communicator.  One GPU is all a test box has, so the
+communicator has a single rank (sum over one rank = identity); what is checked is the linkage, the argument
+handling and that the reduction is enqueued on the caller's stream after the pricing kernels."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from adrates_amd import _native
+from adrates_amd.trades import synthetic
+
+from . import _fixtures as F
+from .test_gpu_parity_batch import _device_curve
+
+pytestmark = pytest.mark.gpu
+
+
+def test_allreduce_of_the_aggregate_ladder_single_rank(gpu_ctx):
+    import torch
+    rccl = C.CDLL("librccl.so")
+    comm = C.c_void_p()
+    devs = (C.c_int * 1)(0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, devs) == 0
+    try:
+        vd = F.README_VALUE_DT
+        curve = F.readme_model().curves.GBP_OIS_SONIA
+        host, dc = _device_curve(gpu_ctx, curve)
+        batch = synthetic.synthesize(vd, 3000, seed=9)
+        dt = _native.DeviceTrades(gpu_ctx, batch)
+        P = 32
+        dev = torch.device("cuda", 0)
+        agg = torch.zeros(1 + P + P * P, dtype=torch.float64, device=dev)
+        stream = torch.cuda.Stream(dev)
+        with torch.cuda.stream(stream):
+            _native.price_dev(gpu_ctx, dc, dt, 7, 0, 0, 0, agg.data_ptr(), stream.cuda_stream)
+            rc = _native.load().adr_allreduce_agg(gpu_ctx._h, comm, C.c_void_p(agg.data_ptr()), agg.numel(),
+                                                  C.c_void_p(stream.cuda_stream))
+            assert rc == 0
+        stream.synchronize()
+        want = _native.price(gpu_ctx, dc, dt, per_trade=False, aggregate=True)
+        got = agg.cpu().numpy()
+        assert got[0] == want["agg_pv"]
+        assert np.array_equal(got[1:1 + P], want["agg_delta"])
+        assert np.array_equal(got[1 + P:].reshape(P, P), want["agg_gamma"])
+        # argument checks
+        assert _native.load().adr_allreduce_agg(gpu_ctx._h, None, C.c_void_p(agg.data_ptr()), agg.numel(), None) < 0
+        assert b"adr_allreduce_agg" in _native.load().adr_last_error()
+    finally:
+        rccl.ncclCommDestroy(comm)
