@@ -17,7 +17,7 @@ namespace adr {
 constexpr int kAggStride = 1 + kPillarPad + kPillarPad * kPillarPad; // padded [pv, delta, gamma] record
 constexpr int kGeneralThreads = 256;                                 // general kernel: 4 wavefronts per block
 constexpr int kFastThreads = ADR_FAST_THREADS;
-constexpr int kRowSlots = 32;                                        // cash-flow slots per row of the fast table                                   // fast kernel: 8 wavefronts per block
+constexpr int kRowSlots = 32;                                        // cash-flow slots per row of the fast table
 
 // Per-trade header, 32 bytes, read once per trade with scalar loads.
 struct TradeHeader {
