@@ -191,7 +191,7 @@ int adr_curve_layout_host(int K, int P, const double* times, const double* dfs, 
     const std::string err = adr::build_curve_tables(K, P, times, dfs, jac, hess, t);
     if (!err.empty()) return fail(ADR_ERR_INVALID, "adr_curve_layout_host: " + err);
     adr::CurveDev d{};
-    d.K = t.K; d.Kc = t.Kc; d.Kcore = t.Kcore; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Eu = t.Eu; d.epg = t.epg; d.cpg = t.cpg; d.hub = t.hub ? 1 : 0; d.n_mini = t.n_mini;
+    d.K = t.K; d.Kc = t.Kc; d.Kcore = t.Kcore; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Eu = t.Eu; d.epg = t.epg; d.cpg = t.cpg; d.hub = t.hub ? 1 : 0; d.n_lut = static_cast<int>(t.lut.size() / 2); d.n_mini = t.n_mini;
     info[0] = t.packed_ok ? 1 : 0; info[1] = t.Pc; info[2] = t.Ec; info[3] = t.Eu; info[4] = t.epg;
     info[5] = t.Kcore; info[6] = t.n_mini;
     info[7] = t.packed_ok ? static_cast<int64_t>(adr::fast_kernel_lds_bytes(d, t.has_hess)) : 0;
@@ -251,6 +251,8 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     }
     track(upload(first16, &d_first), d_first);
     track(upload(comp16, &d_comp), d_comp);
+    int16_t* d_lut = nullptr;
+    track(upload(t.lut, &d_lut), d_lut);
     if (t.packed_ok) {
         track(upload(t.ljc, &d_ljc), d_ljc);
         track(upload(t.lcc, &d_lcc), d_lcc);
@@ -265,7 +267,7 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     if (e != hipSuccess) { adr_free_curve(c); return fail_hip(e, "adr_curve_upload: copying tables"); }
     c->dev.K = t.K; c->dev.Kc = t.Kc; c->dev.P = t.P; c->dev.method = interp_method;
     c->dev.x = d_x; c->dev.log_df = d_log; c->dev.inv_x = d_invx; c->dev.lj = d_lj; c->dev.lc_lanes = d_lc; c->dev.lc_block_mask = d_lcmask;
-    c->dev.first_of = d_first; c->dev.compact_of = d_comp;
+    c->dev.first_of = d_first; c->dev.compact_of = d_comp; c->dev.lut = d_lut; c->dev.n_lut = static_cast<int>(t.lut.size() / 2);
     // the fast kernels store the [P][P] matrices as 16-byte pairs of the flat array: P must be even
     c->dev.packed_ok = (t.packed_ok && t.P % 2 == 0) ? 1 : 0;
     c->dev.Pc = t.Pc; c->dev.pc_pad = t.pc_pad; c->dev.Ec = t.Ec; c->dev.Eu = t.Eu; c->dev.epg = t.epg; c->dev.cpg = t.cpg; c->dev.hub = t.hub ? 1 : 0;
@@ -348,6 +350,8 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     track(upload(t.inv_x, &d_invx), d_invx);
     track(upload(first16, &d_first), d_first);
     track(upload(comp16, &d_comp), d_comp);
+    int16_t* d_lut = nullptr;
+    track(upload(t.lut, &d_lut), d_lut);
     if (t.packed_ok) {
         track(upload(core_pillars, &d_core), d_core);
         track(upload(t.knot_class, &d_class), d_class);
@@ -369,6 +373,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     adr::CurveDev& c = plan->shared;
     c.K = t.K; c.Kc = t.Kc; c.P = t.P; c.method = interp_method;
     c.x = d_x; c.inv_x = d_invx; c.first_of = d_first; c.compact_of = d_comp; c.lc_block_mask = d_lcmask;
+    c.lut = d_lut; c.n_lut = static_cast<int>(t.lut.size() / 2);
     c.packed_ok = d.packed_ok;
     c.Pc = t.Pc; c.pc_pad = t.pc_pad; c.Ec = t.Ec; c.Eu = t.Eu; c.epg = t.epg; c.cpg = t.cpg; c.hub = t.hub ? 1 : 0; c.Kcore = t.Kcore; c.n_mini = t.n_mini;
     c.knot_class = d_class; c.pillar_to_core = d_p2c; c.out_map = d_omap; c.store_map = d_smap; c.ent_pq = d_pq; c.core_pos = d_cpos;

@@ -25,6 +25,17 @@ std::string build_curve_tables(int K, int P, const double* times, const double* 
     out.first_of.resize(K);
     out.compact_of.assign(K, -1);
 
+    {   // knot-search table
+        const double t_last = std::max(times[K - 1], 0.0);
+        const int n_lut = std::min(kLutMax, static_cast<int>(t_last * kLutPerYear) + 2);
+        out.lut.assign(2 * static_cast<size_t>(n_lut), 0);
+        auto first_later = [&](double tau) { return static_cast<int>(std::upper_bound(times, times + K, tau) - times); };
+        for (int b = 0; b < n_lut; ++b) {
+            out.lut[2 * b] = static_cast<int16_t>(b == 0 ? 0 : first_later(b / kLutPerYear));
+            out.lut[2 * b + 1] = static_cast<int16_t>(b + 1 == n_lut ? K : first_later((b + 1) / kLutPerYear));
+        }
+    }
+
     // runs of exactly equal times: keep the first and the last knot of each run
     for (int k = 0; k < K; ++k) {
         out.first_of[k] = (k > 0 && times[k] == times[k - 1]) ? out.first_of[k - 1] : k;

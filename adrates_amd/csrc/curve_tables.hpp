@@ -23,6 +23,8 @@ namespace adr {
 constexpr int kPillarPad = 32;                                  // ladders are padded to this on chip
 constexpr int kGammaPerLane = kPillarPad * kPillarPad / 64;     // 16 gamma entries per lane (4x4 block)
 constexpr int kGroupLanes = 32;                                 // lanes per trade in the fast kernel
+constexpr double kLutPerYear = 4.0;                             // buckets per year of the knot-search table
+constexpr int kLutMax = 512;                                    // at most this many buckets (128 years)
 
 // A knot whose log-DF depends on at most two par rates (single-period calibration swaps of the short
 // end): its whole first/second-derivative information is 2 + 3 numbers.
@@ -42,6 +44,10 @@ struct CurveTables {
     bool has_hess = false;
     bool packed_ok = false;            // packed layout below is usable
     std::vector<double> x;             // [K]   knot times (full grid, for the search)
+    // search accelerator: bucket b = [b / kLutPerYear, (b + 1) / kLutPerYear) of time; the first knot later than
+    // a time in the bucket has an index in [lut[2b], lut[2b + 1]] (bucket 0 also takes negative times, the last
+    // bucket everything later)
+    std::vector<int16_t> lut;          // [n_lut][2]
     std::vector<int32_t> first_of;     // [K]   first index of the run of equal times containing k
     std::vector<int32_t> compact_of;   // [K]   row of knot k in the compact tables, -1 if unreachable
     std::vector<int32_t> knot_index;   // [Kc]  inverse of compact_of

@@ -69,6 +69,8 @@ struct CurveDev {
     const double* x;             // [K]
     const double* log_df;        // [Kc]
     const double* inv_x;         // [Kc]
+    const int16_t* lut;          // [n_lut][2] knot-search table (curve_tables.hpp)
+    int n_lut;
     const int16_t* first_of;     // [K]
     const int16_t* compact_of;   // [K]
     // general kernel: dense 32-wide tables

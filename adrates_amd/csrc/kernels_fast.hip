@@ -96,6 +96,8 @@ struct CurveLds {
     const double* ljc;          // [Kcore + 1][pc_pad]
     const double* lcc;          // [Kcore + 1][Ec + 1]
     const MiniKnot* mini;       // [n_mini]
+    const int16_t* lut;         // [n_lut][2]
+    int n_lut;
     const int16_t* first_of;    // [K]
     const int16_t* compact_of;  // [K]
     const int16_t* knot_class;  // [Kc]
@@ -110,7 +112,10 @@ struct Lookup {
 // InterpolatorAd.simple_interpolate for one time (interpolator_ad.py:210-243) in weight form.
 __device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
     const int K = c.K;
-    int lo = 0, hi = K;                 // j = first knot with x > t
+    // j = first knot with x > t, searched inside the index range the time's bucket allows
+    const double tb = t * kLutPerYear;
+    const int bucket = tb > 0.0 ? (tb < static_cast<double>(c.n_lut) ? static_cast<int>(tb) : c.n_lut - 1) : 0;
+    int lo = c.lut[2 * bucket], hi = c.lut[2 * bucket + 1];
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (c.x[mid] > t) hi = mid; else lo = mid + 1;
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     int16_t* s_first = reinterpret_cast<int16_t*>(s_slot + kWavesPerBlock * kSlotDoubles);
     int16_t* s_comp = s_first + cv.K;
     int16_t* s_class = s_comp + cv.K;
+    int16_t* s_lut = s_class + cv.Kc;
 
     {
         const double* src = reinterpret_cast<const double*>(cv.mini);
@@ -220,6 +226,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
         s_invx[i] = cv.inv_x[i];
         s_class[i] = cv.knot_class[i];
     }
+    for (int i = threadIdx.x; i < 2 * cv.n_lut; i += kBlockThreads) s_lut[i] = cv.lut[i];
     for (int i = threadIdx.x; i < n_ljc; i += kBlockThreads) s_ljc[i] = cv.ljc[i];
     for (int i = threadIdx.x; i < n_lcc; i += kBlockThreads) s_lcc[i] = cv.lcc[i];
     for (int i = threadIdx.x; i < n_slack; i += kBlockThreads) s_lcc[n_lcc + i] = 0.0;
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 
     CurveLds c;
     c.x = s_x; c.log_df = s_log; c.inv_x = s_invx; c.ljc = s_ljc; c.lcc = s_lcc; c.mini = s_mini;
-    c.first_of = s_first; c.compact_of = s_comp; c.knot_class = s_class;
+    c.first_of = s_first; c.compact_of = s_comp; c.knot_class = s_class; c.lut = s_lut; c.n_lut = cv.n_lut;
     c.K = cv.K; c.method = cv.method; c.pc_pad = cv.pc_pad; c.ec_stride = ec_stride;
 
     const int lane = threadIdx.x & 63;
@@ -778,7 +785,7 @@ size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
     doubles += doubles & 1;   // the slots start on a 16-byte boundary
     doubles += kWavesPerBlock * slot;
     size_t tables = sizeof(MiniKnot) * cv.n_mini + sizeof(double) * doubles +
-                    sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + cv.Kc);
+                    sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + cv.Kc + 2 * static_cast<size_t>(cv.n_lut));
     size_t reduce = sizeof(double) * kWavesPerBlock * kAggStride;
     size_t need = tables > reduce ? tables : reduce;
     return (need + 15) & ~static_cast<size_t>(15);
