@@ -59,6 +59,8 @@ struct CurveLds {
     const double* log_df;   // [Kc]
     const double* inv_x;    // [Kc]
     const double* lj;       // [Kc][32]
+    const int16_t* lut;         // [n_lut][2] knot-search table (curve_tables.hpp)
+    int n_lut;
     const int16_t* first_of;    // [K]
     const int16_t* compact_of;  // [K]
     int K;
@@ -74,8 +76,10 @@ struct Lookup {
 // InterpolatorAd.simple_interpolate for one time (interpolator_ad.py:210-243) in weight form.
 __device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
     const int K = c.K;
-    // j = first knot with x > t
-    int lo = 0, hi = K;
+    // j = first knot with x > t, searched inside the index range the time's bucket allows
+    const double tb = t * kLutPerYear;
+    const int bucket = tb > 0.0 ? (tb < static_cast<double>(c.n_lut) ? static_cast<int>(tb) : c.n_lut - 1) : 0;
+    int lo = c.lut[2 * bucket], hi = c.lut[2 * bucket + 1];
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (c.x[mid] > t) hi = mid; else lo = mid + 1;
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
     double* s_vbuf = s_lj + static_cast<size_t>(cv.Kc) * kPillarPad;
     int16_t* s_first = reinterpret_cast<int16_t*>(s_vbuf + kWavesPerBlock * kPillarPad);
     int16_t* s_comp = s_first + cv.K;
+    int16_t* s_lut = s_comp + cv.K;                      // [kLutMax][2] reserved
 
     for (int i = threadIdx.x; i < cv.K; i += kBlockThreads) {
         s_x[i] = cv.x[i];
@@ -215,12 +220,13 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
         s_log[i] = cv.log_df[i];
         s_invx[i] = cv.inv_x[i];
     }
+    for (int i = threadIdx.x; i < 2 * cv.n_lut; i += kBlockThreads) s_lut[i] = cv.lut[i];
     for (int i = threadIdx.x; i < cv.Kc * kPillarPad; i += kBlockThreads) s_lj[i] = cv.lj[i];
     __syncthreads();
 
     CurveLds c;
     c.x = s_x; c.log_df = s_log; c.inv_x = s_invx; c.lj = s_lj;
-    c.first_of = s_first; c.compact_of = s_comp; c.K = cv.K; c.method = cv.method;
+    c.first_of = s_first; c.compact_of = s_comp; c.K = cv.K; c.method = cv.method; c.lut = s_lut; c.n_lut = cv.n_lut;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar loads of the header
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
 
 size_t general_kernel_lds_bytes(int K, int Kc) {
     size_t tables = sizeof(double) * (static_cast<size_t>(K) + 2 * Kc + static_cast<size_t>(Kc) * kPillarPad +
-                                      kWavesPerBlock * kPillarPad) + sizeof(int16_t) * 2 * static_cast<size_t>(K);
+                                      kWavesPerBlock * kPillarPad) + sizeof(int16_t) * (2 * static_cast<size_t>(K) + 2 * kLutMax);
     size_t reduce = sizeof(double) * kWavesPerBlock * kAggStride;
     size_t need = tables > reduce ? tables : reduce;
     return (need + 15) & ~static_cast<size_t>(15);
