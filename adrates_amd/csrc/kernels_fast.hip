@@ -56,6 +56,10 @@ namespace adr {
 namespace {
 
 constexpr int kBlockThreads = kFastThreads;
+#ifndef ADR_OUT_PARTS
+#define ADR_OUT_PARTS 2
+#endif
+constexpr int kOutParts = ADR_OUT_PARTS;      // the 8 output bands of a trade are gathered in this many batches
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 
 __device__ __forceinline__ double shfl_d(double x, int src) { return __shfl(x, src, 64); }
@@ -624,33 +628,34 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                 }
                 if (lane == 0) slot[kZeroEntry] = 0.0;
                 wave_lds_sync();
-                // LDS reads of a trade in two batches: the running-total slice + bands 0-3, then bands 4-7
+                // LDS reads of a trade in kOutParts batches: the running-total slice with the first
                 double* gm = (tt >= 0 ? out.gamma + static_cast<int64_t>(tt) * (P * P) : out.dump) + 2 * lane;
                 double* sink = out.dump + 2 * lane;            // pairs beyond a P < 32 matrix go here
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    double ts_[EPL], gv[8];
-                    int mbs[4];
-                    if (half == 0) {
+                for (int part = 0; part < kOutParts; ++part) {
+                    constexpr int kBands = 8 / kOutParts;
+                    double ts_[EPL], gv[2 * kBands];
+                    int mbs[kBands];
+                    if (part == 0) {
 #pragma unroll
                         for (int s = 0; s < EPL; ++s) ts_[s] = slot[lane + 64 * s];
                     }
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) mbs[b] = mm[4 * half + b];
+                    for (int b = 0; b < kBands; ++b) mbs[b] = mm[kBands * part + b];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
+                    for (int b = 0; b < kBands; ++b) {
                         gv[2 * b] = slot[mbs[b] & 0xffff];
                         gv[2 * b + 1] = slot[mbs[b] >> 16];
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (half == 0) {
+                    if (part == 0) {
 #pragma unroll
                         for (int s = 0; s < EPL; ++s) tot_gamma[s] += ts_[s];
                     }
                     if (STORE) {
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const int band = 4 * half + b;
+                        for (int b = 0; b < kBands; ++b) {
+                            const int band = kBands * part + b;
                             *reinterpret_cast<double2*>(((beyond >> band) & 1 ? sink : gm) + band * 128) =
                                 make_double2(gv[2 * b], gv[2 * b + 1]);
                         }
