@@ -1,9 +1,9 @@
 """Market model: named curves, their build parameters and scenario copies.
 
 Mirrors the parts of cavour/models/models.py the OIS path uses: `CurveAccessor`
-:23-49, `Model.build_curve` :142-228, `Model.scenario` :507-557, `Model.curves`
-:559-572.  Bloomberg-backed `prebuilt_*` builders and the XCCY curve builder are
-outside the built scope.
+:23-49, `Model.build_curve` :142-228, `Model.build_xccy_curve` :267-391,
+`Model.scenario` :507-557, `Model.curves` :559-572.  The Bloomberg-backed `prebuilt_*`
+builders are outside the built scope.
 """
 from dataclasses import dataclass, field
 from typing import Dict, List
@@ -83,6 +83,48 @@ class Model:
                 raise ValueError(f"Invalid currency code in pair: {pair}")
             self._fx_params_dict[pair] = {"base": base, "quote": quote,
                                           "ticker": f"{pair} Curncy", "price": float(price)}
+
+    def build_xccy_curve(self, name: str, domestic_curve_name: str, foreign_curve_name: str,
+                         basis_spreads: List[float], tenor_list: List[str], spot_fx: float,
+                         domestic_notional: float = 100_000_000,
+                         domestic_freq_type=FrequencyTypes.ANNUAL, foreign_freq_type=FrequencyTypes.ANNUAL,
+                         domestic_dc_type=DayCountTypes.ACT_360, foreign_dc_type=DayCountTypes.ACT_365F,
+                         bus_day_type=BusDayAdjustTypes.MODIFIED_FOLLOWING,
+                         interp_type=InterpTypes.FLAT_FWD_RATES, use_ad: bool = True):
+        """Register a cross-currency curve bootstrapped from basis swaps quoted in bp on the foreign leg
+        (cavour/models/models.py:267-391).  The calibration swaps exchange ``domestic_notional`` against
+        ``domestic_notional / spot_fx``; the curve itself is built with ``1 / spot_fx`` (:369).  ``bus_day_type``
+        is accepted and, as in the reference, not passed on to the swaps."""
+        for curve in (domestic_curve_name, foreign_curve_name):
+            if curve not in self._curves_dict:
+                kind = "Domestic" if curve == domestic_curve_name else "Foreign"
+                raise ValueError(f"{kind} curve '{curve}' not found in model. "
+                                 f"Build it first using build_curve() or prebuilt_curve().")
+        from ..trades.rates.xccy_basis_swap import XccyBasisSwap
+        from ..trades.rates.xccy_curve import XccyCurve
+        dom_ccy = CurrencyTypes[domestic_curve_name.split("_")[0]]
+        for_ccy = CurrencyTypes[foreign_curve_name.split("_")[0]]
+        swaps = [XccyBasisSwap(effective_dt=self.value_dt, term_dt_or_tenor=tenor,
+                               domestic_notional=domestic_notional, foreign_notional=domestic_notional / spot_fx,
+                               domestic_spread=0.0, foreign_spread=spread_bps / 10000.0,
+                               domestic_freq_type=domestic_freq_type, foreign_freq_type=foreign_freq_type,
+                               domestic_dc_type=domestic_dc_type, foreign_dc_type=foreign_dc_type,
+                               domestic_floating_index=CurveTypes[domestic_curve_name],
+                               foreign_floating_index=CurveTypes[foreign_curve_name],
+                               domestic_currency=dom_ccy, foreign_currency=for_ccy)
+                 for tenor, spread_bps in zip(tenor_list, basis_spreads)]
+        self._curves_dict[name] = XccyCurve(value_dt=self.value_dt, basis_swaps=swaps,
+                                            domestic_curve=self._curves_dict[domestic_curve_name],
+                                            foreign_curve=self._curves_dict[foreign_curve_name],
+                                            spot_fx=1 / spot_fx, interp_type=interp_type, use_ad=use_ad)
+        self._curve_params_dict[name] = {
+            "domestic_curve_name": domestic_curve_name, "foreign_curve_name": foreign_curve_name,
+            "basis_spreads": basis_spreads, "tenor_list": tenor_list, "spot_fx": spot_fx,
+            "domestic_notional": domestic_notional, "domestic_freq_type": domestic_freq_type,
+            "foreign_freq_type": foreign_freq_type, "domestic_dc_type": domestic_dc_type,
+            "foreign_dc_type": foreign_dc_type, "bus_day_type": bus_day_type, "interp_type": interp_type,
+            "use_ad": use_ad,
+        }
 
     def scenario(self, curve_name: str, shock, new_name=None):
         """New model whose ``curve_name`` quotes are shifted by ``shock`` (percent
