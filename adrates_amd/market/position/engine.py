@@ -65,6 +65,9 @@ class Engine:
         dtype = derivative.derivative_type
         if dtype == InstrumentTypes.OIS_SWAP:
             return self._compute_ois(derivative, reqs, collateral_type)
+        if dtype == InstrumentTypes.XCCY_SWAP:
+            from .xccy_engine import compute_xccy
+            return compute_xccy(self, derivative, reqs)
         raise LibError(f"{dtype} not yet implemented")
 
     def _compute_ois(self, derivative, reqs, collateral_type=None):

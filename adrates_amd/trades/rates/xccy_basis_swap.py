@@ -98,6 +98,10 @@ class XccyBasisSwap:
             return dom + frn / spot_fx
         return dom * spot_fx + frn
 
+    def position(self, model):
+        from ...market.position.position import Position
+        return Position(self, model)
+
     def __repr__(self):
         return (f"XccyBasisSwap({self._effective_dt} -> {self._maturity_dt}, "
                 f"{self._domestic_currency.name} {self._domestic_notional:,.0f} vs "

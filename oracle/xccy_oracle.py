@@ -118,3 +118,81 @@ def build(curve_value_dt, swaps, domestic_curve, foreign_curve, spot_fx, times_f
                 jac_foreign=jacrev(from_basis_and_foreign, argnums=1)(spreads, f_dfs).numpy(),
                 mixed=jacrev(jacfwd(from_basis_and_foreign, argnums=1), argnums=0)(spreads, f_dfs)
                 .permute(0, 2, 1).numpy())
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Engine._compute_xccy (cavour/market/position/engine.py:1411-1988): VALUE, the three delta ladders and the
+# three gamma matrices of a cross-currency basis swap.  The cross-gamma block (:1895-1960) is not restated: it
+# contracts a tensor indexed by the foreign curve's OWN nodes with the Jacobian of the engine's knot grid,
+# whose sizes differ.
+# ------------------------------------------------------------------------------------------------------------
+import numpy as np
+from torch.func import grad, hessian
+
+from . import cavour_oracle as O
+
+
+def float_leg_dual(disc_dfs, disc_times, disc_method, idx_dfs, idx_times, idx_method, payment_times, start_times,
+                   end_times, alphas, spread, notional, leg_sign, exchange, t_eff, t_mat, value_time=0.0):
+    """`_float_leg_jax` (engine.py:2639-2728) with a separate index curve and notional exchanges."""
+    payment_times = np.asarray(payment_times, dtype=np.float64)
+    a_np = np.asarray(alphas, dtype=np.float64)
+    a = torch.as_tensor(a_np)
+    df_val = O.simple_interpolate(value_time, disc_times, disc_dfs, disc_method)
+    df_s = O.simple_interpolate(np.asarray(start_times, dtype=np.float64), idx_times, idx_dfs, idx_method)
+    df_e = O.simple_interpolate(np.asarray(end_times, dtype=np.float64), idx_times, idx_dfs, idx_method)
+    pos = torch.as_tensor(a_np > 0)
+    fwd = torch.where(pos, (df_s / df_e - 1.0) / torch.where(pos, a, torch.ones_like(a)), torch.zeros_like(a))
+    cf = (fwd + spread) * a * notional
+    df_rel = O.simple_interpolate(payment_times, disc_times, disc_dfs, disc_method) / df_val
+    valid = torch.as_tensor(payment_times >= value_time)
+    pv = torch.where(valid, cf * df_rel, torch.zeros_like(df_rel)).sum()
+    if exchange:
+        if t_eff >= value_time:
+            pv = pv - notional * O.simple_interpolate(t_eff, disc_times, disc_dfs, disc_method) / df_val
+        if t_mat >= value_time:
+            pv = pv + notional * O.simple_interpolate(t_mat, disc_times, disc_dfs, disc_method) / df_val
+    return leg_sign * pv
+
+
+def _chain(pv_fn, dfs, jac, hess):
+    d = torch.as_tensor(np.asarray(dfs), dtype=_F64)
+    J = torch.as_tensor(np.asarray(jac), dtype=_F64)
+    g = grad(pv_fn)(d)
+    H = hessian(pv_fn)(d)
+    gamma = J.T @ H @ J + torch.sum(g[:, None, None] * torch.as_tensor(np.asarray(hess), dtype=_F64), dim=0)
+    return float(pv_fn(d)), (g @ J).numpy(), gamma.numpy()
+
+
+def xccy_analytics(swap, value_dt, dom_cache, dom_method, for_cache, for_method, xccy_curve, times_from_dates):
+    """dict(value, delta_dom, delta_for, delta_basis, gamma_dom, gamma_for, gamma_basis) in domestic currency,
+    per bp / bp^2 (engine.py:1578, 1680-1733, 1769-1880)."""
+    spot = xccy_curve._spot_fx
+    dl, fl = swap._domestic_leg, swap._foreign_leg
+    receive = type(dl._leg_type).RECEIVE
+    ddc, fdc, xdc = dl._dc_type, fl._dc_type, xccy_curve._dc_type
+    T = lambda dts, dc: np.array([times_from_dates(d, value_dt, dc) for d in dts])
+    x_times, x_dfs, x_method = np.asarray(xccy_curve._times), np.asarray(xccy_curve._dfs), xccy_curve._interp_type.value
+
+    def pv_dom(d):
+        return float_leg_dual(d, dom_cache["times"], dom_method, d, dom_cache["times"], dom_method,
+                              T(dl._payment_dts, ddc), T(dl._start_accrued_dts, ddc), T(dl._end_accrued_dts, ddc),
+                              dl._year_fracs, dl._spread, dl._notional, 1.0 if dl._leg_type == receive else -1.0,
+                              dl._notional_exchange, times_from_dates(swap._effective_dt, value_dt, ddc),
+                              times_from_dates(swap._maturity_dt, value_dt, ddc))
+
+    def pv_for(x_d, f_d):
+        return float_leg_dual(x_d, x_times, x_method, f_d, for_cache["times"], for_method,
+                              T(fl._payment_dts, xdc), T(fl._start_accrued_dts, fdc), T(fl._end_accrued_dts, fdc),
+                              fl._year_fracs, fl._spread, fl._notional, 1.0 if fl._leg_type == receive else -1.0,
+                              fl._notional_exchange, times_from_dates(swap._effective_dt, value_dt, xdc),
+                              times_from_dates(swap._maturity_dt, value_dt, xdc))
+
+    f_fixed = torch.as_tensor(np.asarray(for_cache["dfs"]), dtype=_F64)
+    x_fixed = torch.as_tensor(x_dfs, dtype=_F64)
+    v_dom, d_dom, g_dom = _chain(pv_dom, dom_cache["dfs"], dom_cache["jac"], dom_cache["hess"])
+    v_for, d_for, g_for = _chain(lambda f: pv_for(x_fixed, f), for_cache["dfs"], for_cache["jac"], for_cache["hess"])
+    _, d_bas, g_bas = _chain(lambda x: pv_for(x, f_fixed), x_dfs, xccy_curve._jac_basis, xccy_curve._hess_basis)
+    return dict(value=v_dom + v_for / spot, delta_dom=d_dom * 1e-4, delta_for=d_for * 1e-4 / spot,
+                delta_basis=d_bas * 1e-4 / spot, gamma_dom=g_dom * 1e-8, gamma_for=g_for * 1e-8 / spot,
+                gamma_basis=g_bas * 1e-8 / spot)
