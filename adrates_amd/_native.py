@@ -49,6 +49,8 @@ _SIGNATURES = {
     "adr_free_curve_set": (None, [_vp]),
     "adr_trades_upload": (C.c_int, [_vp, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, _dp, _dp, _dp,
                                     _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
+    "adr_trades_upload_weighted": (C.c_int, [_vp, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, _dp, _dp, _dp, _dp,
+                                             _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
     "adr_free_trades": (None, [_vp]),
     "adr_trades_count": (C.c_int64, [_vp]),
     "adr_trades_input_bytes": (C.c_int64, [_vp]),
@@ -256,11 +258,16 @@ class DeviceTrades:
             arrs[name] = _f64(getattr(b, name))
         if arrs["fix_off"].shape != (n + 1,) or arrs["flt_off"].shape != (n + 1,):
             raise LibError("offset arrays must have n_trades + 1 entries")
+        weight = getattr(b, "flt_weight", None)      # per-coupon notional multipliers (XCCY assembly) or None
+        if weight is not None:
+            weight = _f64(weight)
+            if weight.shape != arrs["flt_tp"].shape:
+                raise LibError("flt_weight must have one entry per float coupon")
         h = _vp()
-        _check(load().adr_trades_upload(
+        _check(load().adr_trades_upload_weighted(
             ctx._h, n, _ptr(arrs["fix_off"], _i64p), _ptr(arrs["flt_off"], _i64p),
             _ptr(arrs["fix_tp"]), _ptr(arrs["fix_pay"]), _ptr(arrs["flt_tp"]), _ptr(arrs["flt_ts"]),
-            _ptr(arrs["flt_te"]), _ptr(arrs["flt_alpha"]), _ptr(arrs["notional"]), _ptr(arrs["spread"]),
+            _ptr(arrs["flt_te"]), _ptr(arrs["flt_alpha"]), _ptr(weight), _ptr(arrs["notional"]), _ptr(arrs["spread"]),
             _ptr(arrs["fix_sign"]), _ptr(arrs["flt_sign"]), C.byref(h)), "adr_trades_upload")
         self._h, self._ctx = h, ctx
         self.n_trades = n

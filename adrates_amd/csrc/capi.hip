@@ -506,6 +506,15 @@ int adr_trades_upload(adr_ctx* ctx, int64_t n, const int64_t* fix_off, const int
                       const double* fix_pay, const double* flt_tp, const double* flt_ts, const double* flt_te,
                       const double* flt_alpha, const double* notional, const double* spread, const double* fix_sign,
                       const double* flt_sign, adr_trades** out) {
+    return adr_trades_upload_weighted(ctx, n, fix_off, flt_off, fix_tp, fix_pay, flt_tp, flt_ts, flt_te, flt_alpha,
+                                      nullptr, notional, spread, fix_sign, flt_sign, out);
+}
+
+int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, const int64_t* flt_off,
+                               const double* fix_tp, const double* fix_pay, const double* flt_tp, const double* flt_ts,
+                               const double* flt_te, const double* flt_alpha, const double* flt_weight,
+                               const double* notional, const double* spread, const double* fix_sign,
+                               const double* flt_sign, adr_trades** out) {
     if (!ctx || !out) return fail(ADR_ERR_INVALID, "adr_trades_upload: null ctx/out");
     *out = nullptr;
     if (n < 0) return fail(ADR_ERR_INVALID, "adr_trades_upload: negative trade count");
@@ -530,7 +539,8 @@ int adr_trades_upload(adr_ctx* ctx, int64_t n, const int64_t* fix_off, const int
     for (int64_t t = 0; t < n; ++t) {
         bool general = rows_of(t) > kMaxChain;
         for (int64_t j = flt_off[t]; j < flt_off[t + 1] && !general; ++j)
-            general = flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j];       // payment lag: ratio terms
+            general = (flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j])      // payment lag: ratio terms
+                      || (flt_weight && flt_weight[j] != 1.0);              // per-coupon notionals
         (general ? list_general : rows_of(t) > 1 ? list_long : list_fast).push_back(static_cast<int32_t>(t));
     }
     for (int64_t t = 0; t < n; ++t) {
@@ -576,6 +586,7 @@ int adr_trades_upload(adr_ctx* ctx, int64_t n, const int64_t* fix_off, const int
     tr->dev.flt_ts = static_cast<const double*>(put(flt_ts, n_flt * sizeof(double)));
     tr->dev.flt_te = static_cast<const double*>(put(flt_te, n_flt * sizeof(double)));
     tr->dev.flt_alpha = static_cast<const double*>(put(flt_alpha, n_flt * sizeof(double)));
+    tr->dev.flt_weight = flt_weight ? static_cast<const double*>(put(flt_weight, n_flt * sizeof(double))) : nullptr;
     tr->dev.list = nullptr;
     tr->dev.n_list = n;
     tr->n_fast = static_cast<int64_t>(list_fast.size());

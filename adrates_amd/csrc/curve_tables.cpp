@@ -17,6 +17,13 @@ std::string build_curve_tables(int K, int P, const double* times, const double* 
         if (k > 0 && times[k] < times[k - 1]) return "knot times must be non-decreasing";
     }
 
+    // The reference prices relative to the discount factor at the value time, D(tp)/D(0) (engine.py:2426-2435, 2669-2692);
+    // its grids always start with the value-time point (t = 0, D = 1, no sensitivity), which is what lets the
+    // kernels leave that division out.  A table that does not start there would be priced differently: refuse it.
+    if (times[0] != 0.0 || dfs[0] != 1.0) return "the first knot must be the value time (t = 0, discount factor 1)";
+    for (int p = 0; p < P; ++p)
+        if (jac[p] != 0.0) return "the value-time knot (t = 0) must have no sensitivity";
+
     out = CurveTables();
     out.K = K;
     out.P = P;

@@ -44,6 +44,7 @@ struct TradesDev {
     const double* flt_ts;
     const double* flt_te;
     const double* flt_alpha;
+    const double* flt_weight;    // per-coupon multiplier of the notional, or null (= 1); general kernel only
     // General kernel: the launch covers n_list trades: list[i] when list != null, else trade i.
     const int32_t* list;
     int64_t n_list;

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
         const double* f_ts = tr.flt_ts + h.flt_begin;
         const double* f_te = tr.flt_te + h.flt_begin;
         const double* f_al = tr.flt_alpha + h.flt_begin;
+        const double* f_w = tr.flt_weight ? tr.flt_weight + h.flt_begin : nullptr;   // wave-uniform
         const double* x_tp = tr.fix_tp + h.fix_begin;
         const double* x_pay = tr.fix_pay + h.fix_begin;
 
@@ -261,17 +262,18 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
             const bool in = j < n_flt;
             double tp = 0.0, ts = 0.0, te = 0.0, al = 0.0;
             if (in) { tp = f_tp[j]; ts = f_ts[j]; te = f_te[j]; al = f_al[j]; }
+            const double Nw = (f_w && in) ? N * f_w[j] : N;     // the coupon's own notional
             const bool valid = in && tp >= 0.0;
             const bool accrues = al > 0.0;
             const bool linear = accrues && te == tp;      // D(ts)/D(te)*D(tp) collapses to D(ts)
             const bool ratio = accrues && te != tp;
 
             // payment node P_j: -N(1 - spread*a) D(tp) (or N*spread*a*D(tp) when nothing accrues)
-            double a_pay = valid ? sl * N * (spread * al - (accrues ? 1.0 : 0.0)) : 0.0;
+            double a_pay = valid ? sl * Nw * (spread * al - (accrues ? 1.0 : 0.0)) : 0.0;
             // next coupon's start node lands here when its accrual starts on this payment time
             if (in && j + 1 < n_flt) {
                 const double ntp = f_tp[j + 1], nts = f_ts[j + 1], nte = f_te[j + 1], nal = f_al[j + 1];
-                if (nal > 0.0 && nte == ntp && ntp >= 0.0 && nts == tp) a_pay += sl * N;
+                if (nal > 0.0 && nte == ntp && ntp >= 0.0 && nts == tp) a_pay += sl * (f_w ? N * f_w[j + 1] : N);
             }
             // the fixed coupon paid at the same time joins the node
             if (in && j < n_fix) {
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
                 if (own_start) {
                     const Lookup q = curve_lookup(c, ts);
                     k[0] = q.ka; k[1] = q.kb; b[0] = q.ba; b[1] = q.bb;
-                    omega = sl * N * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
+                    omega = sl * Nw * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
                     acc.pv += omega;
                 }
                 add_nodes<2, DELTA, GAMMA>(__ballot(own_start), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
                     double l = 0.0;
 #pragma unroll
                     for (int i = 0; i < 6; ++i) l = fma(b[i], c.log_df[k[i]], l);
-                    omega = sl * N * exp(l);
+                    omega = sl * Nw * exp(l);
                     acc.pv += omega;
                     // te and tp are a few days apart and usually bracketed by the same knots: fold the te weights
                     // into the tp entries (zero-weight entries are skipped downstream)

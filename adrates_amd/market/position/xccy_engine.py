@@ -10,11 +10,13 @@ ONE curve's knots once the other curve is held fixed - which is exactly how the 
 
 1. domestic leg: a float leg plus two "fixed" flows (-N at the effective time, +N at maturity) on the
    domestic curve's tables;
-2. foreign-rate ladders: one single-coupon trade per foreign coupon on the foreign OIS tables, notional
-   ``N * D_x(tp_j)``, paid at time 0 (where D = 1), accrual from ``ts_j`` to ``te_j``: its Greeks are those of
-   ``N D_x(tp_j) D_f(ts_j) / D_f(te_j)``;
+2. foreign-rate ladders: the foreign coupons on the foreign OIS tables with notional ``N * D_x(tp_j)``, paid at
+   time 0 (where D = 1), accrual from ``ts_j`` to ``te_j``: the Greeks of ``sum_j N D_x(tp_j) D_f(ts_j) / D_f(te_j)``;
 3. foreign PV and basis ladders: fixed flows ``N (fwd_j + s) alpha_j`` at ``tp_j`` plus the two exchanges, on
    tables uploaded from the XCCY curve's ``(_times, _dfs, _jac_basis, _hess_basis)``.
+
+Piece 2 is one trade per swap whose coupons carry a per-coupon notional multiplier
+(`adr_trades_upload_weighted`), so a book of swaps costs three launches.
 
 Flows dated exactly at the value time follow the reference's masks: coupons and exchanges count (``>=``), and
 since their discount factor is 1 they are added to the PV on the host (the kernels' fixed-flow mask is ``>``).
@@ -58,115 +60,186 @@ def _times(dts, value_dt, dc):
     return np.array([times_from_dates(d, value_dt, dc) for d in dts], dtype=np.float64)
 
 
-def _batch(n, fix_tp, fix_pay, fix_counts, flt, flt_counts, notional, spread, fix_sign, flt_sign):
-    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
-    off = lambda c: np.concatenate(([0], np.cumsum(c))).astype(np.int64)
-    z = np.zeros(0)
-    tp, ts, te, al = flt if flt is not None else (z, z, z, z)
-    return TradeBatch(off(fix_counts), off(flt_counts), f64(fix_tp), f64(fix_pay), f64(tp), f64(ts), f64(te), f64(al),
-                      f64(notional), f64(spread), f64(fix_sign), f64(flt_sign))
+class _Csr:
+    """Flat cash-flow arrays of a batch under construction."""
+
+    def __init__(self, fields):
+        self.cols = {f: [] for f in fields}
+        self.off = [0]
+
+    def add(self, **cols):
+        n = None
+        for k, v in cols.items():
+            self.cols[k].append(np.asarray(v, dtype=np.float64).reshape(-1))
+            n = self.cols[k][-1].size
+        self.off.append(self.off[-1] + (n or 0))
+
+    def col(self, k):
+        return np.concatenate(self.cols[k]) if self.cols[k] else np.zeros(0)
+
+    def offsets(self):
+        return np.asarray(self.off, dtype=np.int64)
 
 
-def compute_xccy(engine, derivative, reqs):
+def _sign(leg):
+    return 1.0 if leg._leg_type == SwapTypes.RECEIVE else -1.0
+
+
+def compile_xccy(swaps, value_dt, xccy, for_times, for_dfs, for_method):
+    """The three trade batches of the assembly above, plus the per-swap PV of the flows dated at the value time.
+
+    ``for_times, for_dfs``: the foreign OIS curve's engine grid (the reference projects the foreign forwards off
+    `_cached_curve`'s knots, engine.py:1640-1668).  Returns ``(domestic, foreign_rates, foreign_flows, pv_const,
+    spot)``; ``foreign_rates`` carries `flt_weight`."""
+    spot = xccy._spot_fx
+    x_times, x_dfs, x_method = np.asarray(xccy._times), np.asarray(xccy._dfs), xccy._interp_type.value
+    xdc = xccy._dc_type
+    n = len(swaps)
+    pv_const = np.zeros(n)
+    dom_fix, dom_flt = _Csr(("tp", "pay")), _Csr(("tp", "ts", "te", "al"))
+    for_flt = _Csr(("tp_x", "ts", "te", "al"))
+    exch = _Csr(("tp", "pay"))
+    for i, swap in enumerate(swaps):
+        dl, fl = swap._domestic_leg, swap._foreign_leg
+        ddc, fdc = dl._dc_type, fl._dc_type
+        tp, pay = [], []
+        if dl._notional_exchange:
+            for t, amount in ((times_from_dates(swap._effective_dt, value_dt, ddc), -dl._notional),
+                              (times_from_dates(swap._maturity_dt, value_dt, ddc), dl._notional)):
+                if t > 0.0:
+                    tp.append(t); pay.append(amount)
+                elif t == 0.0:
+                    pv_const[i] += _sign(dl) * amount
+        dom_fix.add(tp=tp, pay=pay)
+        dom_flt.add(tp=_times(dl._payment_dts, value_dt, ddc), ts=_times(dl._start_accrued_dts, value_dt, ddc),
+                    te=_times(dl._end_accrued_dts, value_dt, ddc), al=dl._year_fracs)
+        for_flt.add(tp_x=_times(fl._payment_dts, value_dt, xdc), ts=_times(fl._start_accrued_dts, value_dt, fdc),
+                    te=_times(fl._end_accrued_dts, value_dt, fdc), al=fl._year_fracs)
+        tp, pay = [], []
+        if fl._notional_exchange:
+            for t, amount in ((times_from_dates(swap._effective_dt, value_dt, xdc), -fl._notional),
+                              (times_from_dates(swap._maturity_dt, value_dt, xdc), fl._notional)):
+                if t > 0.0:
+                    tp.append(t); pay.append(amount)
+                elif t == 0.0:
+                    pv_const[i] += _sign(fl) * amount / spot
+        exch.add(tp=tp, pay=pay)
+
+    f64 = lambda v: np.array(v, dtype=np.float64)
+    dom_n, dom_s = f64([s._domestic_leg._notional for s in swaps]), f64([_sign(s._domestic_leg) for s in swaps])
+    for_n, for_s = f64([s._foreign_leg._notional for s in swaps]), f64([_sign(s._foreign_leg) for s in swaps])
+    domestic = TradeBatch(dom_fix.offsets(), dom_flt.offsets(), dom_fix.col("tp"), dom_fix.col("pay"),
+                          dom_flt.col("tp"), dom_flt.col("ts"), dom_flt.col("te"), dom_flt.col("al"), dom_n,
+                          f64([s._domestic_leg._spread for s in swaps]), dom_s, dom_s)
+
+    # foreign coupons, all swaps at once: forwards off the foreign OIS grid, discount factors off the XCCY knots
+    off = for_flt.offsets()
+    owner = np.repeat(np.arange(n), np.diff(off))
+    tp_x, ts, te, al = for_flt.col("tp_x"), for_flt.col("ts"), for_flt.col("te"), for_flt.col("al")
+    c = knot_df(x_times, x_dfs, tp_x, x_method) / knot_df(x_times, x_dfs, 0.0, x_method)   # relative to the value time
+    accrues = al > 0
+    fwd = np.where(accrues, (knot_df(for_times, for_dfs, ts, for_method) / knot_df(for_times, for_dfs, te, for_method)
+                             - 1.0) / np.where(accrues, al, 1.0), 0.0)
+    live = tp_x >= 0.0
+    keep = live & accrues
+    kept_off = np.concatenate(([0], np.cumsum(np.bincount(owner[keep], minlength=n)))).astype(np.int64)
+    zeros_n, none = np.zeros(n), np.zeros(0)
+    foreign_rates = TradeBatch(np.zeros(n + 1, dtype=np.int64), kept_off, none, none, np.zeros(int(keep.sum())),
+                               ts[keep], te[keep], al[keep], for_n, zeros_n, for_s, for_s, flt_weight=c[keep])
+
+    spreads = f64([s._foreign_leg._spread for s in swaps])
+    amounts = (fwd + spreads[owner]) * al * for_n[owner]
+    at_value_time = live & (tp_x == 0.0)
+    np.add.at(pv_const, owner[at_value_time], (for_s[owner] * amounts)[at_value_time] / spot)
+    later = live & (tp_x > 0.0)
+    # per swap: its later coupons, then its exchanges
+    cnt = np.bincount(owner[later], minlength=n) + np.diff(exch.offsets())
+    fix_off = np.concatenate(([0], np.cumsum(cnt))).astype(np.int64)
+    flow_tp, flow_pay = np.empty(int(fix_off[-1])), np.empty(int(fix_off[-1]))
+    coupon_pos = fix_off[:-1][owner[later]] + (np.arange(later.sum()) - np.concatenate(([0], np.cumsum(np.bincount(owner[later], minlength=n))))[:-1][owner[later]])
+    flow_tp[coupon_pos], flow_pay[coupon_pos] = tp_x[later], amounts[later]
+    e_off, e_owner = exch.offsets(), np.repeat(np.arange(n), np.diff(exch.offsets()))
+    exch_pos = fix_off[1:][e_owner] - (e_off[1:][e_owner] - np.arange(e_off[-1]))
+    flow_tp[exch_pos], flow_pay[exch_pos] = exch.col("tp"), exch.col("pay")
+    foreign_flows = TradeBatch(fix_off, np.zeros(n + 1, dtype=np.int64), flow_tp, flow_pay, none, none, none, none,
+                               for_n, zeros_n, for_s, for_s)
+    return domestic, foreign_rates, foreign_flows, pv_const, spot
+
+
+def _curves(engine, swaps):
     model = engine.model
-    dom_model = getattr(model.curves, derivative._domestic_floating_index.name)
-    for_model = getattr(model.curves, derivative._foreign_floating_index.name)
-    name = f"{derivative._foreign_currency.name}_{derivative._domestic_currency.name}_BASIS"
+    first = swaps[0]
+    for s in swaps:
+        if (s._domestic_floating_index, s._foreign_floating_index, s._domestic_currency, s._foreign_currency) != \
+           (first._domestic_floating_index, first._foreign_floating_index, first._domestic_currency, first._foreign_currency):
+            raise LibError("a batch of cross-currency swaps must share its currencies and floating indices")
+    dom_model = getattr(model.curves, first._domestic_floating_index.name)
+    for_model = getattr(model.curves, first._foreign_floating_index.name)
+    name = f"{first._foreign_currency.name}_{first._domestic_currency.name}_BASIS"
     try:
         xccy = getattr(model.curves, name)
     except AttributeError:
         raise LibError(f"XCCY curve {name} not found in model.")
     if getattr(xccy, "_jac_basis", None) is None:
         raise LibError("the XCCY curve carries no basis Jacobian (build it with use_ad=True)")
-    spot = xccy._spot_fx
-    value_dt = model.value_dt
-    want_delta = bool(reqs & {RequestTypes.DELTA, RequestTypes.GAMMA})
-    want_gamma = RequestTypes.GAMMA in reqs
-
     dom_cur, for_cur = engine._device_curve(dom_model), engine._device_curve(for_model)
-    ctx = dom_cur["ctx"]
     x_dev = getattr(xccy, "_adr_device_curve", None)
     if x_dev is None:
-        x_dev = _native.DeviceCurve(ctx, xccy._interp_type.value, np.asarray(xccy._times), np.asarray(xccy._dfs),
-                                    np.asarray(xccy._jac_basis), np.asarray(xccy._hess_basis))
+        hess = getattr(xccy, "_hess_basis", None)
+        x_dev = _native.DeviceCurve(dom_cur["ctx"], xccy._interp_type.value, np.asarray(xccy._times),
+                                    np.asarray(xccy._dfs), np.asarray(xccy._jac_basis),
+                                    None if hess is None else np.asarray(hess))
         xccy._adr_device_curve = x_dev
+    return dom_model, for_model, xccy, dom_cur, for_cur, x_dev
 
-    dl, fl = derivative._domestic_leg, derivative._foreign_leg
-    sign = lambda leg: 1.0 if leg._leg_type == SwapTypes.RECEIVE else -1.0
-    kw = dict(want_value=True, want_delta=want_delta, want_gamma=want_gamma)
-    pv_const = 0.0          # flows dated exactly at the value time (discount factor 1, no sensitivity)
 
-    # ---- 1. domestic leg on the domestic curve
-    ddc = dl._dc_type
-    t_eff, t_mat = times_from_dates(derivative._effective_dt, value_dt, ddc), times_from_dates(derivative._maturity_dt, value_dt, ddc)
-    fix_tp, fix_pay = [], []
-    if dl._notional_exchange:
-        for t, amount in ((t_eff, -dl._notional), (t_mat, dl._notional)):
-            if t > 0.0:
-                fix_tp.append(t); fix_pay.append(amount)
-            elif t == 0.0:
-                pv_const += sign(dl) * amount
-    b = _batch(1, fix_tp, fix_pay, [len(fix_tp)],
-               (_times(dl._payment_dts, value_dt, ddc), _times(dl._start_accrued_dts, value_dt, ddc),
-                _times(dl._end_accrued_dts, value_dt, ddc), np.asarray(dl._year_fracs)), [len(dl._payment_dts)],
-               [dl._notional], [dl._spread], [sign(dl)], [sign(dl)])
-    dom = _price(ctx, dom_cur["dev"], b, kw)
+def price_xccy_batch(engine, swaps, reqs, per_trade=True, aggregate=False):
+    """VALUE / DELTA / GAMMA of a book of cross-currency basis swaps on one currency pair: three launches.
 
-    # ---- 2. foreign coupons: forwards off the foreign OIS grid, discount factors off the XCCY knots
-    fdc, xdc = fl._dc_type, xccy._dc_type
-    tp_x = _times(fl._payment_dts, value_dt, xdc)
-    ts_f, te_f = _times(fl._start_accrued_dts, value_dt, fdc), _times(fl._end_accrued_dts, value_dt, fdc)
-    alpha = np.asarray(fl._year_fracs, dtype=np.float64)
-    live = tp_x >= 0.0
-    x_times, x_dfs, x_method = np.asarray(xccy._times), np.asarray(xccy._dfs), xccy._interp_type.value
+    Returns a dict: ``pv [n]``, ``delta_dom [n, P_d]``, ``delta_for [n, P_f]``, ``delta_basis [n, P_b]`` and the
+    three ``gamma_*`` (per request, when ``per_trade``), ``agg_*`` sums over the book (when ``aggregate``);
+    everything in domestic currency, per bp / bp^2."""
+    reqs = set(reqs)
+    swaps = list(swaps)
+    dom_model, for_model, xccy, dom_cur, for_cur, x_dev = _curves(engine, swaps)
+    ctx = dom_cur["ctx"]
     f_host = for_cur["host"]
-    f_method = for_model._interp_type.value
-    c = knot_df(x_times, x_dfs, tp_x, x_method) / knot_df(x_times, x_dfs, 0.0, x_method)   # relative to the value time
-    fwd = np.where(alpha > 0, (knot_df(f_host.times, f_host.dfs, ts_f, f_method)
-                               / knot_df(f_host.times, f_host.dfs, te_f, f_method) - 1.0) / np.where(alpha > 0, alpha, 1.0), 0.0)
-    delta_for = gamma_for = None
-    if want_delta:
-        idx = np.flatnonzero(live & (alpha > 0))
-        m = idx.size
-        zeros = np.zeros(m)
-        b = _batch(m, [], [], [0] * m, (zeros, ts_f[idx], te_f[idx], alpha[idx]), [1] * m,
-                   fl._notional * c[idx], zeros, np.ones(m), np.full(m, sign(fl)))
-        out = _price(ctx, for_cur["dev"], b, dict(want_value=False, want_delta=True, want_gamma=want_gamma))
-        delta_for = out["delta"].sum(0) / spot
-        gamma_for = out["gamma"].sum(0) / spot if want_gamma else None
+    domestic, foreign_rates, foreign_flows, pv_const, spot = compile_xccy(
+        swaps, engine.model.value_dt, xccy, f_host.times, f_host.dfs, for_model._interp_type.value)
+    want_value = RequestTypes.VALUE in reqs
+    want_gamma = RequestTypes.GAMMA in reqs
+    want_delta = want_gamma or RequestTypes.DELTA in reqs
+    kw = dict(want_delta=want_delta, want_gamma=want_gamma, per_trade=per_trade, aggregate=aggregate)
+    dom = _price(ctx, dom_cur["dev"], domestic, dict(kw, want_value=want_value))
+    frn = _price(ctx, x_dev, foreign_flows, dict(kw, want_value=want_value))
+    rates = _price(ctx, for_cur["dev"], foreign_rates, dict(kw, want_value=False)) if want_delta else {}
+    out = {}
+    for pre in (("",) if per_trade else ()) + (("agg_",) if aggregate else ()):
+        if want_value:
+            const = pv_const if pre == "" else float(pv_const.sum())
+            out[pre + "pv"] = dom[pre + "pv"] + frn[pre + "pv"] / spot + const
+        for kind in (("delta",) if want_delta else ()) + (("gamma",) if want_gamma else ()):
+            out[f"{pre}{kind}_dom"] = np.asarray(dom[pre + kind])
+            out[f"{pre}{kind}_for"] = np.asarray(rates[pre + kind]) / spot
+            out[f"{pre}{kind}_basis"] = np.asarray(frn[pre + kind]) / spot
+    out["tenors"] = (to_tenor(list(dom_model.swap_times)), to_tenor(list(for_model.swap_times)),
+                     to_tenor(list(xccy.swap_times)))
+    return out
 
-    # ---- 3. foreign PV and basis ladders: the coupons as fixed flows on the XCCY tables
-    amounts = (fwd + fl._spread) * alpha * fl._notional
-    fix_tp, fix_pay = [], []
-    for t, amount in zip(tp_x[live], amounts[live]):
-        if t > 0.0:
-            fix_tp.append(t); fix_pay.append(amount)
-        else:
-            pv_const += sign(fl) * amount / spot
-    if fl._notional_exchange:
-        for t, amount in ((times_from_dates(derivative._effective_dt, value_dt, xdc), -fl._notional),
-                          (times_from_dates(derivative._maturity_dt, value_dt, xdc), fl._notional)):
-            if t > 0.0:
-                fix_tp.append(t); fix_pay.append(amount)
-            elif t == 0.0:
-                pv_const += sign(fl) * amount / spot
-    b = _batch(1, fix_tp, fix_pay, [len(fix_tp)], None, [0], [fl._notional], [0.0], [sign(fl)], [sign(fl)])
-    frn = _price(ctx, x_dev, b, kw)
 
+def compute_xccy(engine, derivative, reqs):
+    res = price_xccy_batch(engine, [derivative], reqs)
     ccy = derivative._domestic_currency
+    curves = (derivative._domestic_floating_index, derivative._foreign_floating_index, CurveTypes.USD_GBP_BASIS)
     value = delta = gamma = None
     if RequestTypes.VALUE in reqs:
-        value = Valuation(amount=float(dom["pv"][0] + frn["pv"][0] / spot + pv_const), currency=ccy)
-    dom_tenors, for_tenors = to_tenor(list(dom_model.swap_times)), to_tenor(list(for_model.swap_times))
-    basis_tenors = to_tenor(list(xccy.swap_times))
+        value = Valuation(amount=float(res["pv"][0]), currency=ccy)
     if RequestTypes.DELTA in reqs:
-        delta = Risk([Delta(np.array(dom["delta"][0]), dom_tenors, ccy, derivative._domestic_floating_index),
-                      Delta(np.array(delta_for), for_tenors, ccy, derivative._foreign_floating_index),
-                      Delta(np.array(frn["delta"][0] / spot), basis_tenors, ccy, CurveTypes.USD_GBP_BASIS)])
-    if want_gamma:
-        gamma = Risk([Gamma(np.array(dom["gamma"][0]), dom_tenors, ccy, derivative._domestic_floating_index),
-                      Gamma(np.array(gamma_for), for_tenors, ccy, derivative._foreign_floating_index),
-                      Gamma(np.array(frn["gamma"][0] / spot), basis_tenors, ccy, CurveTypes.USD_GBP_BASIS)])
+        delta = Risk([Delta(np.array(res[k][0]), t, ccy, c)
+                      for k, t, c in zip(("delta_dom", "delta_for", "delta_basis"), res["tenors"], curves)])
+    if RequestTypes.GAMMA in reqs:
+        gamma = Risk([Gamma(np.array(res[k][0]), t, ccy, c)
+                      for k, t, c in zip(("gamma_dom", "gamma_for", "gamma_basis"), res["tenors"], curves)])
     return AnalyticsResult(value=value, risk=delta, gamma=gamma)
 
 

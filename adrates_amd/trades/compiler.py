@@ -10,7 +10,7 @@ notional and leg signs.
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Iterable, Sequence, Union
+from typing import Iterable, Optional, Sequence, Union
 
 import numpy as np
 
@@ -34,6 +34,7 @@ class TradeBatch:
     spread: np.ndarray
     fix_sign: np.ndarray
     flt_sign: np.ndarray
+    flt_weight: Optional[np.ndarray] = None   # per float coupon: multiplies the notional (adr_trades_upload_weighted)
 
     @property
     def n_trades(self) -> int:
@@ -46,7 +47,8 @@ class TradeBatch:
         return TradeBatch(self.fix_off[lo:hi + 1] - f0, self.flt_off[lo:hi + 1] - l0,
                           self.fix_tp[f0:f1], self.fix_pay[f0:f1], self.flt_tp[l0:l1], self.flt_ts[l0:l1],
                           self.flt_te[l0:l1], self.flt_alpha[l0:l1], self.notional[lo:hi], self.spread[lo:hi],
-                          self.fix_sign[lo:hi], self.flt_sign[lo:hi])
+                          self.fix_sign[lo:hi], self.flt_sign[lo:hi],
+                          None if self.flt_weight is None else self.flt_weight[l0:l1])
 
 
 def _times(dts, value_dt, dc_type):

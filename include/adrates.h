@@ -74,7 +74,10 @@ int adr_device_count(void);
  * (engine.py:2405-2411): knot times [K] (non-decreasing, duplicates allowed and
  * meaningful), knot discount factors [K], jac = d dfs / d par-rates [K*P]
  * row-major, hess = d2 dfs / d par-rates2 [K*P*P] row-major (may be NULL when
- * gamma will never be requested).  The library converts them to log space,
+ * gamma will never be requested).  The first knot must be the value-time point
+ * the reference's grids start with (t = 0, discount factor 1, zero jac row): the
+ * reference prices relative to D(0) (engine.py:2426-2435) and the kernels rely on
+ * D(0) = 1 instead of dividing.  The library converts the tables to log space,
  * keeps only the knots a query can reference and uploads them.
  */
 int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P,
@@ -165,6 +168,23 @@ int adr_trades_upload(adr_ctx* ctx, int64_t n_trades,
                       const double* notional, const double* spread,
                       const double* fix_sign, const double* flt_sign,
                       adr_trades** out);
+/*
+ * The same with a weight per float coupon (flt_weight[sum n_flt], NULL = all 1) that multiplies the trade's
+ * notional for that coupon.  It carries the discount factor of the *other* curve when a float leg is
+ * discounted on one curve and projected on another - the foreign leg of a cross-currency swap, where the
+ * reference calls _float_leg_jax with disc != index curve (engine.py:1640-1712): holding the XCCY curve fixed,
+ * the sensitivities to the foreign OIS rates are those of sum_j w_j N D(ts_j)/D(te_j) with w_j = D_x(tp_j).
+ * Trades with a weight != 1 are priced by the general kernel.
+ */
+int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n_trades,
+                               const int64_t* fix_off, const int64_t* flt_off,
+                               const double* fix_tp, const double* fix_pay,
+                               const double* flt_tp, const double* flt_ts,
+                               const double* flt_te, const double* flt_alpha,
+                               const double* flt_weight,
+                               const double* notional, const double* spread,
+                               const double* fix_sign, const double* flt_sign,
+                               adr_trades** out);
 void adr_free_trades(adr_trades* trades);
 int64_t adr_trades_count(const adr_trades* trades);
 /* Bytes of trade input one pricing pass has to read (SURVEY.md section 8(d):

@@ -134,7 +134,8 @@ static void add_term(work_t* w, int m, const df_t* X, const double* fX, const do
 }
 
 static double price_one(const curve_t* c, work_t* w, int mf, const double* ftp, const double* fpay, int ml,
-                        const double* ltp, const double* lts, const double* lte, const double* lal, double N,
+                        const double* ltp, const double* lts, const double* lte, const double* lal,
+                        const double* lw /* per-coupon weights or NULL */, double N,
                         double spread, double sf, double sl, double* delta, double* gamma, double* tmp /* MAXLOC*P */) {
     const int P = c->P;
     const double tv = 0.0;
@@ -166,7 +167,7 @@ static double price_one(const curve_t* c, work_t* w, int mf, const double* ftp, 
         if (al > 0.0) {
             interpolate(c, lts[j], &X[0]);
             interpolate(c, lte[j], &X[1]);
-            const double A = X[0].v, B = X[1].v, n = sl * N;
+            const double A = X[0].v, B = X[1].v, n = sl * N * (lw ? lw[j] : 1.0);
             const double fwd = (A / B - 1.0) / al;
             const double cf = (fwd + spread) * al * n;
             pv += cf * R;
@@ -182,7 +183,7 @@ static double price_one(const curve_t* c, work_t* w, int mf, const double* ftp, 
             fXY[3 * 4 + 3] = 2.0 * cf * C / (Vv * Vv * Vv);
             add_term(w, 4, X, fX, fXY);
         } else {
-            const double cf = spread * al * sl * N;   /* forward is forced to 0 when nothing accrues */
+            const double cf = spread * al * sl * N * (lw ? lw[j] : 1.0);   /* forward is forced to 0 when nothing accrues */
             pv += cf * R;
             df_t Y[2] = {X[2], V};
             const double fX[2] = {cf / Vv, -cf * C / (Vv * Vv)};
@@ -231,6 +232,13 @@ static double price_one(const curve_t* c, work_t* w, int mf, const double* ftp, 
     return pv;
 }
 
+int adr_port_price_weighted(int K, int P, int method, const double* times, const double* dfs, const double* jac,
+                            const double* hess, int64_t n, const int64_t* fix_off, const int64_t* flt_off,
+                            const double* fix_tp, const double* fix_pay, const double* flt_tp, const double* flt_ts,
+                            const double* flt_te, const double* flt_alpha, const double* flt_weight,
+                            const double* notional, const double* spread, const double* fix_sign,
+                            const double* flt_sign, double* pv, double* delta, double* gamma, int n_threads);
+
 /* Returns 0, or -1 on bad arguments / a trade touching more than MAXLOC knots cannot occur silently:
  * the number of knots per trade is bounded by 2 + 6 * flows, checked up front. */
 int adr_port_price(int K, int P, int method, const double* times, const double* dfs, const double* jac,
@@ -239,6 +247,19 @@ int adr_port_price(int K, int P, int method, const double* times, const double* 
                    const double* flt_te, const double* flt_alpha, const double* notional, const double* spread,
                    const double* fix_sign, const double* flt_sign, double* pv, double* delta, double* gamma,
                    int n_threads) {
+    return adr_port_price_weighted(K, P, method, times, dfs, jac, hess, n, fix_off, flt_off, fix_tp, fix_pay, flt_tp,
+                                   flt_ts, flt_te, flt_alpha, NULL, notional, spread, fix_sign, flt_sign, pv, delta,
+                                   gamma, n_threads);
+}
+
+/* The same with a weight per float coupon multiplying its notional (NULL = all 1): the cross-currency foreign leg,
+ * whose coupons are discounted on another curve (engine.py:2639-2728 called with disc != index curve). */
+int adr_port_price_weighted(int K, int P, int method, const double* times, const double* dfs, const double* jac,
+                            const double* hess, int64_t n, const int64_t* fix_off, const int64_t* flt_off,
+                            const double* fix_tp, const double* fix_pay, const double* flt_tp, const double* flt_ts,
+                            const double* flt_te, const double* flt_alpha, const double* flt_weight,
+                            const double* notional, const double* spread, const double* fix_sign,
+                            const double* flt_sign, double* pv, double* delta, double* gamma, int n_threads) {
     if (K < 2 || P < 1 || (method != 1 && method != 4) || (gamma && !hess)) return -1;
     for (int64_t t = 0; t < n; ++t)
         if (2 + 2 * (fix_off[t + 1] - fix_off[t]) + 6 * (flt_off[t + 1] - flt_off[t]) > MAXLOC && K > MAXLOC)
@@ -264,7 +285,8 @@ int adr_port_price(int K, int P, int method, const double* times, const double* 
                 const int64_t f0 = fix_off[t], l0 = flt_off[t];
                 double v = price_one(&c, &w, (int)(fix_off[t + 1] - f0), fix_tp + f0, fix_pay + f0,
                                      (int)(flt_off[t + 1] - l0), flt_tp + l0, flt_ts + l0, flt_te + l0,
-                                     flt_alpha + l0, notional[t], spread[t], fix_sign[t], flt_sign[t],
+                                     flt_alpha + l0, flt_weight ? flt_weight + l0 : NULL, notional[t], spread[t],
+                                     fix_sign[t], flt_sign[t],
                                      delta ? delta + (size_t)t * P : NULL,
                                      gamma ? gamma + (size_t)t * P * P : NULL, tmp);
                 if (pv) pv[t] = v;

@@ -29,6 +29,9 @@ def _load():
         _lib.adr_port_price.restype = C.c_int
         _lib.adr_port_price.argtypes = ([C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, _ip, _ip]
                                         + [_dp] * 10 + [_dp, _dp, _dp, C.c_int])
+        _lib.adr_port_price_weighted.restype = C.c_int
+        _lib.adr_port_price_weighted.argtypes = ([C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, _ip, _ip]
+                                                 + [_dp] * 11 + [_dp, _dp, _dp, C.c_int])
         _lib.adr_port_max_threads.restype = C.c_int
     return _lib
 
@@ -55,10 +58,13 @@ def price(method, times, dfs, jac, hess, batch, want_delta=True, want_gamma=True
     pv = np.empty(n)
     delta = np.empty((n, P)) if (want_delta or want_gamma) else None
     gamma = np.empty((n, P, P)) if want_gamma else None
-    rc = lib.adr_port_price(K, P, int(method), _p(times), _p(dfs), _p(jac), _p(hess), n, _p(fo, _ip), _p(lo, _ip),
-                            _p(arr["fix_tp"]), _p(arr["fix_pay"]), _p(arr["flt_tp"]), _p(arr["flt_ts"]),
-                            _p(arr["flt_te"]), _p(arr["flt_alpha"]), _p(arr["notional"]), _p(arr["spread"]),
-                            _p(arr["fix_sign"]), _p(arr["flt_sign"]), _p(pv), _p(delta), _p(gamma), int(n_threads))
+    w = getattr(batch, "flt_weight", None)          # per-coupon weights of the cross-currency assembly, or None
+    w = None if w is None else f(w)
+    rc = lib.adr_port_price_weighted(K, P, int(method), _p(times), _p(dfs), _p(jac), _p(hess), n, _p(fo, _ip),
+                                     _p(lo, _ip), _p(arr["fix_tp"]), _p(arr["fix_pay"]), _p(arr["flt_tp"]),
+                                     _p(arr["flt_ts"]), _p(arr["flt_te"]), _p(arr["flt_alpha"]), _p(w),
+                                     _p(arr["notional"]), _p(arr["spread"]), _p(arr["fix_sign"]), _p(arr["flt_sign"]),
+                                     _p(pv), _p(delta), _p(gamma), int(n_threads))
     if rc != 0:
         raise RuntimeError("adr_port_price rejected its arguments")
     return dict(pv=pv, delta=delta, gamma=gamma)

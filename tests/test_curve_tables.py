@@ -83,3 +83,9 @@ def test_native_table_argument_checks(native_lib):
         _native.curve_tables_host(good["times"], np.array([1.0, -0.1, 0.9]), good["jac"])    # DF <= 0
     with pytest.raises(LibError):
         _native.curve_tables_host(good["times"], good["dfs"], np.zeros((3, 40)))             # too many pillars
+    with pytest.raises(LibError, match="value time"):
+        _native.curve_tables_host(np.array([0.5, 1.0, 2.0]), good["dfs"], good["jac"])       # grid not anchored at t = 0
+    with pytest.raises(LibError, match="value time"):
+        _native.curve_tables_host(good["times"], np.array([0.99, 0.95, 0.9]), good["jac"])   # D(0) != 1
+    with pytest.raises(LibError, match="no sensitivity"):
+        _native.curve_tables_host(good["times"], good["dfs"], np.full((3, 2), 0.1))

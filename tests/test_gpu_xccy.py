@@ -100,3 +100,72 @@ def test_linear_zero_rate_curves():
                         (CurveTypes.USD_GBP_BASIS, "delta_basis", "gamma_basis")):
         _close(res.risk(curve).risk_ladder, want[d], scale * 1e-4)
         _close(res.gamma(curve).risk_ladder, want[g], scale * 1e-6)
+
+
+def test_book_in_three_launches_per_trade_and_aggregate():
+    from adrates_amd.market.position.engine import Engine
+    from adrates_amd.market.position.xccy_engine import price_xccy_batch
+    m = _model()
+    book = [_swap("5Y", 0.0034), _swap("7Y", 0.0060, lag=2, notional=25_000_000),
+            _swap("10Y", 0.0030, freq=FrequencyTypes.SEMI_ANNUAL), _swap("4Y", 0.0040, effective=VALUE_DT.add_months(9)),
+            _swap("6Y", 0.0035, effective=VALUE_DT.add_months(-8)), _swap("20Y", 0.0045, freq=FrequencyTypes.QUARTERLY),
+            _swap("1Y", 0.0025)]
+    out = price_xccy_batch(Engine(m), book, {RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA},
+                           per_trade=True, aggregate=True)
+    gbp, usd, x = m.curves.GBP_OIS_SONIA, m.curves.USD_OIS_SOFR, m.curves.USD_GBP_BASIS
+    wants = [XO.xccy_analytics(s, VALUE_DT, _cache(gbp), gbp._interp_type.value, _cache(usd), usd._interp_type.value,
+                               x, times_from_dates) for s in book]
+    for i, (s, w) in enumerate(zip(book, wants)):
+        scale = abs(s._domestic_leg._notional)
+        _close(out["pv"][i], w["value"], scale)
+        for k in ("delta_dom", "delta_for", "delta_basis"):
+            _close(out[k][i], w[k], scale * 1e-4)
+        for k in ("gamma_dom", "gamma_for", "gamma_basis"):
+            _close(out[k][i], w[k], scale * 1e-6)
+    total = sum(abs(s._domestic_leg._notional) for s in book)
+    _close(out["agg_pv"], sum(w["value"] for w in wants), total)
+    for k in ("delta_dom", "delta_for", "delta_basis", "gamma_dom", "gamma_for", "gamma_basis"):
+        _close(out["agg_" + k], sum(w[k] for w in wants), total * 1e-4)
+    # delta-only request of BASELINE.json's config 3: same ladders, no gamma keys
+    d = price_xccy_batch(Engine(m), book, {RequestTypes.DELTA}, per_trade=True)
+    assert "gamma_dom" not in d and "pv" not in d
+    for k in ("delta_dom", "delta_for", "delta_basis"):
+        assert np.allclose(d[k], out[k], rtol=1e-12, atol=1e-9)
+
+
+def test_weighted_coupons_vs_c_oracle():
+    """adr_trades_upload_weighted on a mixed batch: weighted trades (with and without payment lag) go to the
+    general kernel, weight-1 trades of the same batch stay on the fast kernel."""
+    from adrates_amd import _native
+    from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
+    from adrates_amd.utils import BusDayAdjustTypes
+    from oracle import port
+    m, gbp, _ = _ois_curves()
+    host = build_engine_curve(gbp.swap_rates, gbp.swap_times, gbp.year_fracs)
+    ctx = _native.default_context()
+    dc = _native.DeviceCurve(ctx, gbp._interp_type.value, host.times, host.dfs, host.jac, host.hess)
+    rng = np.random.default_rng(21)
+    n = 3000
+    terms = OISTerms(effective_dt=VALUE_DT, tenor=[f"{int(k)}M" for k in rng.integers(1, 241, n)],
+                     coupon=rng.uniform(0.01, 0.07, n), notional=np.round(rng.uniform(1e6, 5e7, n), -5),
+                     pay_fixed=rng.random(n) < 0.5, fixed_freq_type=FrequencyTypes.ANNUAL,
+                     fixed_dc_type=DayCountTypes.ACT_365F, floating_index=CurveTypes.GBP_OIS_SONIA,
+                     currency=CurrencyTypes.GBP, float_freq_type=FrequencyTypes.SEMI_ANNUAL,
+                     float_dc_type=DayCountTypes.ACT_365F, float_spread=np.where(rng.random(n) < 0.3, 0.0015, 0.0),
+                     payment_lag=rng.choice([0, 2], size=n), bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
+    batch = compile_ois_terms(terms, VALUE_DT)
+    w = rng.uniform(0.2, 1.3, batch.flt_tp.size)
+    plain = np.repeat(rng.random(n) < 0.4, np.diff(batch.flt_off))      # 40 % of the trades keep weight 1
+    w[plain] = 1.0
+    batch.flt_weight = w
+    trades = _native.DeviceTrades(ctx, batch)
+    got = _native.price(ctx, dc, trades, aggregate=True)
+    ref = port.price(gbp._interp_type.value, host.times, host.dfs, host.jac, host.hess, batch)
+    from tests._parity import assert_batch_parity
+    assert_batch_parity(got, ref, batch.notional)
+    assert np.allclose(got["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
+    # the weights matter: the same batch without them prices differently
+    batch.flt_weight = None
+    unweighted = port.price(gbp._interp_type.value, host.times, host.dfs, host.jac, host.hess, batch)
+    assert np.max(np.abs(unweighted["pv"] - ref["pv"])) > 1.0
+    trades.close(); dc.close()

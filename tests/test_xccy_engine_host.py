@@ -1,0 +1,127 @@
+"""Host side of the cross-currency assembly (market/position/xccy_engine.py) without a GPU: the three trade
+batches it compiles are priced by the C restatement (oracle/port.c) standing in for the device calls, and the
+assembled ladders are compared with the torch-autodiff restatement of Engine._compute_xccy.  The same cases run
+through the HIP kernels in tests/test_gpu_xccy.py."""
+import numpy as np
+import pytest
+
+from adrates_amd import _native
+from adrates_amd.market.position import xccy_engine
+from adrates_amd.utils import CurveTypes, FrequencyTypes, RequestTypes
+from adrates_amd.utils.helpers import times_from_dates
+from oracle import port
+from oracle import xccy_oracle as XO
+from tests.test_gpu_xccy import VALUE_DT, _cache, _model, _swap
+
+CURVES = (CurveTypes.GBP_OIS_SONIA, CurveTypes.USD_OIS_SOFR, CurveTypes.USD_GBP_BASIS)
+
+
+class _HostCurve:
+    def __init__(self, ctx, method, times, dfs, jac, hess=None):
+        self.args = (method, np.asarray(times, float), np.asarray(dfs, float), np.asarray(jac, float),
+                     None if hess is None else np.asarray(hess, float))
+        self.n_pillars = np.asarray(jac).shape[1]
+
+
+class _HostTrades:
+    def __init__(self, ctx, batch):
+        self.batch, self.n_trades = batch, batch.n_trades
+
+    def close(self):
+        pass
+
+
+def _host_price(ctx, curve, trades, want_value=True, want_delta=True, want_gamma=True, per_trade=True, aggregate=False):
+    r = port.price(*curve.args, trades.batch, want_delta=want_delta, want_gamma=want_gamma)
+    out = dict(r) if per_trade else {}
+    if aggregate:
+        out.update(agg_pv=float(r["pv"].sum()), agg_delta=r["delta"].sum(0),
+                   agg_gamma=None if r["gamma"] is None else r["gamma"].sum(0))
+    return out
+
+
+@pytest.fixture()
+def host_engine(monkeypatch):
+    monkeypatch.setattr(_native, "DeviceCurve", _HostCurve)
+    monkeypatch.setattr(_native, "DeviceTrades", _HostTrades)
+    monkeypatch.setattr(_native, "price", _host_price)
+    monkeypatch.setattr(_native, "default_context", lambda: None)
+    return _model()
+
+
+def _book():
+    return [_swap("5Y", 0.0034), _swap("7Y", 0.0060, lag=2, notional=25_000_000),
+            _swap("10Y", 0.0030, freq=FrequencyTypes.SEMI_ANNUAL), _swap("4Y", 0.0040, effective=VALUE_DT.add_months(9)),
+            _swap("6Y", 0.0035, effective=VALUE_DT.add_months(-8))]
+
+
+def _oracle(m, swap):
+    gbp, usd, x = m.curves.GBP_OIS_SONIA, m.curves.USD_OIS_SOFR, m.curves.USD_GBP_BASIS
+    return XO.xccy_analytics(swap, VALUE_DT, _cache(gbp), gbp._interp_type.value, _cache(usd), usd._interp_type.value,
+                             x, times_from_dates)
+
+
+def test_single_swap_results_object(host_engine):
+    m = host_engine
+    swap = _book()[1]
+    res = swap.position(m).compute([RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA])
+    want = _oracle(m, swap)
+    scale = abs(swap._domestic_leg._notional)
+    assert abs(res.value.amount - want["value"]) <= 1e-10 * scale
+    for c, d, g in zip(CURVES, ("delta_dom", "delta_for", "delta_basis"), ("gamma_dom", "gamma_for", "gamma_basis")):
+        assert np.max(np.abs(res.risk(c).risk_ladder - want[d])) <= 1e-10 * scale * 1e-4
+        assert np.max(np.abs(res.gamma(c).risk_ladder - want[g])) <= 1e-10 * scale * 1e-6
+        assert len(res.risk(c).tenors) == len(want[d])
+    assert res.risk(CurveTypes.GBP_OIS_SONIA).currency.name == "GBP"
+
+
+def test_book_per_trade_and_aggregate(host_engine):
+    m = host_engine
+    book = _book()
+    from adrates_amd.market.position.engine import Engine
+    out = xccy_engine.price_xccy_batch(Engine(m), book, {RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA},
+                                       per_trade=True, aggregate=True)
+    wants = [_oracle(m, s) for s in book]
+    for i, (s, w) in enumerate(zip(book, wants)):
+        scale = abs(s._domestic_leg._notional)
+        assert abs(out["pv"][i] - w["value"]) <= 1e-10 * scale
+        for k in ("delta_dom", "delta_for", "delta_basis"):
+            assert np.max(np.abs(out[k][i] - w[k])) <= 1e-10 * scale * 1e-4
+        for k in ("gamma_dom", "gamma_for", "gamma_basis"):
+            assert np.max(np.abs(out[k][i] - w[k])) <= 1e-10 * scale * 1e-6
+    total = sum(abs(s._domestic_leg._notional) for s in book)
+    assert abs(out["agg_pv"] - sum(w["value"] for w in wants)) <= 1e-10 * total
+    for k in ("delta_dom", "delta_for", "delta_basis", "gamma_dom", "gamma_for", "gamma_basis"):
+        assert np.max(np.abs(out["agg_" + k] - sum(w[k] for w in wants))) <= 1e-10 * total * 1e-4
+
+
+def test_mixed_currency_pairs_are_refused(host_engine):
+    from adrates_amd.market.position.engine import Engine
+    from adrates_amd.utils import CurrencyTypes
+    from adrates_amd.utils.error import LibError
+    a, b = _book()[:2]
+    b._foreign_currency = CurrencyTypes.EUR
+    with pytest.raises(LibError, match="share"):
+        xccy_engine.price_xccy_batch(Engine(host_engine), [a, b], {RequestTypes.VALUE})
+
+
+def test_weighted_coupons_are_linear_in_the_weights():
+    """oracle/port.c's per-coupon weights against its own unweighted path: a weighted trade equals the sum of
+    its coupons priced one by one with notional N * w_j."""
+    from adrates_amd.trades.compiler import TradeBatch
+    m = _model()
+    c = _cache(m.curves.USD_OIS_SOFR)
+    rng = np.random.default_rng(3)
+    k = 9
+    ts = np.sort(rng.uniform(0.0, 12.0, k)); te = ts + rng.uniform(0.2, 1.1, k); tp = te + rng.choice([0.0, 0.01], k)
+    al = te - ts; w = rng.uniform(0.3, 1.2, k)
+    z = np.zeros(0)
+    one = TradeBatch(np.array([0, 0]), np.array([0, k]), z, z, tp, ts, te, al, np.array([3e6]), np.array([0.002]),
+                     np.array([1.0]), np.array([-1.0]), flt_weight=w)
+    each = TradeBatch(np.zeros(k + 1, dtype=np.int64), np.arange(k + 1), z, z, tp, ts, te, al, 3e6 * w,
+                      np.full(k, 0.002), np.ones(k), -np.ones(k))
+    a = port.price(1, c["times"], c["dfs"], c["jac"], c["hess"], one)
+    b = port.price(1, c["times"], c["dfs"], c["jac"], c["hess"], each)
+    assert np.isclose(a["pv"][0], b["pv"].sum(), rtol=1e-13)
+    assert np.allclose(a["delta"][0], b["delta"].sum(0), rtol=1e-12, atol=1e-9)
+    assert np.allclose(a["gamma"][0], b["gamma"].sum(0), rtol=1e-12, atol=1e-9)
