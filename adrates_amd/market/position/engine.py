@@ -75,8 +75,8 @@ class Engine:
                           else collateral_to_currency(collateral_type))
         if collateral_ccy == derivative._currency:
             return self._compute_ois_natural(derivative, reqs)
-        raise NotImplementedError("OIS with cross-currency collateral needs the XCCY curve path "
-                                  "(SURVEY.md section 8(f) rank 1), which is not built yet")
+        from .xccy_engine import compute_ois_xccy_collateral
+        return compute_ois_xccy_collateral(self, derivative, reqs, collateral_ccy)
 
     def _compute_ois_natural(self, derivative, reqs):
         ir_model = getattr(self.model.curves, derivative._floating_index.name)

@@ -243,6 +243,79 @@ def compute_xccy(engine, derivative, reqs):
     return AnalyticsResult(value=value, risk=delta, gamma=gamma)
 
 
+def compute_ois_xccy_collateral(engine, derivative, reqs, collateral_ccy):
+    """An OIS collateralised in another currency (`Engine._compute_ois_xccy_collateral`, engine.py:217-503):
+    both legs discounted on the ``{swap ccy}_{collateral ccy}_XCCY`` curve, forwards off the swap's own OIS curve,
+    PV and ladders converted to the collateral currency.  Pieces 2 and 3 of the assembly above with the OIS's
+    float leg in the foreign leg's role and its fixed coupons among the flows; every time in the fixed leg's day
+    count (:264-283).  Like the reference: no GAMMA (:489-494), CASHFLOWS is an empty table (:496-501)."""
+    model = engine.model
+    if RequestTypes.GAMMA in reqs:
+        raise NotImplementedError("GAMMA not yet supported for OIS with cross-currency collateral. "
+                                  "Only VALUE and DELTA are currently implemented.")
+    ois_model = getattr(model.curves, derivative._floating_index.name)
+    name = f"{derivative._currency.name}_{collateral_ccy.name}_XCCY"
+    try:
+        xccy = getattr(model.curves, name)
+    except AttributeError:
+        raise LibError(f"XCCY curve {name} not found in model. Required for cross-currency collateral valuation.")
+    spot = xccy._spot_fx
+    value_dt = model.value_dt
+    fx, fl = derivative._fixed_leg, derivative._float_leg
+    dc = fx._dc_type
+    x_times, x_dfs, x_method = np.asarray(xccy._times), np.asarray(xccy._dfs), xccy._interp_type.value
+    ois_cur = engine._device_curve(ois_model)
+    ctx, o_host = ois_cur["ctx"], ois_cur["host"]
+    o_method = ois_model._interp_type.value
+
+    tp, ts, te = (_times(d, value_dt, dc) for d in (fl._payment_dts, fl._start_accrued_dts, fl._end_accrued_dts))
+    al = np.asarray(fl._year_fracs, dtype=np.float64)
+    accrues, live = al > 0, tp >= 0.0
+    fwd = np.where(accrues, (knot_df(o_host.times, o_host.dfs, ts, o_method) / knot_df(o_host.times, o_host.dfs, te, o_method)
+                             - 1.0) / np.where(accrues, al, 1.0), 0.0)
+    amounts = _sign(fl) * (fwd + fl._spread) * al * fl._notional
+    fixed_tp = _times(fx._payment_dts, value_dt, dc)
+    fixed_pay = _sign(fx) * fx._cpn * np.asarray(fx._year_fracs, dtype=np.float64) * fx._notional
+    if fx._principal != 0.0 or fl._principal != 0.0:
+        raise LibError("principal payments are not supported on this path")     # every OIS has principal 0 (ois.py:149)
+    later, fixed_later = live & (tp > 0.0), fixed_tp > 0.0
+    pv_const = float(amounts[live & (tp == 0.0)].sum())          # paid at the value time: discount factor 1
+    none, one, zero = np.zeros(0), np.ones(1), np.zeros(1)
+    flow_tp, flow_pay = np.concatenate([tp[later], fixed_tp[fixed_later]]), np.concatenate([amounts[later], fixed_pay[fixed_later]])
+    flows = TradeBatch(np.array([0, flow_tp.size]), np.array([0, 0]), flow_tp, flow_pay, none, none, none, none,
+                       one, zero, one, one)
+    want_delta = RequestTypes.DELTA in reqs
+    has_jac = getattr(xccy, "_jac_basis", None) is not None
+    x_dev = getattr(xccy, "_adr_device_curve", None)
+    if x_dev is None:
+        jac = np.asarray(xccy._jac_basis) if has_jac else np.zeros((x_times.size, 1))
+        hess = getattr(xccy, "_hess_basis", None)
+        x_dev = _native.DeviceCurve(ctx, x_method, x_times, x_dfs, jac, None if (hess is None or not has_jac) else np.asarray(hess))
+        xccy._adr_device_curve = x_dev
+    on_x = _price(ctx, x_dev, flows, dict(want_value=True, want_delta=want_delta and has_jac, want_gamma=False))
+
+    value = delta = cashflows = None
+    if RequestTypes.VALUE in reqs:
+        value = Valuation(amount=float(on_x["pv"][0] + pv_const) / spot, currency=collateral_ccy)
+    if want_delta:
+        keep = live & accrues
+        weight = knot_df(x_times, x_dfs, tp[keep], x_method) / knot_df(x_times, x_dfs, 0.0, x_method)
+        m = int(keep.sum())
+        rates = TradeBatch(np.array([0, 0]), np.array([0, m]), none, none, np.zeros(m), ts[keep], te[keep], al[keep],
+                           np.array([fl._notional]), zero, one, np.array([_sign(fl)]), flt_weight=weight)
+        on_o = _price(ctx, ois_cur["dev"], rates, dict(want_value=False, want_delta=True, want_gamma=False))
+        ladders = [Delta(np.array(on_o["delta"][0]) / spot, to_tenor(list(ois_model.swap_times)), collateral_ccy,
+                         derivative._floating_index)]
+        if has_jac:
+            ladders.append(Delta(np.array(on_x["delta"][0]) / spot, to_tenor(list(xccy.swap_times)), collateral_ccy,
+                                 CurveTypes.USD_GBP_BASIS))
+        delta = Risk(ladders)
+    if RequestTypes.CASHFLOWS in reqs:
+        from ...requests.results import Cashflows
+        cashflows = Cashflows([], derivative._currency)
+    return AnalyticsResult(value=value, risk=delta, gamma=None, cashflows=cashflows)
+
+
 def _price(ctx, dev_curve, batch, kw):
     trades = _native.DeviceTrades(ctx, batch)
     try:

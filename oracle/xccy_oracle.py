@@ -196,3 +196,33 @@ def xccy_analytics(swap, value_dt, dom_cache, dom_method, for_cache, for_method,
     return dict(value=v_dom + v_for / spot, delta_dom=d_dom * 1e-4, delta_for=d_for * 1e-4 / spot,
                 delta_basis=d_bas * 1e-4 / spot, gamma_dom=g_dom * 1e-8, gamma_for=g_for * 1e-8 / spot,
                 gamma_basis=g_bas * 1e-8 / spot)
+
+
+def ois_xccy_collateral_analytics(swap, value_dt, ois_cache, ois_method, xccy_curve, times_from_dates):
+    """`Engine._compute_ois_xccy_collateral` (engine.py:217-503): an OIS discounted on an XCCY curve, forwards
+    off its own OIS curve; PV and the two delta ladders in collateral currency.  All times in the fixed leg's
+    day count (:264-283); the reference has no gamma for this path (:489-494)."""
+    spot = xccy_curve._spot_fx
+    fx, fl = swap._fixed_leg, swap._float_leg
+    receive = type(fx._leg_type).RECEIVE
+    dc = fx._dc_type
+    T = lambda dts: np.array([times_from_dates(d, value_dt, dc) for d in dts])
+    x_times, x_dfs, x_method = np.asarray(xccy_curve._times), np.asarray(xccy_curve._dfs), xccy_curve._interp_type.value
+    fixed_payments = fx._cpn * np.asarray(fx._year_fracs, dtype=np.float64) * fx._notional
+    fixed_tp, tp, ts, te = T(fx._payment_dts), T(fl._payment_dts), T(fl._start_accrued_dts), T(fl._end_accrued_dts)
+
+    def pv(x_d, o_d):
+        fixed = O.price_fixed_leg(x_d, x_times, x_method, fixed_tp, fixed_payments, fx._principal,
+                                  1.0 if fx._leg_type == receive else -1.0)
+        floating = float_leg_dual(x_d, x_times, x_method, o_d, ois_cache["times"], ois_method, tp, ts, te, fl._year_fracs,
+                                  fl._spread, fl._notional, 1.0 if fl._leg_type == receive else -1.0, False, 0.0, 0.0)
+        return fixed + floating
+
+    x_t = torch.as_tensor(x_dfs, dtype=_F64)
+    o_t = torch.as_tensor(np.asarray(ois_cache["dfs"]), dtype=_F64)
+    g_o = grad(lambda o: pv(x_t, o))(o_t)
+    g_x = grad(lambda x: pv(x, o_t))(x_t)
+    J_o = torch.as_tensor(np.asarray(ois_cache["jac"]), dtype=_F64)
+    J_x = torch.as_tensor(np.asarray(xccy_curve._jac_basis), dtype=_F64)
+    return dict(value=float(pv(x_t, o_t)) / spot, delta_ois=(g_o @ J_o).numpy() * 1e-4 / spot,
+                delta_basis=(g_x @ J_x).numpy() * 1e-4 / spot)

@@ -169,3 +169,9 @@ def test_weighted_coupons_vs_c_oracle():
     unweighted = port.price(gbp._interp_type.value, host.times, host.dfs, host.jac, host.hess, batch)
     assert np.max(np.abs(unweighted["pv"] - ref["pv"])) > 1.0
     trades.close(); dc.close()
+
+
+def test_ois_with_cross_currency_collateral():
+    """Engine._compute_ois_xccy_collateral (engine.py:217-503): the cases of the CPU host test on the kernels."""
+    from tests.test_xccy_engine_host import _collateral_model, check_ois_collateral
+    check_ois_collateral(_collateral_model())
