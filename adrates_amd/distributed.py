@@ -53,3 +53,34 @@ def allgather_sum_fixed_order(agg, group=None):
         total += p
     agg.copy_(total)
     return agg
+
+
+def shard_by_work(work, world_size: int):
+    """Contiguous ranges ``[(lo, hi)] * world_size`` of a list of items with per-item ``work`` (e.g. the coupons of
+    each cross-currency swap), balanced like `shard_bounds`."""
+    cum = np.concatenate(([0], np.cumsum(np.asarray(work, dtype=np.int64))))
+    zeros = np.zeros_like(cum)
+    return shard_bounds(cum, zeros, world_size)
+
+
+def allreduce_book(aggregates: dict, group=None, device=None):
+    """One all-reduce for a whole mixed book (BASELINE.json configs[4]): every ``agg_*`` entry of the result dicts
+    of `price_batch` / `price_xccy_batch` (scalars and arrays; other keys are left alone) is packed into a single
+    float64 buffer in sorted key order, summed over the ranks and unpacked in place.  ``device``: where the buffer
+    lives - the rank's GPU for the RCCL backend, None (CPU) for gloo."""
+    import torch
+    keys = sorted(k for k in aggregates if k.startswith("agg_"))
+    if not keys:
+        return aggregates
+    parts = [np.atleast_1d(np.asarray(aggregates[k], dtype=np.float64)).reshape(-1) for k in keys]
+    buf = torch.from_numpy(np.concatenate(parts))
+    if device is not None:
+        buf = buf.to(device)
+    allreduce_aggregate(buf, group)
+    flat = buf.cpu().numpy()
+    pos = 0
+    for k, p in zip(keys, parts):
+        v = flat[pos:pos + p.size].reshape(np.shape(aggregates[k]))
+        aggregates[k] = float(v) if np.ndim(aggregates[k]) == 0 else v.copy()
+        pos += p.size
+    return aggregates

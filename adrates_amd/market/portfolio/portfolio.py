@@ -28,15 +28,27 @@ class Portfolio:
         """Aggregate VALUE / DELTA / GAMMA over all positions."""
         reqs = set(request_list)
         groups = {}   # (model id, curve name, currency) -> positions, in first-seen order
+        singles = []  # everything that is not an OIS: priced one by one and added with `+`, as the reference does
         for pos in self._positions:
             d = pos.derivative
             if d.derivative_type != InstrumentTypes.OIS_SWAP:
-                # same error the per-position path raises
-                pos.compute(request_list)
+                singles.append(pos)
+                continue
             key = (id(pos.model), d._floating_index, d._currency)
             groups.setdefault(key, []).append(pos)
 
         total_val = total_delta = total_gamma = None
+        for pos in singles:
+            # cross-currency swaps return `Risk` containers, which have no `+` in the reference either
+            # (requests/results.py:839-942): two of them with DELTA / GAMMA raise TypeError there and here;
+            # books of XCCY swaps go through xccy_engine.price_xccy_batch(aggregate=True) instead
+            res = pos.compute(request_list)
+            if RequestTypes.VALUE in reqs:
+                total_val = res.value if total_val is None else total_val + res.value
+            if RequestTypes.DELTA in reqs:
+                total_delta = res.risk if total_delta is None else total_delta + res.risk
+            if RequestTypes.GAMMA in reqs:
+                total_gamma = res.gamma if total_gamma is None else total_gamma + res.gamma
         for (_, curve_type, currency), members in groups.items():
             model = members[0].model
             ir_model = getattr(model.curves, curve_type.name)

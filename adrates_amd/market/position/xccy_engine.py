@@ -166,6 +166,31 @@ def compile_xccy(swaps, value_dt, xccy, for_times, for_dfs, for_method):
     return domestic, foreign_rates, foreign_flows, pv_const, spot
 
 
+def _xccy_device_curve(ctx, xccy):
+    """The XCCY curve's tables as an `adr_curve` (cached on the curve object).  The fast kernel's packed layout
+    wants an even pillar count (16-byte gamma stores), so an odd basis ladder gets one all-zero pillar appended
+    here and dropped again from the results (`_trim`)."""
+    hit = getattr(xccy, "_adr_device_curve", None)
+    if hit is not None:
+        return hit
+    times, dfs = np.asarray(xccy._times, dtype=np.float64), np.asarray(xccy._dfs, dtype=np.float64)
+    jac = getattr(xccy, "_jac_basis", None)
+    hess = getattr(xccy, "_hess_basis", None) if jac is not None else None
+    jac = np.zeros((times.size, 2)) if jac is None else np.asarray(jac, dtype=np.float64)
+    hess = None if hess is None else np.asarray(hess, dtype=np.float64)
+    if jac.shape[1] % 2:
+        jac = np.pad(jac, ((0, 0), (0, 1)))
+        hess = None if hess is None else np.pad(hess, ((0, 0), (0, 1), (0, 1)))
+    xccy._adr_device_curve = _native.DeviceCurve(ctx, xccy._interp_type.value, times, dfs, jac, hess)
+    return xccy._adr_device_curve
+
+
+def _trim(a, kind, P):
+    """Drop the padding pillar of `_xccy_device_curve` from a delta ([..., P']) or gamma ([..., P', P']) array."""
+    a = np.asarray(a)
+    return a[..., :P] if kind == "delta" else a[..., :P, :P]
+
+
 def _curves(engine, swaps):
     model = engine.model
     first = swaps[0]
@@ -183,13 +208,7 @@ def _curves(engine, swaps):
     if getattr(xccy, "_jac_basis", None) is None:
         raise LibError("the XCCY curve carries no basis Jacobian (build it with use_ad=True)")
     dom_cur, for_cur = engine._device_curve(dom_model), engine._device_curve(for_model)
-    x_dev = getattr(xccy, "_adr_device_curve", None)
-    if x_dev is None:
-        hess = getattr(xccy, "_hess_basis", None)
-        x_dev = _native.DeviceCurve(dom_cur["ctx"], xccy._interp_type.value, np.asarray(xccy._times),
-                                    np.asarray(xccy._dfs), np.asarray(xccy._jac_basis),
-                                    None if hess is None else np.asarray(hess))
-        xccy._adr_device_curve = x_dev
+    x_dev = _xccy_device_curve(dom_cur["ctx"], xccy)
     return dom_model, for_model, xccy, dom_cur, for_cur, x_dev
 
 
@@ -221,7 +240,7 @@ def price_xccy_batch(engine, swaps, reqs, per_trade=True, aggregate=False):
         for kind in (("delta",) if want_delta else ()) + (("gamma",) if want_gamma else ()):
             out[f"{pre}{kind}_dom"] = np.asarray(dom[pre + kind])
             out[f"{pre}{kind}_for"] = np.asarray(rates[pre + kind]) / spot
-            out[f"{pre}{kind}_basis"] = np.asarray(frn[pre + kind]) / spot
+            out[f"{pre}{kind}_basis"] = _trim(frn[pre + kind], kind, len(xccy.swap_times)) / spot
     out["tenors"] = (to_tenor(list(dom_model.swap_times)), to_tenor(list(for_model.swap_times)),
                      to_tenor(list(xccy.swap_times)))
     return out
@@ -286,12 +305,7 @@ def compute_ois_xccy_collateral(engine, derivative, reqs, collateral_ccy):
                        one, zero, one, one)
     want_delta = RequestTypes.DELTA in reqs
     has_jac = getattr(xccy, "_jac_basis", None) is not None
-    x_dev = getattr(xccy, "_adr_device_curve", None)
-    if x_dev is None:
-        jac = np.asarray(xccy._jac_basis) if has_jac else np.zeros((x_times.size, 1))
-        hess = getattr(xccy, "_hess_basis", None)
-        x_dev = _native.DeviceCurve(ctx, x_method, x_times, x_dfs, jac, None if (hess is None or not has_jac) else np.asarray(hess))
-        xccy._adr_device_curve = x_dev
+    x_dev = _xccy_device_curve(ctx, xccy)
     on_x = _price(ctx, x_dev, flows, dict(want_value=True, want_delta=want_delta and has_jac, want_gamma=False))
 
     value = delta = cashflows = None
@@ -307,7 +321,8 @@ def compute_ois_xccy_collateral(engine, derivative, reqs, collateral_ccy):
         ladders = [Delta(np.array(on_o["delta"][0]) / spot, to_tenor(list(ois_model.swap_times)), collateral_ccy,
                          derivative._floating_index)]
         if has_jac:
-            ladders.append(Delta(np.array(on_x["delta"][0]) / spot, to_tenor(list(xccy.swap_times)), collateral_ccy,
+            ladders.append(Delta(_trim(on_x["delta"][0], "delta", len(xccy.swap_times)) / spot,
+                                 to_tenor(list(xccy.swap_times)), collateral_ccy,
                                  CurveTypes.USD_GBP_BASIS))
         delta = Risk(ladders)
     if RequestTypes.CASHFLOWS in reqs:
