@@ -186,3 +186,49 @@ def test_portfolio_with_cross_currency_positions(host_engine):
     assert one.risk(CurveTypes.USD_GBP_BASIS).risk_ladder.shape == (13,)
     with pytest.raises(TypeError):
         pf.compute([RequestTypes.DELTA])
+
+
+def test_ladders_against_bump_and_reprice(host_engine):
+    """The reference's own check of this path (tests/test_engine_basis_swap.py:152-332): each delta ladder against
+    central differences of VALUE under a 1 bp move of one quote, the other curves held as the engine holds them
+    (domestic / foreign: the XCCY curve object is reused; basis: the XCCY curve is re-bootstrapped)."""
+    from adrates_amd.utils import BusDayAdjustTypes, DayCountTypes, InterpTypes, SwapTypes
+    from tests.test_gpu_xccy import BASIS, GBP, SPOT, TENORS, USD
+
+    def model(gbp=GBP, usd=USD, basis=BASIS, reuse=None):
+        from adrates_amd.models.models import Model
+        m = Model(VALUE_DT)
+        for name, px, dc in (("GBP_OIS_SONIA", gbp, DayCountTypes.ACT_365F), ("USD_OIS_SOFR", usd, DayCountTypes.ACT_360)):
+            m.build_curve(name=name, px_list=list(px), tenor_list=TENORS, spot_days=0, swap_type=SwapTypes.PAY,
+                          fixed_dcc_type=dc, fixed_freq_type=FrequencyTypes.ANNUAL, float_freq_type=FrequencyTypes.ANNUAL,
+                          float_dc_type=dc, bus_day_type=BusDayAdjustTypes.MODIFIED_FOLLOWING,
+                          interp_type=InterpTypes.FLAT_FWD_RATES)
+        if reuse is not None:
+            m._curves_dict["USD_GBP_BASIS"] = reuse
+            setattr(m.curves, "USD_GBP_BASIS", reuse)
+        else:
+            m.build_xccy_curve(name="USD_GBP_BASIS", domestic_curve_name="GBP_OIS_SONIA", foreign_curve_name="USD_OIS_SOFR",
+                               basis_spreads=[b * 1e4 for b in basis], tenor_list=TENORS, spot_fx=SPOT,
+                               domestic_dc_type=DayCountTypes.ACT_365F, foreign_dc_type=DayCountTypes.ACT_360,
+                               interp_type=InterpTypes.FLAT_FWD_RATES)
+        return m
+
+    swap = _swap("7Y", 0.0060, notional=25_000_000, freq=FrequencyTypes.SEMI_ANNUAL)
+    value = lambda m: swap.position(m).compute([RequestTypes.VALUE]).value.amount
+    base = model()
+    x = base.curves.USD_GBP_BASIS
+    res = swap.position(base).compute([RequestTypes.VALUE, RequestTypes.DELTA])
+    h = 0.01                                             # quotes in percent: 1 bp
+    for curve, quotes, key in ((CurveTypes.GBP_OIS_SONIA, GBP, "gbp"), (CurveTypes.USD_OIS_SOFR, USD, "usd")):
+        ladder = res.risk(curve).risk_ladder
+        for i in (0, 3, 6, 7):
+            up, dn = list(quotes), list(quotes)
+            up[i] += h; dn[i] -= h
+            fd = (value(model(**{key: up}, reuse=x)) - value(model(**{key: dn}, reuse=x))) / 2.0
+            assert abs(fd - ladder[i]) <= 2e-6 * max(1.0, abs(ladder).max()), (curve, i, fd, ladder[i])
+    ladder = res.risk(CurveTypes.USD_GBP_BASIS).risk_ladder
+    for i in (2, 6, 7):
+        up, dn = list(BASIS), list(BASIS)
+        up[i] += 1e-4; dn[i] -= 1e-4                     # basis spreads are decimals: 1 bp = 1e-4
+        fd = (value(model(basis=up)) - value(model(basis=dn))) / 2.0
+        assert abs(fd - ladder[i]) <= 2e-6 * max(1.0, abs(ladder).max()), (i, fd, ladder[i])
