@@ -88,3 +88,35 @@ t0 = time.perf_counter()
 agg = _native.price(ctx, dc, dt, per_trade=False, aggregate=True)
 print(f"portfolio ladder of {n:,} trades (PV + delta + gamma, aggregated on the device) in "
       f"{1e3 * (time.perf_counter() - t0):.1f} ms: PV {agg['agg_pv']:,.0f}, delta {agg['agg_delta'].sum():,.1f}")
+
+# ---- cross-currency: a USD curve, the GBP/USD basis curve, a basis swap and an OIS under USD collateral
+from adrates_amd.trades.rates.xccy_basis_swap import XccyBasisSwap
+from adrates_amd.utils import CollateralType
+usd_px = [5.35, 5.32, 5.31, 5.29, 5.27, 5.25, 5.23, 5.21, 5.19, 5.17, 5.15, 5.13, 5.11, 5.09, 5.07, 4.95, 4.85, 4.70,
+          4.58, 4.48, 4.41, 4.36, 4.32, 4.29, 4.27, 4.28, 4.30, 4.32, 4.31, 4.29, 4.24, 4.18]
+model.build_curve(name="USD_OIS_SOFR", px_list=usd_px, tenor_list=tenor_list, spot_days=0, swap_type=SwapTypes.PAY,
+                  fixed_dcc_type=DayCountTypes.ACT_360, fixed_freq_type=FrequencyTypes.ANNUAL,
+                  float_freq_type=FrequencyTypes.ANNUAL, float_dc_type=DayCountTypes.ACT_360,
+                  bus_day_type=BusDayAdjustTypes.MODIFIED_FOLLOWING, interp_type=InterpTypes.FLAT_FWD_RATES)
+basis_tenors = ["1Y", "2Y", "3Y", "5Y", "7Y", "10Y", "15Y", "20Y", "30Y"]
+basis_bp = [25.0, 28.0, 30.0, 34.0, 36.0, 39.0, 42.0, 45.0, 48.0]
+for name, dom, frn, spreads, fx in (("USD_GBP_BASIS", "GBP_OIS_SONIA", "USD_OIS_SOFR", basis_bp, 0.79),
+                                    ("GBP_USD_XCCY", "USD_OIS_SOFR", "GBP_OIS_SONIA", [-b for b in basis_bp], 1 / 0.79)):
+    model.build_xccy_curve(name=name, domestic_curve_name=dom, foreign_curve_name=frn, basis_spreads=spreads,
+                           tenor_list=basis_tenors, spot_fx=fx,
+                           domestic_dc_type=DayCountTypes.ACT_365F if dom.startswith("GBP") else DayCountTypes.ACT_360,
+                           foreign_dc_type=DayCountTypes.ACT_360 if dom.startswith("GBP") else DayCountTypes.ACT_365F,
+                           interp_type=InterpTypes.FLAT_FWD_RATES)
+xccy = XccyBasisSwap(effective_dt=value_dt, term_dt_or_tenor="7Y", domestic_notional=7_900_000, foreign_notional=10_000_000,
+                     domestic_spread=0.0, foreign_spread=0.0040, domestic_freq_type=FrequencyTypes.ANNUAL,
+                     foreign_freq_type=FrequencyTypes.SEMI_ANNUAL, domestic_dc_type=DayCountTypes.ACT_365F,
+                     foreign_dc_type=DayCountTypes.ACT_360, domestic_floating_index=CurveTypes.GBP_OIS_SONIA,
+                     foreign_floating_index=CurveTypes.USD_OIS_SOFR, domestic_currency=CurrencyTypes.GBP,
+                     foreign_currency=CurrencyTypes.USD)
+x = xccy.position(model).compute([RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA])
+print(f"7Y GBP/USD basis swap: PV {x.value.amount:,.2f} GBP; delta per bp - SONIA {x.risk.GBP_OIS_SONIA.value.amount:,.2f}, "
+      f"SOFR {x.risk.USD_OIS_SOFR.value.amount:,.2f}, basis {x.risk.USD_GBP_BASIS.value.amount:,.2f}; "
+      f"basis gamma {x.gamma.USD_GBP_BASIS.value.amount:.4f}")
+c = swap.position(model).compute([RequestTypes.VALUE, RequestTypes.DELTA], collateral_type=CollateralType.USD)
+print(f"the 10Y OIS under USD collateral: PV {c.value.amount:,.2f} {c.value.currency.name} "
+      f"(vs {res.value.amount / 0.79:,.2f} converted at spot), basis delta {c.risk.USD_GBP_BASIS.value.amount:,.2f} per bp")
