@@ -139,11 +139,13 @@ struct Ladders {
 
 // Add the nodes held by the lanes in `mask` to the trade's ladders.  A node is NK (knot, weight) pairs
 // and a coefficient*exp() value `omega`; NK is 2 for plain nodes and 6 for ratio nodes.
-template <int NK, bool DELTA, bool GAMMA>
+// CF: the convexity coefficients of the entries come from `cf` (final values: the caller has summed the weights
+// of the nodes that share a knot) instead of omega * b; without CF the argument is ignored.
+template <int NK, bool DELTA, bool GAMMA, bool CF = false>
 __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k)[NK], const double (&b)[NK],
                                           double omega, const CurveLds& c, const double* __restrict__ lc_lanes,
                                           const unsigned long long* __restrict__ lc_block_mask,
-                                          double* vbuf, int lane, Ladders<GAMMA>& acc) {
+                                          double* vbuf, int lane, Ladders<GAMMA>& acc, const double (&cf)[NK]) {
     const int p = lane & 31;
     const int bi = lane >> 3, bj = lane & 7;
     while (mask) {
@@ -154,6 +156,9 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
         double bb[NK];
 #pragma unroll
         for (int i = 0; i < NK; ++i) { kk[i] = readlane_i(k[i], n); bb[i] = readlane_d(b[i], n); }
+        double cc[NK];
+#pragma unroll
+        for (int i = 0; i < NK; ++i) cc[i] = (CF && GAMMA) ? readlane_d(cf[i], n) : om * bb[i];
         double v = 0.0;
 #pragma unroll
         for (int i = 0; i < NK; ++i) v = fma(bb[i], c.lj[kk[i] * kPillarPad + p], v);
@@ -180,7 +185,7 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
             // curve-convexity part: sum_i om*b_i * LC[k_i]
 #pragma unroll
             for (int i = 0; i < NK; ++i) {
-                const double coef = om * bb[i];
+                const double coef = cc[i];
                 // most 4x4 blocks of LC_k are structurally zero (a knot depends on its bootstrap chain's
                 // pillars only): the lanes holding such a block skip the tile read
                 if (coef != 0.0 && ((lc_block_mask[kk[i]] >> lane) & 1ull)) {
@@ -199,7 +204,9 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
 }
 
 template <bool DELTA, bool GAMMA>
-__global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
+// Two blocks per CU fit in LDS (the curve tables are about 75 KB), i.e. two waves per SIMD: the register budget is
+// pinned to that (without the bound the gamma instantiation drifts to 256 VGPRs + AGPRs and one wave per SIMD).
+__global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS carve-up: doubles first (16-byte aligned base), then the int16 index tables
     double* s_x = reinterpret_cast<double*>(smem_raw);
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
                     omega = a_pay * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
                     acc.pv += omega;
                 }
-                add_nodes<2, DELTA, GAMMA>(__ballot(on), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+                add_nodes<2, DELTA, GAMMA>(__ballot(on), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b);
             }
             {   // unmerged start nodes
                 int k[2]; double b[2]; double omega = 0.0;
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
                     omega = sl * Nw * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
                     acc.pv += omega;
                 }
-                add_nodes<2, DELTA, GAMMA>(__ballot(own_start), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+                add_nodes<2, DELTA, GAMMA>(__ballot(own_start), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b);
             }
             const bool own_ratio = valid && ratio;
             if (__ballot(own_ratio)) {   // payment lag: N D(ts) D(tp) / D(te) keeps all three lookups
@@ -330,7 +337,39 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
                         for (int jx = 4; jx < 6; ++jx)
                             if (b[i] != 0.0 && k[i] == k[jx]) { b[jx] += b[i]; b[i] = 0.0; }
                 }
-                add_nodes<6, DELTA, GAMMA>(__ballot(own_ratio), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+                // Convexity per DATE instead of per coupon: coupon j's accrual start is usually coupon j-1's accrual
+                // end, bracketed by the same two knots - its start weights (+omega_j b) are handed to the previous
+                // lane's end / payment entries on those knots (-omega_{j-1} b'), so that each date's LC tiles are
+                // read once.
+                double cf[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) cf[i] = own_ratio ? omega * b[i] : 0.0;
+                if constexpr (GAMMA) {
+                    const bool prev_ratio = lane > 0 && __shfl_up(own_ratio ? 1 : 0, 1, 64) != 0;
+                    int pk[4];
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) pk[jx] = __shfl_up(k[2 + jx], 1, 64);
+                    double give[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        bool given = false;
+                        // payment entries first: with a payment lag inside one knot interval the end weights
+                        // have been folded into them, and adding to a live entry costs no extra tile read
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            const int jx = (o + 2) & 3;
+                            if (!given && own_ratio && prev_ratio && cf[i] != 0.0 && pk[jx] == k[i]) {
+                                give[jx] += cf[i]; cf[i] = 0.0; given = true;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) {
+                        const double got = __shfl_down(give[jx], 1, 64);
+                        if (lane < 63) cf[2 + jx] += got;
+                    }
+                }
+                add_nodes<6, DELTA, GAMMA, true>(__ballot(own_ratio), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf);
             }
         }
         // ---------------------------------------------------------------- fixed coupons not merged above
@@ -353,7 +392,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_general_kernel(CurveDev c
                 omega = a * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
                 acc.pv += omega;
             }
-            add_nodes<2, DELTA, GAMMA>(__ballot(on), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+            add_nodes<2, DELTA, GAMMA>(__ballot(on), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b);
         }
 
         // ---------------------------------------------------------------- results of this trade
