@@ -220,6 +220,8 @@ def price_xccy_batch(engine, swaps, reqs, per_trade=True, aggregate=False):
     everything in domestic currency, per bp / bp^2."""
     reqs = set(reqs)
     swaps = list(swaps)
+    if not swaps:
+        raise LibError("price_xccy_batch needs at least one swap (the book's currency pair names its curves)")
     dom_model, for_model, xccy, dom_cur, for_cur, x_dev = _curves(engine, swaps)
     ctx = dom_cur["ctx"]
     f_host = for_cur["host"]

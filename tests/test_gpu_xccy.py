@@ -175,3 +175,8 @@ def test_ois_with_cross_currency_collateral():
     """Engine._compute_ois_xccy_collateral (engine.py:217-503): the cases of the CPU host test on the kernels."""
     from tests.test_xccy_engine_host import _collateral_model, check_ois_collateral
     check_ois_collateral(_collateral_model())
+
+
+def test_matured_and_maturing_swaps():
+    from tests.test_xccy_engine_host import check_matured_and_maturing
+    check_matured_and_maturing(_model())

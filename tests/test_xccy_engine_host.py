@@ -232,3 +232,27 @@ def test_ladders_against_bump_and_reprice(host_engine):
         up[i] += 1e-4; dn[i] -= 1e-4                     # basis spreads are decimals: 1 bp = 1e-4
         fd = (value(model(basis=up)) - value(model(basis=dn))) / 2.0
         assert abs(fd - ladder[i]) <= 2e-6 * max(1.0, abs(ladder).max()), (i, fd, ladder[i])
+
+
+def test_matured_and_maturing_swaps(host_engine):
+    check_matured_and_maturing(host_engine)
+
+
+def check_matured_and_maturing(m):
+    """Edge cases of the masks (engine.py:2694 `>=`, :2706-2722): a swap that matured before the value date is worth
+    nothing and has empty ladders; one maturing today keeps its last coupon and final exchange (discount factor 1,
+    no sensitivity); an empty book is refused."""
+    from adrates_amd.market.position.engine import Engine
+    from adrates_amd.utils.error import LibError
+    gone = _swap(VALUE_DT.add_months(-1), 0.003, effective=VALUE_DT.add_months(-25))
+    today = _swap(VALUE_DT, 0.003, effective=VALUE_DT.add_months(-24))
+    live = _book()[0]
+    out = xccy_engine.price_xccy_batch(Engine(m), [gone, today, live], {RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA})
+    assert out["pv"][0] == 0.0
+    for k in ("delta_dom", "delta_for", "delta_basis", "gamma_dom", "gamma_for", "gamma_basis"):
+        assert not np.any(out[k][0]) and not np.any(out[k][1])
+    want = _oracle(m, today)
+    assert abs(want["value"]) > 100.0 and abs(out["pv"][1] - want["value"]) <= 1e-10 * abs(today._domestic_leg._notional)
+    assert abs(out["pv"][2] - _oracle(m, live)["value"]) <= 1e-10 * abs(live._domestic_leg._notional)
+    with pytest.raises(LibError, match="at least one"):
+        xccy_engine.price_xccy_batch(Engine(m), [], {RequestTypes.VALUE})
