@@ -32,6 +32,10 @@ def parse():
     ap.add_argument("--kind", default="offgrid", choices=["offgrid", "ongrid"])
     ap.add_argument("--interp", default="LINEAR_ZERO_RATES", choices=["LINEAR_ZERO_RATES", "FLAT_FWD_RATES"])
     ap.add_argument("--requests", default="value,delta,gamma")
+    ap.add_argument("--xccy-swaps", type=int, default=0,
+                    help="BASELINE configs[4]: add a book of this many GBP/USD basis swaps per GPU to every step "
+                         "(three more launches) and all-reduce all aggregate ladders in one buffer; 0 = the headline "
+                         "OIS workload only")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0,
                     help="approximate CPU time budget of the baseline leg (0 disables it)")
     return ap.parse_args()
@@ -111,7 +115,31 @@ def main():
     pv = torch.empty(n, dtype=torch.float64, device=dev)
     delta = torch.empty((n, P), dtype=torch.float64, device=dev) if want_delta else None
     gamma = torch.empty((n, P, P), dtype=torch.float64, device=dev) if want_gamma else None
-    agg = torch.zeros(1 + P + P * P, dtype=torch.float64, device=dev)
+
+    # optional mixed book (BASELINE configs[4]): a cross-currency book per GPU next to the OIS portfolio
+    xccy = []          # [(device trades, device curve, pv, delta, gamma, offset of its aggregate in `agg`)]
+    n_x = args.xccy_swaps
+    agg_len = 1 + P + P * P
+    if n_x > 0:
+        from adrates_amd.market.position.engine import Engine
+        from adrates_amd.trades import synthetic_xccy
+        from tests._fixtures import GBP_PX, TENORS, USD_PX
+        market = synthetic_xccy.build_market(README_VALUE_DT, GBP_PX, USD_PX, TENORS)
+        _native._default_ctx[local_rank] = ctx          # the engine uploads the book's curves through this rank's context
+        parts, _ = synthetic_xccy.synthesize_book(Engine(market), README_VALUE_DT, n_x, seed=synthetic.DEFAULT_SEED + 1000 + rank)
+        for b, cur in parts:
+            Px = cur.n_pillars
+            xccy.append((_native.DeviceTrades(ctx, b), cur, torch.empty(n_x, dtype=torch.float64, device=dev),
+                         torch.empty((n_x, Px), dtype=torch.float64, device=dev) if want_delta else None,
+                         torch.empty((n_x, Px, Px), dtype=torch.float64, device=dev) if want_gamma else None, agg_len))
+            agg_len += 1 + Px + Px * Px
+    # one buffer for every aggregate ladder of the step: a single all-reduce whatever the book holds
+    agg = torch.zeros(agg_len, dtype=torch.float64, device=dev)
+
+    def price_xccy():
+        for trades_x, cur, pv_x, de_x, ga_x, off in xccy:
+            _native.price_dev(ctx, cur, trades_x, mask, pv_x.data_ptr(), de_x.data_ptr() if de_x is not None else 0,
+                              ga_x.data_ptr() if ga_x is not None else 0, agg.data_ptr() + 8 * off, stream.cuda_stream)
     # a non-default torch stream: the kernels, the HIP events that time them and the RCCL all-reduce all
     # go to this one stream (torch.cuda.Event only sees the stream it is recorded on)
     stream = torch.cuda.Stream(dev)
@@ -121,8 +149,9 @@ def main():
         _native.price_dev(ctx, dev_curve, dev_trades, mask, pv.data_ptr(),
                           delta.data_ptr() if delta is not None else 0,
                           gamma.data_ptr() if gamma is not None else 0, agg.data_ptr(), stream.cuda_stream)
+        price_xccy()
         if world > 1:
-            dist.all_reduce(agg)   # the one exchange step: 1 + P + P*P doubles over RCCL/xGMI
+            dist.all_reduce(agg)   # the one exchange step: 1 + P + P*P doubles (per curve) over RCCL/xGMI
 
     def fence():
         if world > 1:
@@ -142,6 +171,7 @@ def main():
                           delta.data_ptr() if delta is not None else 0,
                           gamma.data_ptr() if gamma is not None else 0, agg.data_ptr(), stream.cuda_stream)
         b.record(stream)
+        price_xccy()
         if world > 1:
             dist.all_reduce(agg)
     fence()
@@ -155,7 +185,7 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * n * args.steps / elapsed
+        value = world * (n + n_x) * args.steps / elapsed
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "OIS trades/sec PV+delta+gamma, 32-pillar curve; achieved HBM GB/s",
@@ -174,7 +204,13 @@ def main():
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_bytes_per_trade": algo_bytes / n},
         }
-        if args.cpu_baseline_seconds > 0 and world == 1:
+        if n_x > 0:
+            line["metric"] = "OIS trades + XCCY swaps per second, PV+delta+gamma, aggregate ladders all-reduced"
+            line["config"]["workload"] += (f" + {n_x} GBP/USD basis swaps per GPU with SONIA / SOFR / basis ladders "
+                                           f"(BASELINE configs[4]; the roofline object is the OIS kernel alone)")
+            line["config"]["xccy_swaps_per_gpu"] = n_x
+            line["config"]["allreduce_doubles"] = agg_len
+        if args.cpu_baseline_seconds > 0 and world == 1 and n_x == 0:
             line["cpu_baseline"] = cpu_baseline(curve, README_VALUE_DT, interp.value, want_gamma,
                                                 args.cpu_baseline_seconds)
         print(json.dumps(line), flush=True)
