@@ -237,6 +237,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar loads of the header
+    const int knot0 = c.compact_of[0];                                    // the value-time knot (t = 0)
     double* vbuf = s_vbuf + wave * kPillarPad;
     const int P = cv.P;
     const double* __restrict__ lc_lanes = cv.lc_lanes;
@@ -301,7 +302,10 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
                     omega = a_pay * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
                     acc.pv += omega;
                 }
-                add_nodes<2, DELTA, GAMMA>(__ballot(on), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b);
+                // a node on the value-time knot alone (t = 0: D = 1, no sensitivity - build_curve_tables checks
+                // that) adds to the PV only; the cross-currency assembly pays every weighted coupon there
+                const bool flat = k[0] == knot0 && b[1] == 0.0;
+                add_nodes<2, DELTA, GAMMA>(__ballot(on && !flat), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b);
             }
             {   // unmerged start nodes
                 int k[2]; double b[2]; double omega = 0.0;
@@ -369,7 +373,17 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
                         if (lane < 63) cf[2 + jx] += got;
                     }
                 }
-                add_nodes<6, DELTA, GAMMA, true>(__ballot(own_ratio), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf);
+                // paid on the value-time knot alone (the cross-currency assembly): the payment entries carry no
+                // sensitivity, the node is its four accrual entries
+                const bool pay_flat = k[4] == knot0 && b[5] == 0.0;
+                add_nodes<6, DELTA, GAMMA, true>(__ballot(own_ratio && !pay_flat), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf);
+                const unsigned long long flat_mask = __ballot(own_ratio && pay_flat);
+                if (flat_mask) {
+                    int k4[4]; double b4[4], cf4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { k4[i] = k[i]; b4[i] = b[i]; cf4[i] = cf[i]; }
+                    add_nodes<4, DELTA, GAMMA, true>(flat_mask, k4, b4, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf4);
+                }
             }
         }
         // ---------------------------------------------------------------- fixed coupons not merged above
