@@ -13,6 +13,10 @@ python bench.py --trades 100000 --requests value,delta --cpu-baseline-seconds 0 
 python tools/ablate.py > gpurun_out/ablate_$TAG.log 2>&1 || exit 1
 python tools/bench_long_legs.py > gpurun_out/bench_${TAG}_long_legs.json 2>/dev/null || exit 1
 python tools/bench_curve_build.py > gpurun_out/bench_${TAG}_curve_build.json 2>/dev/null || exit 1
+python tools/bench_long_legs.py 200000 lag > gpurun_out/bench_${TAG}_payment_lag.json 2>/dev/null || exit 1
+python tools/bench_xccy.py 100000 3 > gpurun_out/bench_${TAG}_xccy.json 2>/dev/null || exit 1
+python tools/bench_xccy.py 100000 7 >> gpurun_out/bench_${TAG}_xccy.json 2>/dev/null || exit 1
+python bench.py --xccy-swaps 100000 --steps 10 --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_mixed_book.json 2>/dev/null || exit 1
 bash tools/profile.sh $TAG || exit 1
 bash tools/pmc.sh && python tools/pmc_summary.py > gpurun_out/pmc_$TAG.txt
 echo refresh-done
