@@ -249,6 +249,10 @@ def price_xccy_batch(engine, swaps, reqs, per_trade=True, aggregate=False):
 
 
 def compute_xccy(engine, derivative, reqs):
+    if RequestTypes.CASHFLOWS in reqs:
+        # the reference's block for this request (engine.py:1970-1986) ends in a NameError (`risk_ccy` is never
+        # assigned in _compute_xccy), so there is no behaviour to mirror
+        raise NotImplementedError("CASHFLOWS is not available for cross-currency swaps")
     res = price_xccy_batch(engine, [derivative], reqs)
     ccy = derivative._domestic_currency
     curves = (derivative._domestic_floating_index, derivative._foreign_floating_index, CurveTypes.USD_GBP_BASIS)

@@ -286,3 +286,8 @@ def test_synthetic_book_is_a_scaled_draw_of_the_templates(host_engine):
     assert np.array_equal(twice.notional, flows.notional[[4, 4, 1]] * [1.0, 2.0, 3.0])
     w = SX.take(rts, [5, 0], [1.0, 1.0])
     assert np.array_equal(w.flt_weight[:w.flt_off[1]], rts.flt_weight[rts.flt_off[5]:rts.flt_off[6]])
+
+
+def test_cashflows_request_is_refused_for_cross_currency_swaps(host_engine):
+    with pytest.raises(NotImplementedError, match="CASHFLOWS"):
+        _book()[0].position(host_engine).compute([RequestTypes.VALUE, RequestTypes.CASHFLOWS])
