@@ -292,21 +292,22 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
             bool own_start = valid && linear;
             if (own_start && j > 0 && f_tp[j - 1] == ts) own_start = false;
 
-            {   // payment nodes
-                int k[2]; double b[2]; double omega = 0.0;
-                const bool on = in && a_pay != 0.0;
-                k[0] = k[1] = 0; b[0] = b[1] = 0.0;
-                if (on) {
-                    const Lookup q = curve_lookup(c, tp);
-                    k[0] = q.ka; k[1] = q.kb; b[0] = q.ba; b[1] = q.bb;
-                    omega = a_pay * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
-                    acc.pv += omega;
-                }
-                // a node on the value-time knot alone (t = 0: D = 1, no sensitivity - build_curve_tables checks
-                // that) adds to the PV only; the cross-currency assembly pays every weighted coupon there
-                const bool flat = k[0] == knot0 && b[1] == 0.0;
-                add_nodes<2, DELTA, GAMMA>(__ballot(on && !flat), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b);
+            // payment node; its ladder work comes after the ratio nodes, which take over its convexity entries
+            int kp[2]; double bp[2], cfp[2]; double omega_p = 0.0;
+            const bool pay_on = in && a_pay != 0.0;
+            kp[0] = kp[1] = 0; bp[0] = bp[1] = 0.0;
+            Lookup qpay;
+            qpay.ka = qpay.kb = 0; qpay.ba = qpay.bb = 0.0;
+            if (pay_on || (valid && ratio)) qpay = curve_lookup(c, tp);
+            if (pay_on) {
+                kp[0] = qpay.ka; kp[1] = qpay.kb; bp[0] = qpay.ba; bp[1] = qpay.bb;
+                omega_p = a_pay * exp(fma(qpay.ba, c.log_df[qpay.ka], qpay.bb * c.log_df[qpay.kb]));
+                acc.pv += omega_p;
             }
+            cfp[0] = omega_p * bp[0]; cfp[1] = omega_p * bp[1];
+            // a node on the value-time knot alone (t = 0: D = 1, no sensitivity - build_curve_tables checks
+            // that) adds to the PV only; the cross-currency assembly pays every weighted coupon there
+            const bool pay_node = pay_on && !(kp[0] == knot0 && bp[1] == 0.0);
             {   // unmerged start nodes
                 int k[2]; double b[2]; double omega = 0.0;
                 k[0] = k[1] = 0; b[0] = b[1] = 0.0;
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
 #pragma unroll
                 for (int i = 0; i < 6; ++i) { k[i] = 0; b[i] = 0.0; }
                 if (own_ratio) {
-                    const Lookup qs = curve_lookup(c, ts), qe = curve_lookup(c, te), qp = curve_lookup(c, tp);
+                    const Lookup qs = curve_lookup(c, ts), qe = curve_lookup(c, te), qp = qpay;
                     k[0] = qs.ka; k[1] = qs.kb; b[0] = qs.ba; b[1] = qs.bb;
                     k[2] = qe.ka; k[3] = qe.kb; b[2] = -qe.ba; b[3] = -qe.bb;
                     k[4] = qp.ka; k[5] = qp.kb; b[4] = qp.ba; b[5] = qp.bb;
@@ -373,6 +374,12 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
                         if (lane < 63) cf[2 + jx] += got;
                     }
                 }
+                // the coupon's payment node sits on the same two knots as the ratio node's payment entries: one
+                // set of LC tiles serves both
+                if (own_ratio && pay_node) {
+                    cf[4] += cfp[0]; cf[5] += cfp[1];
+                    cfp[0] = cfp[1] = 0.0;
+                }
                 // paid on the value-time knot alone (the cross-currency assembly): the payment entries carry no
                 // sensitivity, the node is its four accrual entries
                 const bool pay_flat = k[4] == knot0 && b[5] == 0.0;
@@ -385,6 +392,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
                     add_nodes<4, DELTA, GAMMA, true>(flat_mask, k4, b4, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf4);
                 }
             }
+            add_nodes<2, DELTA, GAMMA, true>(__ballot(pay_node), kp, bp, omega_p, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cfp);
         }
         // ---------------------------------------------------------------- fixed coupons not merged above
         for (int base = 0; base < n_fix; base += 64) {
