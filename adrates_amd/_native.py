@@ -360,6 +360,16 @@ def curve_layout_host(times, dfs, jac, hess=None):
 _default_ctx = {}
 
 
+def set_default_context(ctx: Context, device: int | None = None) -> None:
+    """Make ``ctx`` the context `default_context` hands out (for hosts that create their own, e.g. one per rank)."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+        n = load().adr_device_count()
+        if n > 0:
+            device %= n
+    _default_ctx[device] = ctx
+
+
 def default_context(device: int | None = None) -> Context:
     """Process-wide context for ``device`` (default: LOCAL_RANK or 0)."""
     if device is None:

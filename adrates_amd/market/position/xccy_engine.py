@@ -156,10 +156,13 @@ def compile_xccy(swaps, value_dt, xccy, for_times, for_dfs, for_method):
     cnt = np.bincount(owner[later], minlength=n) + np.diff(exch.offsets())
     fix_off = np.concatenate(([0], np.cumsum(cnt))).astype(np.int64)
     flow_tp, flow_pay = np.empty(int(fix_off[-1])), np.empty(int(fix_off[-1]))
-    coupon_pos = fix_off[:-1][owner[later]] + (np.arange(later.sum()) - np.concatenate(([0], np.cumsum(np.bincount(owner[later], minlength=n))))[:-1][owner[later]])
+    c_owner = owner[later]                                  # sorted: the coupons are laid out swap by swap
+    c_first = np.concatenate(([0], np.cumsum(np.bincount(c_owner, minlength=n))))[:-1]
+    coupon_pos = fix_off[:-1][c_owner] + (np.arange(c_owner.size) - c_first[c_owner])     # from the swap's first slot
     flow_tp[coupon_pos], flow_pay[coupon_pos] = tp_x[later], amounts[later]
-    e_off, e_owner = exch.offsets(), np.repeat(np.arange(n), np.diff(exch.offsets()))
-    exch_pos = fix_off[1:][e_owner] - (e_off[1:][e_owner] - np.arange(e_off[-1]))
+    e_off = exch.offsets()
+    e_owner = np.repeat(np.arange(n), np.diff(e_off))
+    exch_pos = fix_off[1:][e_owner] - (e_off[1:][e_owner] - np.arange(e_off[-1]))         # back from its last slot
     flow_tp[exch_pos], flow_pay[exch_pos] = exch.col("tp"), exch.col("pay")
     foreign_flows = TradeBatch(fix_off, np.zeros(n + 1, dtype=np.int64), flow_tp, flow_pay, none, none, none, none,
                                for_n, zeros_n, for_s, for_s)

@@ -125,7 +125,7 @@ def main():
         from adrates_amd.trades import synthetic_xccy
         from tests._fixtures import GBP_PX, TENORS, USD_PX
         market = synthetic_xccy.build_market(README_VALUE_DT, GBP_PX, USD_PX, TENORS)
-        _native._default_ctx[local_rank] = ctx          # the engine uploads the book's curves through this rank's context
+        _native.set_default_context(ctx)                # the engine uploads the book's curves through this rank's context
         parts, _ = synthetic_xccy.synthesize_book(Engine(market), README_VALUE_DT, n_x, seed=synthetic.DEFAULT_SEED + 1000 + rank)
         for b, cur in parts:
             Px = cur.n_pillars
