@@ -80,7 +80,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # ADR_BENCH_FORCE_DIST=1 runs the process-group code path with a single rank (a one-GPU box can rehearse
+    # the collective calls the N > 1 runs make; needs MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE in the env)
+    use_dist = world > 1 or os.environ.get("ADR_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from adrates_amd import _native
@@ -150,11 +153,11 @@ def main():
                           delta.data_ptr() if delta is not None else 0,
                           gamma.data_ptr() if gamma is not None else 0, agg.data_ptr(), stream.cuda_stream)
         price_xccy()
-        if world > 1:
+        if use_dist:
             dist.all_reduce(agg)   # the one exchange step: 1 + P + P*P doubles (per curve) over RCCL/xGMI
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -172,14 +175,14 @@ def main():
                           gamma.data_ptr() if gamma is not None else 0, agg.data_ptr(), stream.cuda_stream)
         b.record(stream)
         price_xccy()
-        if world > 1:
+        if use_dist:
             dist.all_reduce(agg)
     fence()
     elapsed = time.perf_counter() - t0
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -215,7 +218,7 @@ def main():
                                                 args.cpu_baseline_seconds)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -47,3 +47,28 @@ def test_allreduce_of_the_aggregate_ladder_single_rank(gpu_ctx):
         assert b"adr_allreduce_agg" in _native.load().adr_last_error()
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+def test_bench_process_group_path_with_one_rank(tmp_path):
+    """bench.py's N > 1 code path (init_process_group("nccl"), all_reduce of the aggregate on the launch stream,
+    barrier, MAX over ranks) rehearsed with a single rank, and the JSON contract of its one output line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0", ADR_BENCH_FORCE_DIST="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--trades", "20000", "--steps", "3",
+                          "--warmup", "1", "--cpu-baseline-seconds", "0"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert d["value"] > 1e6 and d["roofline"]["bound"] == "hbm" and 0.0 < d["roofline"]["frac"] < 1.0
+    assert abs(d["value"] - 20000 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
