@@ -144,7 +144,7 @@ struct Ladders {
 template <int NK, bool DELTA, bool GAMMA, bool CF = false>
 __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k)[NK], const double (&b)[NK],
                                           double omega, const CurveLds& c, const double* __restrict__ lc_lanes,
-                                          const unsigned long long* __restrict__ lc_block_mask,
+                                          const unsigned long long* lc_block_mask,
                                           double* vbuf, int lane, Ladders<GAMMA>& acc, const double (&cf)[NK]) {
     const int p = lane & 31;
     const int bi = lane >> 3, bj = lane & 7;
@@ -214,7 +214,10 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
     double* s_invx = s_log + cv.Kc;
     double* s_lj = s_invx + cv.Kc;
     double* s_vbuf = s_lj + static_cast<size_t>(cv.Kc) * kPillarPad;
-    int16_t* s_first = reinterpret_cast<int16_t*>(s_vbuf + kWavesPerBlock * kPillarPad);
+    // per-knot masks of the structurally non-zero LC blocks: read before every tile, so LDS-resident (a global
+    // read here would put a second L2 round trip in front of each tile)
+    unsigned long long* s_lcmask = reinterpret_cast<unsigned long long*>(s_vbuf + kWavesPerBlock * kPillarPad);
+    int16_t* s_first = reinterpret_cast<int16_t*>(s_lcmask + (GAMMA ? cv.Kc : 0));
     int16_t* s_comp = s_first + cv.K;
     int16_t* s_lut = s_comp + cv.K;                      // [kLutMax][2] reserved
 
@@ -226,6 +229,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
     for (int i = threadIdx.x; i < cv.Kc; i += kBlockThreads) {
         s_log[i] = cv.log_df[i];
         s_invx[i] = cv.inv_x[i];
+        if (GAMMA) s_lcmask[i] = cv.lc_block_mask[i];
     }
     for (int i = threadIdx.x; i < 2 * cv.n_lut; i += kBlockThreads) s_lut[i] = cv.lut[i];
     for (int i = threadIdx.x; i < cv.Kc * kPillarPad; i += kBlockThreads) s_lj[i] = cv.lj[i];
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
     double* vbuf = s_vbuf + wave * kPillarPad;
     const int P = cv.P;
     const double* __restrict__ lc_lanes = cv.lc_lanes;
-    const unsigned long long* __restrict__ lc_block_mask = cv.lc_block_mask;
+    const unsigned long long* lc_block_mask = s_lcmask;
 
     Ladders<GAMMA> total;   // this wave's share of the portfolio aggregate
     total.clear();
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
 }  // namespace
 
 size_t general_kernel_lds_bytes(int K, int Kc) {
-    size_t tables = sizeof(double) * (static_cast<size_t>(K) + 2 * Kc + static_cast<size_t>(Kc) * kPillarPad +
+    size_t tables = sizeof(double) * (static_cast<size_t>(K) + 3 * Kc + static_cast<size_t>(Kc) * kPillarPad +
                                       kWavesPerBlock * kPillarPad) + sizeof(int16_t) * (2 * static_cast<size_t>(K) + 2 * kLutMax);
     size_t reduce = sizeof(double) * kWavesPerBlock * kAggStride;
     size_t need = tables > reduce ? tables : reduce;
