@@ -163,3 +163,26 @@ def test_oracle_reproduces_golden_vectors():
             assert r["value"] == pytest.approx(row["pv"], rel=1e-13, abs=1e-9)
             assert np.allclose(r["delta"], row["delta"], rtol=1e-12, atol=1e-12)
             assert np.allclose(r["gamma"], np.array(row["gamma"]), rtol=1e-12, atol=1e-16)
+
+
+def test_notebook_non_ad_valuation_outputs_bit_for_bit():
+    """notebooks/intro.ipynb cells 23-29: the 1W calibration swap through `OISCurve`'s own nodes and the legs'
+    non-AD `value()` - par rate, PV, PV01 by `bump()` and PV under the 10Y-shocked
+    scenario model, each equal to the printed repr.  (The notebook's OIS call predates the `floating_index` /
+    `currency` arguments; they are the GBP ones here.)"""
+    from adrates_amd.trades.rates.ois import OIS
+    from adrates_amd.utils import (BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes,
+                                   SwapTypes)
+    vd = F.README_VALUE_DT
+    model = F.readme_model()
+    curve = model.curves.GBP_OIS_SONIA
+    swap = OIS(effective_dt=vd.add_weekdays(0), term_dt_or_tenor="1W", fixed_leg_type=SwapTypes.PAY,
+               fixed_coupon=5.2014 / 100, fixed_freq_type=FrequencyTypes.ANNUAL, fixed_dc_type=DayCountTypes.ACT_365F,
+               floating_index=CurveTypes.GBP_OIS_SONIA, currency=CurrencyTypes.GBP,
+               bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING, float_freq_type=FrequencyTypes.ANNUAL,
+               float_dc_type=DayCountTypes.ACT_365F)
+    assert swap.swap_rate(vd, curve) * 10000 == 5.201400000000243          # cell 23
+    assert swap.value(vd, curve) == 4.672529030358419e-11                  # cell 25
+    assert swap.pv01(vd, curve) == 1.9158970567491285                      # cell 27
+    bumped = model.scenario("GBP_OIS_SONIA", {"10Y": 0.01})
+    assert swap.value(vd, bumped.curves.GBP_OIS_SONIA) == 4.672529030358419e-11   # cell 29
