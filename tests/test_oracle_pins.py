@@ -186,3 +186,36 @@ def test_notebook_non_ad_valuation_outputs_bit_for_bit():
     assert swap.pv01(vd, curve) == 1.9158970567491285                      # cell 27
     bumped = model.scenario("GBP_OIS_SONIA", {"10Y": 0.01})
     assert swap.value(vd, bumped.curves.GBP_OIS_SONIA) == 4.672529030358419e-11   # cell 29
+
+
+@pytest.mark.parametrize("which", ["base", "bump_10Y_1bp"])
+def test_notebook_curve_tables_all_rows(readme, which):
+    """Cells 12 and 20 in full (tests/golden/notebook_curve_tables.json, extracted by make_notebook_table.py): the
+    32-row table of the README curve and of its 10Y + 1 bp scenario.  Tenor, last accrual fraction and rate
+    columns are the curve's inputs to the engine and must match to the printed digits.  The DF
+    column of that notebook is one row late (row i shows pillar i - 1's value, row 0 the 1.0 of t = 0) and was
+    produced when the curve's own bootstrap still used each swap's own rate for its intermediate coupons - which
+    is what the ENGINE grid does today (row B): every printed value equals the engine-grid DF of its pillar, and
+    the curve's own nodes agree up to the 10Y pillar, before the first tenor gap."""
+    from adrates_amd.market.curves.curve_tables import build_engine_curve
+    table = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "notebook_curve_tables.json")))[which]
+    rows = np.array(table["rows"])
+    assert rows.shape == (32, 4)
+    model = readme[0] if which == "base" else readme[0].scenario("GBP_OIS_SONIA", {"10Y": 0.01})
+    curve = model.curves.GBP_OIS_SONIA
+    for i in range(32):
+        assert rows[i, 0] == round(curve.swap_times[i], 4)
+        assert rows[i, 1] == round(curve.year_fracs[i][-1], 4)
+        assert rows[i, 2] == round(curve.swap_rates[i], 4)
+    assert rows[0, 3] == 1.0
+    for name, (t, d) in (("oracle", (lambda c: (c["times"], c["dfs"]))(O.cached_curve(curve.swap_rates, curve.swap_times, curve.year_fracs))),
+                         ("product", (lambda h: (h.times, h.dfs))(build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)))):
+        for i in range(1, 32):
+            knot = int(np.searchsorted(t, curve.swap_times[i - 1]))        # first knot of the cluster: the pillar's own swap
+            assert abs(t[knot] - curve.swap_times[i - 1]) < 1e-9
+            assert round(float(d[knot]), 4) == pytest.approx(rows[i, 3], abs=1e-12), (name, i)
+    for i in range(1, 26):
+        assert round(float(curve._repr_dfs[i]), 4) == pytest.approx(rows[i, 3], abs=1e-12)
+    if which == "bump_10Y_1bp":
+        base = np.array(json.load(open(os.path.join(os.path.dirname(__file__), "golden", "notebook_curve_tables.json")))["base"]["rows"])
+        assert np.flatnonzero(np.abs(base - rows).max(axis=1) > 0).tolist() == [24, 25]    # the 10Y rate row, its DF one row late
