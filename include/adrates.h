@@ -207,7 +207,9 @@ int adr_price(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades,
  * Same, with device-resident outputs and no host synchronisation: the kernels
  * are enqueued on `stream` (a hipStream_t; NULL = the ctx's own stream) and the
  * call returns immediately.  Output pointers are device memory owned by the
- * caller.  This is the entry the throughput benchmark times.
+ * caller.  This is the entry the throughput benchmark times.  The call neither
+ * allocates nor synchronises, so a sequence of them (a scenario ladder, the pieces
+ * of a cross-currency book) can be captured on `stream` into a HIP graph and replayed.
  */
 int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades,
                   uint32_t req_mask,

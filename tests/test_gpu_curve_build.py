@@ -125,3 +125,40 @@ def test_plan_rejects_bad_inputs(gpu_ctx):
         cset.close()
     finally:
         plan.close()
+
+
+def test_price_dev_calls_can_be_captured_into_a_hip_graph():
+    """adr_price_dev neither allocates nor synchronises: a bump ladder of pricing calls captured on a stream into a
+    HIP graph (torch.cuda.CUDAGraph) replays to the same bits as the eager launches."""
+    import torch
+    from adrates_amd import _native
+    from adrates_amd.market.position.scenarios import ScenarioGrid, bump_ladder
+    from adrates_amd.trades import synthetic
+    from tests._fixtures import README_VALUE_DT, TENORS, readme_model
+    grid = ScenarioGrid(readme_model(), "GBP_OIS_SONIA", bump_ladder(TENORS[:6], 1.0), with_gamma=True)
+    n, S, P = 500, len(grid), 32
+    trades = _native.DeviceTrades(grid._ctx, synthetic.synthesize(README_VALUE_DT, n, seed=5))
+    dev = torch.device("cuda", 0)
+    pv = torch.zeros((S, n), dtype=torch.float64, device=dev)
+    delta = torch.zeros((S, n, P), dtype=torch.float64, device=dev)
+    agg = torch.zeros((S, 1 + P + P * P), dtype=torch.float64, device=dev)
+    stream = torch.cuda.Stream(dev)
+
+    def launch_all():
+        for i in range(S):
+            _native.price_dev(grid._ctx, grid.device_curve(i), trades, 7, pv[i].data_ptr(), delta[i].data_ptr(), 0,
+                              agg[i].data_ptr(), stream.cuda_stream)
+
+    with torch.cuda.stream(stream):
+        launch_all()
+        stream.synchronize()
+        eager = (pv.clone(), delta.clone(), agg.clone())
+        pv.zero_(); delta.zero_(); agg.zero_()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            launch_all()
+        graph.replay()
+        stream.synchronize()
+    assert torch.equal(pv, eager[0]) and torch.equal(delta, eager[1]) and torch.equal(agg, eager[2])
+    assert float(pv.abs().max()) > 0.0
+    trades.close(); grid.close()
