@@ -211,9 +211,10 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
                      const double* jac, const double* hess, adr_curve** out) {
     if (!ctx || !out) return fail(ADR_ERR_INVALID, "adr_curve_upload: null ctx/out");
     *out = nullptr;
-    if (interp_method != ADR_INTERP_FLAT_FWD_RATES && interp_method != ADR_INTERP_LINEAR_ZERO_RATES)
-        return fail(ADR_ERR_UNSUPPORTED,
-                    "adr_curve_upload: only FLAT_FWD_RATES (1) and LINEAR_ZERO_RATES (4) are implemented");
+    if (interp_method != ADR_INTERP_FLAT_FWD_RATES && interp_method != ADR_INTERP_LINEAR_ZERO_RATES &&
+        interp_method != ADR_INTERP_LINEAR_FWD_RATES)
+        return fail(ADR_ERR_UNSUPPORTED, "adr_curve_upload: only FLAT_FWD_RATES (1), LINEAR_FWD_RATES (2) and "
+                                         "LINEAR_ZERO_RATES (4) are implemented");
     if (P > ADR_MAX_PILLARS)
         return fail(ADR_ERR_UNSUPPORTED, "adr_curve_upload: more than ADR_MAX_PILLARS pillars");
     adr::CurveTables t;
@@ -269,7 +270,9 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     c->dev.x = d_x; c->dev.log_df = d_log; c->dev.inv_x = d_invx; c->dev.lj = d_lj; c->dev.lc_lanes = d_lc; c->dev.lc_block_mask = d_lcmask;
     c->dev.first_of = d_first; c->dev.compact_of = d_comp; c->dev.lut = d_lut; c->dev.n_lut = static_cast<int>(t.lut.size() / 2);
     // the fast kernels store the [P][P] matrices as 16-byte pairs of the flat array: P must be even
-    c->dev.packed_ok = (t.packed_ok && t.P % 2 == 0) ? 1 : 0;
+    // LINEAR_FWD_RATES is linear in the knot DFs, not in their logs: only the general kernel carries the extra
+    // Hessian term (kernels_general.hip, `Lookup`)
+    c->dev.packed_ok = (t.packed_ok && t.P % 2 == 0 && interp_method != ADR_INTERP_LINEAR_FWD_RATES) ? 1 : 0;
     c->dev.Pc = t.Pc; c->dev.pc_pad = t.pc_pad; c->dev.Ec = t.Ec; c->dev.Eu = t.Eu; c->dev.epg = t.epg; c->dev.cpg = t.cpg; c->dev.hub = t.hub ? 1 : 0;
     c->dev.Kcore = t.Kcore; c->dev.n_mini = t.n_mini;
     c->dev.ljc = d_ljc; c->dev.lcc = d_lcc; c->dev.mini = d_mini; c->dev.knot_class = d_class;
@@ -299,9 +302,10 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
                           const double* base_jac, const double* base_hess, adr_curve_plan** out) {
     if (!ctx || !out) return fail(ADR_ERR_INVALID, "adr_curve_plan_create: null ctx/out");
     *out = nullptr;
-    if (interp_method != ADR_INTERP_FLAT_FWD_RATES && interp_method != ADR_INTERP_LINEAR_ZERO_RATES)
-        return fail(ADR_ERR_UNSUPPORTED,
-                    "adr_curve_plan_create: only FLAT_FWD_RATES (1) and LINEAR_ZERO_RATES (4) are implemented");
+    if (interp_method != ADR_INTERP_FLAT_FWD_RATES && interp_method != ADR_INTERP_LINEAR_ZERO_RATES &&
+        interp_method != ADR_INTERP_LINEAR_FWD_RATES)
+        return fail(ADR_ERR_UNSUPPORTED, "adr_curve_plan_create: only FLAT_FWD_RATES (1), LINEAR_FWD_RATES (2) and "
+                                         "LINEAR_ZERO_RATES (4) are implemented");
     if (P > ADR_MAX_PILLARS) return fail(ADR_ERR_UNSUPPORTED, "adr_curve_plan_create: more than ADR_MAX_PILLARS pillars");
     if (!acc || !pillar || !prev_idx) return fail(ADR_ERR_INVALID, "adr_curve_plan_create: null scan arrays");
     for (int k = 0; k < K; ++k) {
@@ -366,7 +370,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
 
     adr::CurveBuildPlanDev& d = plan->dev;
     d.K = K; d.P = P; d.Kc = t.Kc; d.acc = d_acc; d.pillar = d_pil; d.prev_idx = d_prev; d.knot_index = d_kidx;
-    d.packed_ok = (t.packed_ok && t.P % 2 == 0) ? 1 : 0;
+    d.packed_ok = (t.packed_ok && t.P % 2 == 0 && interp_method != ADR_INTERP_LINEAR_FWD_RATES) ? 1 : 0;   // as in adr_curve_upload
     d.Pc = t.Pc; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Kcore = t.Kcore; d.n_mini = t.n_mini;
     d.knot_class = d_class; d.core_pillars = d_core; d.lcc_pq = d_lccpq;
 

@@ -67,10 +67,16 @@ struct CurveLds {
     int method;
 };
 
-// One discount-factor lookup: D(t) = exp(ba*L[ka] + bb*L[kb]); ka/kb are rows of the compact tables.
+// One discount-factor lookup.  FLAT_FWD / LINEAR_ZERO: D(t) = exp(ba*L[ka] + bb*L[kb]); ka/kb are rows of the
+// compact tables.  LINEAR_FWD_RATES is linear in the knot DFs themselves, D = (1-w) d_a + w d_b: its log-gradient
+// is the convex combination rho_a LJ[ka] + rho_b LJ[kb] with rho_a = (1-w) d_a / D, so the same node machinery
+// applies with (ba, bb) = (rho_a, rho_b), plus a rank-one correction rho_a rho_b (LJ[ka] - LJ[kb])(...)^T in the
+// Hessian of ln D (`kappa` = rho_a rho_b; 0 for the log-linear schemes).
 struct Lookup {
     int ka, kb;
     double ba, bb;
+    double ln_d;     // ln D(t)
+    double kappa;
 };
 
 // InterpolatorAd.simple_interpolate for one time (interpolator_ad.py:210-243) in weight form.
@@ -94,8 +100,10 @@ __device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
         if (dh < best_dist) { best_dist = dh; best = j; }
     }
     Lookup r;
+    r.kappa = 0.0;
     if (best_dist < 1e-10) {            // exact grid point: that knot's DF, gradient to that knot only
         r.ka = c.compact_of[best]; r.kb = 0; r.ba = 1.0; r.bb = 0.0;
+        r.ln_d = c.log_df[r.ka];
         return r;
     }
     const double tau = t + 1e-12;
@@ -104,6 +112,7 @@ __device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
         const int k = tau < c.x[0] ? 0 : K - 1;
         r.ka = c.compact_of[k]; r.kb = 0; r.bb = 0.0;
         r.ba = lzr ? t * c.inv_x[r.ka] : 1.0;
+        r.ln_d = r.ba * c.log_df[r.ka];
         return r;
     }
     // no knot lies in (t, t + 1e-12] (it would have snapped), so searchsorted(tau, 'right') == j
@@ -114,6 +123,15 @@ __device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
     const double w = (fabs(dx) <= 0x1p-104) ? 0.0 : (tau - xa) / dx;
     r.ka = c.compact_of[i - 1];
     r.kb = c.compact_of[i];
+    if (c.method == 2) {                 // LINEAR_FWD_RATES (interpolator_ad.py:234-235)
+        const double da = exp(c.log_df[r.ka]), db = exp(c.log_df[r.kb]);
+        const double d = da + w * (db - da);
+        r.bb = w * db / d;
+        r.ba = 1.0 - r.bb;
+        r.kappa = r.ba * r.bb;
+        r.ln_d = log(d);
+        return r;
+    }
     if (lzr) {
         r.ba = t * (1.0 - w) * c.inv_x[r.ka];
         r.bb = t * w * c.inv_x[r.kb];
@@ -121,6 +139,7 @@ __device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
         r.ba = 1.0 - w;
         r.bb = w;
     }
+    r.ln_d = fma(r.ba, c.log_df[r.ka], r.bb * c.log_df[r.kb]);
     return r;
 }
 
@@ -203,6 +222,23 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
     }
 }
 
+// LINEAR_FWD_RATES: the rank-one term a discount factor that is linear in its two knot DFs adds to the Hessian,
+// weight * (LJ[ka] - LJ[kb]) (LJ[ka] - LJ[kb])^T with weight = (term value) * (+1 numerator / -1 denominator) * kappa
+// (see `Lookup`).  It has no first-order and no convexity part, so it runs as a node without DELTA and with zero
+// convexity coefficients.
+template <bool GAMMA>
+__device__ __forceinline__ void add_df_correction(bool on, int ka, int kb, double weight, const CurveLds& c,
+                                                  const double* __restrict__ lc_lanes,
+                                                  const unsigned long long* lc_block_mask, double* vbuf, int lane,
+                                                  Ladders<GAMMA>& acc) {
+    if constexpr (GAMMA) {
+        const int k2[2] = {ka, kb};
+        const double b2[2] = {1.0, -1.0}, none[2] = {0.0, 0.0};
+        const double om = on ? weight : 0.0;
+        add_nodes<2, false, true, true>(__ballot(om != 0.0), k2, b2, om, c, lc_lanes, lc_block_mask, vbuf, lane, acc, none);
+    }
+}
+
 template <bool DELTA, bool GAMMA>
 // Two blocks per CU fit in LDS (the curve tables are about 75 KB), i.e. two waves per SIMD: the register budget is
 // pinned to that (without the bound the gamma instantiation drifts to 256 VGPRs + AGPRs and one wave per SIMD).
@@ -242,6 +278,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar loads of the header
     const int knot0 = c.compact_of[0];                                    // the value-time knot (t = 0)
+    const bool linear_df = cv.method == 2;                                // LINEAR_FWD_RATES: see `Lookup`
     double* vbuf = s_vbuf + wave * kPillarPad;
     const int P = cv.P;
     const double* __restrict__ lc_lanes = cv.lc_lanes;
@@ -301,11 +338,11 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
             const bool pay_on = in && a_pay != 0.0;
             kp[0] = kp[1] = 0; bp[0] = bp[1] = 0.0;
             Lookup qpay;
-            qpay.ka = qpay.kb = 0; qpay.ba = qpay.bb = 0.0;
+            qpay.ka = qpay.kb = 0; qpay.ba = qpay.bb = 0.0; qpay.ln_d = 0.0; qpay.kappa = 0.0;
             if (pay_on || (valid && ratio)) qpay = curve_lookup(c, tp);
             if (pay_on) {
                 kp[0] = qpay.ka; kp[1] = qpay.kb; bp[0] = qpay.ba; bp[1] = qpay.bb;
-                omega_p = a_pay * exp(fma(qpay.ba, c.log_df[qpay.ka], qpay.bb * c.log_df[qpay.kb]));
+                omega_p = a_pay * exp(qpay.ln_d);
                 acc.pv += omega_p;
             }
             cfp[0] = omega_p * bp[0]; cfp[1] = omega_p * bp[1];
@@ -315,27 +352,37 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
             {   // unmerged start nodes
                 int k[2]; double b[2]; double omega = 0.0;
                 k[0] = k[1] = 0; b[0] = b[1] = 0.0;
+                double kap = 0.0;
                 if (own_start) {
                     const Lookup q = curve_lookup(c, ts);
-                    k[0] = q.ka; k[1] = q.kb; b[0] = q.ba; b[1] = q.bb;
-                    omega = sl * Nw * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
+                    k[0] = q.ka; k[1] = q.kb; b[0] = q.ba; b[1] = q.bb; kap = q.kappa;
+                    omega = sl * Nw * exp(q.ln_d);
                     acc.pv += omega;
                 }
                 add_nodes<2, DELTA, GAMMA>(__ballot(own_start), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b);
+                if (linear_df) add_df_correction<GAMMA>(own_start, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
             }
             const bool own_ratio = valid && ratio;
             if (__ballot(own_ratio)) {   // payment lag: N D(ts) D(tp) / D(te) keeps all three lookups
                 int k[6]; double b[6]; double omega = 0.0;
+                int kc[6]; double kap[3] = {0.0, 0.0, 0.0};    // LINEAR_FWD: the lookups' own knots and correction weights
 #pragma unroll
-                for (int i = 0; i < 6; ++i) { k[i] = 0; b[i] = 0.0; }
+                for (int i = 0; i < 6; ++i) { k[i] = 0; b[i] = 0.0; kc[i] = 0; }
                 if (own_ratio) {
                     const Lookup qs = curve_lookup(c, ts), qe = curve_lookup(c, te), qp = qpay;
                     k[0] = qs.ka; k[1] = qs.kb; b[0] = qs.ba; b[1] = qs.bb;
                     k[2] = qe.ka; k[3] = qe.kb; b[2] = -qe.ba; b[3] = -qe.bb;
                     k[4] = qp.ka; k[5] = qp.kb; b[4] = qp.ba; b[5] = qp.bb;
                     double l = 0.0;
+                    if (linear_df) {
+                        l = qs.ln_d - qe.ln_d + qp.ln_d;
+                        kap[0] = qs.kappa; kap[1] = -qe.kappa; kap[2] = qp.kappa;
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) l = fma(b[i], c.log_df[k[i]], l);
+                        for (int i = 0; i < 6; ++i) kc[i] = k[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) l = fma(b[i], c.log_df[k[i]], l);
+                    }
                     omega = sl * Nw * exp(l);
                     acc.pv += omega;
                     // te and tp are a few days apart and usually bracketed by the same knots: fold the te weights
@@ -395,8 +442,14 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
                     for (int i = 0; i < 4; ++i) { k4[i] = k[i]; b4[i] = b[i]; cf4[i] = cf[i]; }
                     add_nodes<4, DELTA, GAMMA, true>(flat_mask, k4, b4, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf4);
                 }
+                if (linear_df) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        add_df_correction<GAMMA>(own_ratio, kc[2 * q], kc[2 * q + 1], omega * kap[q], c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+                }
             }
             add_nodes<2, DELTA, GAMMA, true>(__ballot(pay_node), kp, bp, omega_p, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cfp);
+            if (linear_df) add_df_correction<GAMMA>(pay_node, kp[0], kp[1], omega_p * qpay.kappa, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
         }
         // ---------------------------------------------------------------- fixed coupons not merged above
         for (int base = 0; base < n_fix; base += 64) {
@@ -412,13 +465,15 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
             }
             int k[2]; double b[2]; double omega = 0.0;
             k[0] = k[1] = 0; b[0] = b[1] = 0.0;
+            double kap = 0.0;
             if (on) {
                 const Lookup q = curve_lookup(c, tp);
-                k[0] = q.ka; k[1] = q.kb; b[0] = q.ba; b[1] = q.bb;
-                omega = a * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
+                k[0] = q.ka; k[1] = q.kb; b[0] = q.ba; b[1] = q.bb; kap = q.kappa;
+                omega = a * exp(q.ln_d);
                 acc.pv += omega;
             }
             add_nodes<2, DELTA, GAMMA>(__ballot(on), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b);
+            if (linear_df) add_df_correction<GAMMA>(on, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
         }
 
         // ---------------------------------------------------------------- results of this trade

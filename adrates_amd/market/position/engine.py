@@ -28,7 +28,7 @@ from ...utils.global_types import InstrumentTypes, InterpTypes, RequestTypes, Sw
 from ...utils.helpers import to_tenor
 from ..curves.curve_tables import build_engine_curve
 
-_SUPPORTED_INTERP = (InterpTypes.FLAT_FWD_RATES.value, InterpTypes.LINEAR_ZERO_RATES.value)
+_SUPPORTED_INTERP = (InterpTypes.FLAT_FWD_RATES.value, InterpTypes.LINEAR_FWD_RATES.value, InterpTypes.LINEAR_ZERO_RATES.value)
 
 
 class Engine:

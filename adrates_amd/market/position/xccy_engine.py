@@ -50,6 +50,8 @@ def knot_df(times, dfs, t, method: int):
         out = np.exp(-np.interp(tau, x, -np.log(d) / np.maximum(x, 1e-15)) * tt)
     elif method == InterpTypes.FLAT_FWD_RATES.value:
         out = np.exp(-np.interp(tau, x, -np.log(d)))
+    elif method == InterpTypes.LINEAR_FWD_RATES.value:
+        out = np.interp(tau, x, d)
     else:
         raise LibError("Invalid interpolation scheme.")
     out = np.where(snapped, d[k], out)

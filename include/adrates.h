@@ -50,6 +50,7 @@ typedef enum adr_status {
  * (cavour/utils/global_types.py:76-84) accepted by simple_interpolate
  * (cavour/market/curves/interpolator_ad.py:227-235). */
 #define ADR_INTERP_FLAT_FWD_RATES 1
+#define ADR_INTERP_LINEAR_FWD_RATES 2   /* linear in the knot DFs: priced by the general kernel */
 #define ADR_INTERP_LINEAR_ZERO_RATES 4
 
 /* Request mask bits: RequestTypes.VALUE / DELTA / GAMMA (cavour/utils/global_types.py:69-74). */

@@ -83,7 +83,7 @@ static void interpolate(const curve_t* c, double t, df_t* r) {
     const int lzr = c->method == 4;
     if (tau < x[0] || tau > x[K - 1]) {
         int k = tau < x[0] ? 0 : K - 1;
-        set_power(r, c, k, lzr ? t / fmax(x[k], 1e-15) : 1.0, -1, 0.0);
+        set_power(r, c, k, lzr ? t / fmax(x[k], 1e-15) : 1.0, -1, 0.0);   /* LINEAR_FWD: the end knot's DF, flat */
         return;
     }
     int i = upper_bound(x, K, tau);
@@ -91,6 +91,13 @@ static void interpolate(const curve_t* c, double t, df_t* r) {
     if (i > K - 1) i = K - 1;
     const double dx = x[i] - x[i - 1];
     const double w = fabs(dx) <= 0x1p-104 ? 0.0 : (tau - x[i - 1]) / dx;
+    if (c->method == 2) {        /* LINEAR_FWD_RATES (interpolator_ad.py:234-235): linear in the knot DFs themselves */
+        r->v = c->d[i - 1] + w * (c->d[i] - c->d[i - 1]);
+        r->n = 2; r->k[0] = i - 1; r->k[1] = i;
+        r->d1[0] = 1.0 - w; r->d1[1] = w;
+        r->d2[0][0] = r->d2[0][1] = r->d2[1][0] = r->d2[1][1] = 0.0;
+        return;
+    }
     if (lzr) set_power(r, c, i - 1, t * (1.0 - w) / fmax(x[i - 1], 1e-15), i, t * w / fmax(x[i], 1e-15));
     else set_power(r, c, i - 1, 1.0 - w, i, w);
 }
@@ -260,7 +267,7 @@ int adr_port_price_weighted(int K, int P, int method, const double* times, const
                             const double* flt_te, const double* flt_alpha, const double* flt_weight,
                             const double* notional, const double* spread, const double* fix_sign,
                             const double* flt_sign, double* pv, double* delta, double* gamma, int n_threads) {
-    if (K < 2 || P < 1 || (method != 1 && method != 4) || (gamma && !hess)) return -1;
+    if (K < 2 || P < 1 || (method != 1 && method != 2 && method != 4) || (gamma && !hess)) return -1;
     for (int64_t t = 0; t < n; ++t)
         if (2 + 2 * (fix_off[t + 1] - fix_off[t]) + 6 * (flt_off[t + 1] - flt_off[t]) > MAXLOC && K > MAXLOC)
             return -1;

@@ -28,7 +28,7 @@ def _device_curve(ctx, curve):
     return host, _native.DeviceCurve(ctx, curve._interp_type.value, host.times, host.dfs, host.jac, host.hess)
 
 
-@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES])
+@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES, InterpTypes.LINEAR_FWD_RATES])
 @pytest.mark.parametrize("kind", ["offgrid", "ongrid"])
 def test_synthetic_portfolio_vs_c_oracle(gpu_ctx, interp, kind):
     vd = F.README_VALUE_DT
@@ -204,7 +204,7 @@ def test_full_size_properties(gpu_ctx, n):
     assert torch.equal(pv3, 2.0 * pv) and torch.equal(de3, 2.0 * de) and torch.equal(ga3, 2.0 * ga)
 
 
-@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES])
+@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES, InterpTypes.LINEAR_FWD_RATES])
 def test_payment_lag_portfolio_vs_c_oracle(gpu_ctx, interp):
     """Payment-lag trades (accrual end != payment time: ratio terms) and more-than-32-coupon trades go to the
     general kernel, the rest of the same batch to the fast kernel; both launches write into the same outputs."""

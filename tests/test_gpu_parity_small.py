@@ -10,7 +10,7 @@ from ._parity import assert_parity, gpu_price, oracle_price
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES])
+@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES, InterpTypes.LINEAR_FWD_RATES])
 def test_readme_curve_mixed_trades(gpu_ctx, interp):
     vd = F.README_VALUE_DT
     model = F.gbp_model(vd, interp)
@@ -106,7 +106,7 @@ def test_even_pillar_count_below_32_uses_the_fast_kernel(gpu_ctx):
     assert np.allclose(got["agg_delta"], got["delta"].sum(0), rtol=1e-12, atol=1e-9)
 
 
-@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES])
+@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES, InterpTypes.LINEAR_FWD_RATES])
 def test_seasoned_and_expired_trades(gpu_ctx, interp):
     """Trades that started before the value date: past payments are masked (float: payment time >= 0, fixed:
     > 0, engine.py:2437, :2695), the running coupon's accrual start lies left of the first knot, and a fully
@@ -121,3 +121,35 @@ def test_seasoned_and_expired_trades(gpu_ctx, interp):
     got = gpu_price(gpu_ctx, curve, swaps, vd)
     assert_parity(got, oracle_price(curve, swaps, vd), [s._notional for s in swaps])
     assert got["pv"][4] == 0.0 and not got["delta"][4].any() and not got["gamma"][4].any()
+
+
+def test_linear_fwd_rates_through_the_python_api_and_scenario_grid(gpu_ctx):
+    """LINEAR_FWD_RATES (interpolator_ad.py:234-235, linear in the knot DFs): `position(model).compute()` and a
+    scenario grid on such a curve - the general kernel with the extra rank-one Hessian term of a linear DF."""
+    from adrates_amd.market.position.scenarios import ScenarioGrid
+    from adrates_amd.utils import RequestTypes
+    from adrates_amd.utils.helpers import times_from_dates
+    from oracle import cavour_oracle as O
+    vd = F.README_VALUE_DT
+    model = F.gbp_model(vd, InterpTypes.LINEAR_FWD_RATES)
+    curve = model.curves.GBP_OIS_SONIA
+    swaps = [F.make_swap(vd, "87M", 0.04, 1e7, pay=False), F.make_swap(vd, "3Y", 0.04, 1e6, payment_lag=2)]
+    cache = O.cached_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    for swap in swaps:
+        res = swap.position(model).compute([RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA])
+        fx, fl = O.leg_inputs_from_swap(swap, vd, times_from_dates)
+        want = O.ois_analytics(cache, curve._interp_type.value, fx, fl)
+        n = swap._notional
+        assert abs(res.value.amount - want["value"]) <= 1e-10 * n
+        assert np.max(np.abs(res.risk.risk_ladder - want["delta"])) <= 1e-10 * n * 1e-4
+        assert np.max(np.abs(res.gamma.risk_ladder - want["gamma"])) <= 1e-10 * n * 1e-6
+    # the linear scheme really is a different function of the knots
+    lzr = swaps[0].position(F.gbp_model(vd, InterpTypes.LINEAR_ZERO_RATES)).compute([RequestTypes.VALUE]).value.amount
+    assert abs(lzr - swaps[0].position(model).compute([RequestTypes.VALUE]).value.amount) > 1.0
+    grid = ScenarioGrid(model, "GBP_OIS_SONIA", [0.0, {"10Y": 0.01}], with_gamma=True)
+    out = grid.price(swaps, [RequestTypes.VALUE, RequestTypes.DELTA])
+    base = swaps[0].position(model).compute([RequestTypes.VALUE, RequestTypes.DELTA])
+    assert abs(out["pv"][0, 0] - base.value.amount) <= 1e-10 * swaps[0]._notional
+    bumped = swaps[0].position(model.scenario("GBP_OIS_SONIA", {"10Y": 0.01})).compute([RequestTypes.VALUE])
+    assert abs(out["pv"][1, 0] - bumped.value.amount) <= 1e-10 * swaps[0]._notional
+    grid.close()

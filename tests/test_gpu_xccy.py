@@ -80,15 +80,16 @@ def test_value_only_and_missing_curve():
         swap.position(bare).compute([RequestTypes.VALUE])
 
 
-def test_linear_zero_rate_curves():
-    """All three curves on LINEAR_ZERO_RATES (interpolator_ad.py:217-226)."""
+@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.LINEAR_FWD_RATES])
+def test_other_interpolation_schemes_on_all_three_curves(interp):
+    """All three curves on LINEAR_ZERO_RATES / LINEAR_FWD_RATES (interpolator_ad.py:227-235)."""
     m, _, _ = _ois_curves()
     for name in ("GBP_OIS_SONIA", "USD_OIS_SOFR"):
-        getattr(m.curves, name)._interp_type = InterpTypes.LINEAR_ZERO_RATES
+        getattr(m.curves, name)._interp_type = interp
     m.build_xccy_curve(name="USD_GBP_BASIS", domestic_curve_name="GBP_OIS_SONIA", foreign_curve_name="USD_OIS_SOFR",
                        basis_spreads=[b * 1e4 for b in BASIS], tenor_list=TENORS, spot_fx=SPOT,
                        domestic_dc_type=DayCountTypes.ACT_365F, foreign_dc_type=DayCountTypes.ACT_360,
-                       interp_type=InterpTypes.LINEAR_ZERO_RATES)
+                       interp_type=interp)
     swap = _swap("8Y", 0.0045, effective=VALUE_DT.add_months(-5), freq=FrequencyTypes.SEMI_ANNUAL)
     res = swap.position(m).compute([RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA])
     gbp, usd, x = m.curves.GBP_OIS_SONIA, m.curves.USD_OIS_SOFR, m.curves.USD_GBP_BASIS

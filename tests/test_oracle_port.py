@@ -12,7 +12,7 @@ from . import _fixtures as F
 from ._parity import oracle_price, trade_errors
 
 
-@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES])
+@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES, InterpTypes.LINEAR_FWD_RATES])
 def test_port_matches_ad_oracle(interp):
     vd = F.README_VALUE_DT
     curve = F.gbp_model(vd, interp).curves.GBP_OIS_SONIA

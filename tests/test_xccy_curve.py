@@ -122,7 +122,7 @@ def test_model_build_xccy_curve():
         m.build_xccy_curve("X", "EUR_OIS_ESTR", "GBP_OIS_SONIA", [1.0], ["5Y"], 1.1)
 
 
-@pytest.mark.parametrize("method", [InterpTypes.FLAT_FWD_RATES, InterpTypes.LINEAR_ZERO_RATES])
+@pytest.mark.parametrize("method", [InterpTypes.FLAT_FWD_RATES, InterpTypes.LINEAR_ZERO_RATES, InterpTypes.LINEAR_FWD_RATES])
 def test_knot_df_matches_the_oracle_interpolation(built, method):
     """The XCCY engine's host-side discount factors (xccy_engine.knot_df) against the restatement of
     InterpolatorAd.simple_interpolate: knots, near-knots, interior points and both ends of the grid."""

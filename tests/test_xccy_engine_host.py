@@ -291,3 +291,11 @@ def test_synthetic_book_is_a_scaled_draw_of_the_templates(host_engine):
 def test_cashflows_request_is_refused_for_cross_currency_swaps(host_engine):
     with pytest.raises(NotImplementedError, match="CASHFLOWS"):
         _book()[0].position(host_engine).compute([RequestTypes.VALUE, RequestTypes.CASHFLOWS])
+
+
+def test_linear_fwd_rates_on_all_three_curves(host_engine):
+    """The assembly under LINEAR_FWD_RATES (linear in the knot DFs): the host supplies D_x and the forwards with
+    `knot_df`, the kernels' stand-in (oracle/port.c) differentiates the linear scheme."""
+    import tests.test_gpu_xccy as G
+    from adrates_amd.utils import InterpTypes
+    G.test_other_interpolation_schemes_on_all_three_curves(InterpTypes.LINEAR_FWD_RATES)
