@@ -239,7 +239,9 @@ __device__ __forceinline__ void add_df_correction(bool on, int ka, int kb, doubl
     }
 }
 
-template <bool DELTA, bool GAMMA>
+// LINDF: the curve interpolates with LINEAR_FWD_RATES (a compile-time switch: the state of the corrections would
+// otherwise cost the log-linear instantiations registers - measured +9 % on the gamma paths)
+template <bool DELTA, bool GAMMA, bool LINDF>
 // Two blocks per CU fit in LDS (the curve tables are about 75 KB), i.e. two waves per SIMD: the register budget is
 // pinned to that (without the bound the gamma instantiation drifts to 256 VGPRs + AGPRs and one wave per SIMD).
 __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar loads of the header
     const int knot0 = c.compact_of[0];                                    // the value-time knot (t = 0)
-    const bool linear_df = cv.method == 2;                                // LINEAR_FWD_RATES: see `Lookup`
+    constexpr bool linear_df = LINDF;                                     // LINEAR_FWD_RATES: see `Lookup`
     double* vbuf = s_vbuf + wave * kPillarPad;
     const int P = cv.P;
     const double* __restrict__ lc_lanes = cv.lc_lanes;
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
             if (pay_on || (valid && ratio)) qpay = curve_lookup(c, tp);
             if (pay_on) {
                 kp[0] = qpay.ka; kp[1] = qpay.kb; bp[0] = qpay.ba; bp[1] = qpay.bb;
-                omega_p = a_pay * exp(qpay.ln_d);
+                omega_p = a_pay * exp(linear_df ? qpay.ln_d : fma(qpay.ba, c.log_df[qpay.ka], qpay.bb * c.log_df[qpay.kb]));
                 acc.pv += omega_p;
             }
             cfp[0] = omega_p * bp[0]; cfp[1] = omega_p * bp[1];
@@ -356,11 +358,11 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
                 if (own_start) {
                     const Lookup q = curve_lookup(c, ts);
                     k[0] = q.ka; k[1] = q.kb; b[0] = q.ba; b[1] = q.bb; kap = q.kappa;
-                    omega = sl * Nw * exp(q.ln_d);
+                    omega = sl * Nw * exp(linear_df ? q.ln_d : fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
                     acc.pv += omega;
                 }
                 add_nodes<2, DELTA, GAMMA>(__ballot(own_start), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b);
-                if (linear_df) add_df_correction<GAMMA>(own_start, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+                if constexpr (linear_df) add_df_correction<GAMMA>(own_start, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
             }
             const bool own_ratio = valid && ratio;
             if (__ballot(own_ratio)) {   // payment lag: N D(ts) D(tp) / D(te) keeps all three lookups
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
                     k[2] = qe.ka; k[3] = qe.kb; b[2] = -qe.ba; b[3] = -qe.bb;
                     k[4] = qp.ka; k[5] = qp.kb; b[4] = qp.ba; b[5] = qp.bb;
                     double l = 0.0;
-                    if (linear_df) {
+                    if constexpr (linear_df) {
                         l = qs.ln_d - qe.ln_d + qp.ln_d;
                         kap[0] = qs.kappa; kap[1] = -qe.kappa; kap[2] = qp.kappa;
 #pragma unroll
@@ -442,14 +444,14 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
                     for (int i = 0; i < 4; ++i) { k4[i] = k[i]; b4[i] = b[i]; cf4[i] = cf[i]; }
                     add_nodes<4, DELTA, GAMMA, true>(flat_mask, k4, b4, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf4);
                 }
-                if (linear_df) {
+                if constexpr (linear_df) {
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
                         add_df_correction<GAMMA>(own_ratio, kc[2 * q], kc[2 * q + 1], omega * kap[q], c, lc_lanes, lc_block_mask, vbuf, lane, acc);
                 }
             }
             add_nodes<2, DELTA, GAMMA, true>(__ballot(pay_node), kp, bp, omega_p, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cfp);
-            if (linear_df) add_df_correction<GAMMA>(pay_node, kp[0], kp[1], omega_p * qpay.kappa, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+            if constexpr (linear_df) add_df_correction<GAMMA>(pay_node, kp[0], kp[1], omega_p * qpay.kappa, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
         }
         // ---------------------------------------------------------------- fixed coupons not merged above
         for (int base = 0; base < n_fix; base += 64) {
@@ -469,11 +471,11 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
             if (on) {
                 const Lookup q = curve_lookup(c, tp);
                 k[0] = q.ka; k[1] = q.kb; b[0] = q.ba; b[1] = q.bb; kap = q.kappa;
-                omega = a * exp(q.ln_d);
+                omega = a * exp(linear_df ? q.ln_d : fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
                 acc.pv += omega;
             }
             add_nodes<2, DELTA, GAMMA>(__ballot(on), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b);
-            if (linear_df) add_df_correction<GAMMA>(on, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+            if constexpr (linear_df) add_df_correction<GAMMA>(on, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
         }
 
         // ---------------------------------------------------------------- results of this trade
@@ -575,20 +577,27 @@ hipError_t launch_price_general(const CurveDev& cv, const TradesDev& tr, const O
                                 bool want_gamma, int n_blocks, hipStream_t stream) {
     const size_t lds = general_kernel_lds_bytes(cv.K, cv.Kc);
     dim3 grid(n_blocks), block(kBlockThreads);
+    const bool lin = cv.method == 2;
     if (want_gamma) {
-        hipLaunchKernelGGL((price_general_kernel<true, true>), grid, block, lds, stream, cv, tr, out);
+        if (lin) hipLaunchKernelGGL((price_general_kernel<true, true, true>), grid, block, lds, stream, cv, tr, out);
+        else hipLaunchKernelGGL((price_general_kernel<true, true, false>), grid, block, lds, stream, cv, tr, out);
     } else if (want_delta) {
-        hipLaunchKernelGGL((price_general_kernel<true, false>), grid, block, lds, stream, cv, tr, out);
+        if (lin) hipLaunchKernelGGL((price_general_kernel<true, false, true>), grid, block, lds, stream, cv, tr, out);
+        else hipLaunchKernelGGL((price_general_kernel<true, false, false>), grid, block, lds, stream, cv, tr, out);
     } else {
-        hipLaunchKernelGGL((price_general_kernel<false, false>), grid, block, lds, stream, cv, tr, out);
+        if (lin) hipLaunchKernelGGL((price_general_kernel<false, false, true>), grid, block, lds, stream, cv, tr, out);
+        else hipLaunchKernelGGL((price_general_kernel<false, false, false>), grid, block, lds, stream, cv, tr, out);
     }
     return hipGetLastError();
 }
 
 hipError_t set_general_kernel_lds_limit(size_t bytes) {
-    const void* fns[] = {reinterpret_cast<const void*>(&price_general_kernel<true, true>),
-                         reinterpret_cast<const void*>(&price_general_kernel<true, false>),
-                         reinterpret_cast<const void*>(&price_general_kernel<false, false>)};
+    const void* fns[] = {reinterpret_cast<const void*>(&price_general_kernel<true, true, false>),
+                         reinterpret_cast<const void*>(&price_general_kernel<true, false, false>),
+                         reinterpret_cast<const void*>(&price_general_kernel<false, false, false>),
+                         reinterpret_cast<const void*>(&price_general_kernel<true, true, true>),
+                         reinterpret_cast<const void*>(&price_general_kernel<true, false, true>),
+                         reinterpret_cast<const void*>(&price_general_kernel<false, false, true>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
         if (e != hipSuccess) return e;
