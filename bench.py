@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--trades", type=int, default=1_000_000, help="trades per GPU")
     ap.add_argument("--kind", default="offgrid", choices=["offgrid", "ongrid"])
-    ap.add_argument("--interp", default="LINEAR_ZERO_RATES", choices=["LINEAR_ZERO_RATES", "FLAT_FWD_RATES"])
+    ap.add_argument("--interp", default="LINEAR_ZERO_RATES", choices=["LINEAR_ZERO_RATES", "FLAT_FWD_RATES", "LINEAR_FWD_RATES"])
     ap.add_argument("--requests", default="value,delta,gamma")
     ap.add_argument("--xccy-swaps", type=int, default=0,
                     help="BASELINE configs[4]: add a book of this many GBP/USD basis swaps per GPU to every step "
