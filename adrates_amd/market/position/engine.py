@@ -34,15 +34,17 @@ _SUPPORTED_INTERP = (InterpTypes.FLAT_FWD_RATES.value, InterpTypes.LINEAR_FWD_RA
 class Engine:
     def __init__(self, model):
         self.model = model
-        # keyed by tuple(swap_times) like the reference (engine.py:2510); the
-        # device tables themselves are cached on the curve object, so Positions
-        # sharing a model do not re-bootstrap (position.py:55 creates one Engine
+        # The reference keys this cache by tuple(swap_times) alone (engine.py:2362-2412, 2510), so two curves
+        # with the same pillar times - a GBP and a USD curve built on one day count - collide inside one Engine
+        # and a cross-currency swap would read its domestic tables for the foreign leg.  The key here also
+        # carries the rates and the interpolation scheme.  The device tables themselves are cached on the
+        # curve object, so Positions sharing a model do not re-bootstrap (position.py:55 creates one Engine
         # per Position).
         self._curve_cache: Dict[Any, Dict[str, Any]] = {}
 
     # ------------------------------------------------------------------ curves
     def _device_curve(self, ir_model):
-        key = tuple(ir_model.swap_times)
+        key = (tuple(ir_model.swap_times), tuple(ir_model.swap_rates), ir_model._interp_type.value)
         hit = self._curve_cache.get(key)
         if hit is not None:
             return hit

@@ -299,3 +299,23 @@ def test_linear_fwd_rates_on_all_three_curves(host_engine):
     import tests.test_gpu_xccy as G
     from adrates_amd.utils import InterpTypes
     G.test_other_interpolation_schemes_on_all_three_curves(InterpTypes.LINEAR_FWD_RATES)
+
+
+def test_two_curves_with_identical_pillar_times_do_not_collide(host_engine):
+    """The reference's per-Engine curve cache is keyed by tuple(swap_times) only (engine.py:2362-2412): a domestic
+    and a foreign curve built on the same day count and tenors would share one entry.  Here they do not."""
+    from adrates_amd.market.position.engine import Engine
+    from adrates_amd.models.models import Model
+    from adrates_amd.utils import BusDayAdjustTypes, DayCountTypes, InterpTypes, SwapTypes
+    from tests.test_gpu_xccy import GBP, TENORS, USD
+    m = Model(VALUE_DT)
+    for name, px in (("GBP_OIS_SONIA", GBP), ("USD_OIS_SOFR", USD)):
+        m.build_curve(name=name, px_list=list(px), tenor_list=TENORS, spot_days=0, swap_type=SwapTypes.PAY,
+                      fixed_dcc_type=DayCountTypes.ACT_365F, fixed_freq_type=FrequencyTypes.ANNUAL,
+                      float_freq_type=FrequencyTypes.ANNUAL, float_dc_type=DayCountTypes.ACT_365F,
+                      bus_day_type=BusDayAdjustTypes.MODIFIED_FOLLOWING, interp_type=InterpTypes.FLAT_FWD_RATES)
+    gbp, usd = m.curves.GBP_OIS_SONIA, m.curves.USD_OIS_SOFR
+    assert tuple(gbp.swap_times) == tuple(usd.swap_times)
+    engine = Engine(m)
+    a, b = engine._device_curve(gbp), engine._device_curve(usd)
+    assert a is not b and not np.array_equal(a["host"].dfs, b["host"].dfs)
