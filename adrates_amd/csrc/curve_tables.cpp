@@ -222,6 +222,10 @@ bool build_packed_layout(CurveTables& t) {
         if (__builtin_popcount(support[c]) >= 3) core |= support[c];
 
     const int Pc = t.Pc = __builtin_popcount(core);
+    // A curve without a core (every knot depends on at most two pillars: a two- or three-pillar toy curve) has no
+    // packed tables to speak of - the fast kernel's core arrays would be empty.  Curves with a handful of core
+    // pillars gain nothing from the LDS-resident layout either; the general kernel prices both.
+    if (Pc < kMinCorePillars) return false;
     t.pc_pad = (Pc + 2) & ~1;
     t.pillar_to_core.assign(kPillarPad, static_cast<int16_t>(Pc));
     std::vector<int> core_pillars;

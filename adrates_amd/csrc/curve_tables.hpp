@@ -22,6 +22,7 @@ namespace adr {
 
 constexpr int kPillarPad = 32;                                  // ladders are padded to this on chip
 constexpr int kGammaPerLane = kPillarPad * kPillarPad / 64;     // 16 gamma entries per lane (4x4 block)
+constexpr int kMinCorePillars = 8;   // fewer core pillars than this: no packed layout (general kernel)
 constexpr int kGroupLanes = 32;                                 // lanes per trade in the fast kernel
 constexpr double kLutPerYear = 4.0;                             // buckets per year of the knot-search table
 constexpr int kLutMax = 512;                                    // at most this many buckets (128 years)

@@ -57,3 +57,25 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "oracle/port" in src:
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_example")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_abi_example.c"), "-L", os.path.join(root, "adrates_amd"),
+                           "-ladrates_hip", "-Wl,-rpath," + os.path.join(root, "adrates_amd"), "-o", exe])
+    return exe
+
+
+def test_c_example_builds_against_the_header_as_c99(native_lib, tmp_path):
+    """include/adrates.h is plain C: examples/c_abi_example.c compiles with gcc -std=c99 -Werror and links against
+    the library.  Without a GPU it must stop at adr_init with the no-fallback message (the run on a GPU is
+    tests/test_gpu_parity_small.py::test_c_example_matches_the_python_path)."""
+    import subprocess
+    import torch
+    exe = _build_c_example(tmp_path)
+    if not torch.cuda.is_available():
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 1 and "no CPU fallback" in out.stderr

@@ -89,3 +89,22 @@ def test_native_table_argument_checks(native_lib):
         _native.curve_tables_host(good["times"], np.array([0.99, 0.95, 0.9]), good["jac"])   # D(0) != 1
     with pytest.raises(LibError, match="no sensitivity"):
         _native.curve_tables_host(good["times"], good["dfs"], np.full((3, 2), 0.1))
+
+
+def test_curves_without_a_core_are_left_to_the_general_kernel(native_lib):
+    """A two-pillar toy curve (examples/c_abi_example.c) has no knot that depends on three pillars, hence no core
+    tables: the packed LDS layout must refuse it (the fast kernel's core arrays would be empty - this faulted on
+    the GPU once)."""
+    r1, r2 = 0.04, 0.045
+    d1 = 1 / (1 + r1); d2 = (1 - r2 * d1) / (1 + r2); dd1 = -d1 * d1
+    jac = np.array([[0, 0], [dd1, 0], [-r2 * dd1 / (1 + r2), (-d1 * (1 + r2) - (1 - r2 * d1)) / (1 + r2) ** 2]])
+    hess = np.zeros((3, 2, 2)); hess[1, 0, 0] = 2 * d1 ** 3
+    hess[2] = [[-r2 * 2 * d1 ** 3 / (1 + r2), -dd1 / (1 + r2) ** 2], [-dd1 / (1 + r2) ** 2, 2 * (1 + d1) / (1 + r2) ** 3]]
+    info = _native.curve_layout_host(np.array([0.0, 1.0, 2.0]), np.array([1.0, d1, d2]), jac, hess)
+    assert info["packed_ok"] == 0
+    # annual chains: four pillars are still below the layout's minimum core, ten are not
+    from adrates_amd.market.curves.curve_tables import build_engine_curve
+    for n, want in ((4, 0), (10, 1)):
+        h = build_engine_curve([0.04 + 0.001 * i for i in range(n)], [float(i + 1) for i in range(n)],
+                               [[1.0] * (i + 1) for i in range(n)])
+        assert _native.curve_layout_host(h.times, h.dfs, h.jac, h.hess)["packed_ok"] == want

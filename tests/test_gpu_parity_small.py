@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 
+from adrates_amd import _native
 from adrates_amd.utils import DayCountTypes, FrequencyTypes, InterpTypes
 
 from . import _fixtures as F
@@ -153,3 +154,54 @@ def test_linear_fwd_rates_through_the_python_api_and_scenario_grid(gpu_ctx):
     bumped = swaps[0].position(model.scenario("GBP_OIS_SONIA", {"10Y": 0.01})).compute([RequestTypes.VALUE])
     assert abs(out["pv"][1, 0] - bumped.value.amount) <= 1e-10 * swaps[0]._notional
     grid.close()
+
+
+def test_c_example_matches_the_python_path(gpu_ctx, tmp_path):
+    """examples/c_abi_example.c (plain C through include/adrates.h) prints the same numbers `_native.price` returns
+    for the same toy curve and trades, and its first PV equals the closed form N[(1 - d2) - c(d1 + d2)]."""
+    import subprocess
+    from adrates_amd.trades.compiler import TradeBatch
+    from tests.test_capi_library import _build_c_example
+    out = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    r1, r2 = 0.04, 0.045
+    d1 = 1.0 / (1.0 + r1); d2 = (1.0 - r2 * d1) / (1.0 + r2)
+    dd1 = -d1 * d1
+    jac = np.array([[0.0, 0.0], [dd1, 0.0], [-r2 * dd1 / (1 + r2), (-d1 * (1 + r2) - (1 - r2 * d1)) / (1 + r2) ** 2]])
+    hess = np.zeros((3, 2, 2))
+    hess[1, 0, 0] = 2 * d1 ** 3
+    hess[2] = [[-r2 * 2 * d1 ** 3 / (1 + r2), -dd1 / (1 + r2) ** 2], [-dd1 / (1 + r2) ** 2, 2 * (1 + d1) / (1 + r2) ** 3]]
+    dc = _native.DeviceCurve(gpu_ctx, 1, np.array([0.0, 1.0, 2.0]), np.array([1.0, d1, d2]), jac, hess)
+    batch = TradeBatch(np.array([0, 2, 3]), np.array([0, 2, 3]), np.array([1.0, 2.0, 1.0]),
+                       np.array([0.042e7, 0.042e7, 0.039 * 5e6]), np.array([1.0, 2.0, 1.0]), np.array([0.0, 1.0, 0.0]),
+                       np.array([1.0, 2.0, 1.0]), np.ones(3), np.array([1e7, 5e6]), np.zeros(2), np.array([-1.0, 1.0]),
+                       np.array([1.0, -1.0]))
+    want = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), aggregate=True)
+    text = out.stdout.splitlines()
+    for t in range(2):
+        nums = [float(x) for x in text[t].replace("trade %d" % t, "").split() if x not in ("pv", "delta", "gamma")]
+        assert nums[0] == want["pv"][t] and nums[1:3] == list(want["delta"][t]) and nums[3:7] == list(want["gamma"][t].reshape(-1))
+    book = [float(x) for x in text[2].split() if x not in ("book", "pv", "delta")]
+    assert book[0] == want["agg_pv"] and book[1:3] == list(want["agg_delta"])
+    closed = float(text[3].split()[-1])
+    assert abs(want["pv"][0] - closed) <= 1e-9 and abs(closed - 1e7 * ((1 - d2) - 0.042 * (d1 + d2))) <= 1e-9
+
+
+@pytest.mark.parametrize("n_pillars", [4, 10])
+def test_small_annual_curves(gpu_ctx, n_pillars):
+    """Few-pillar curves: 4 annual pillars stay below the packed layout's minimum core (general kernel), 10 are the
+    smallest curve the fast kernel takes."""
+    vd = F.README_VALUE_DT
+    tenors = [f"{i}Y" for i in range(1, n_pillars + 1)]
+    model = F.gbp_model(vd, InterpTypes.FLAT_FWD_RATES, px=[4.0 + 0.05 * i for i in range(n_pillars)], tenors=tenors)
+    curve = model.curves.GBP_OIS_SONIA
+    from adrates_amd.market.curves.curve_tables import build_engine_curve
+    host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    assert _native.curve_layout_host(host.times, host.dfs, host.jac, host.hess)["packed_ok"] == (1 if n_pillars == 10 else 0)
+    swaps = [F.make_swap(vd, "1Y", 0.04, 1e6), F.make_swap(vd, "30M", 0.045, 5e6, pay=False),
+             F.make_swap(vd, f"{n_pillars}Y", 0.043, 1e7), F.make_swap(vd, f"{n_pillars + 2}Y", 0.043, 2e6, pay=False),
+             F.make_swap(vd, "3Y", 0.04, 1e6, payment_lag=2), F.make_swap(vd.add_months(-5), "2Y", 0.04, 3e6)]
+    got = gpu_price(gpu_ctx, curve, swaps, vd, aggregate=True)
+    refs = oracle_price(curve, swaps, vd)
+    assert_parity(got, refs, [s._notional for s in swaps])
+    assert np.allclose(got["agg_gamma"], got["gamma"].sum(0), rtol=1e-12, atol=1e-12)
