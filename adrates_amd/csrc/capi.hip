@@ -532,6 +532,18 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     if ((n_fix > 0 && (!fix_tp || !fix_pay)) || (n_flt > 0 && (!flt_tp || !flt_ts || !flt_te || !flt_alpha)))
         return fail(ADR_ERR_INVALID, "adr_trades_upload: null cash-flow array");
 
+    // NaN / infinite inputs would only produce NaN outputs (every table index in the kernels is clamped), but a
+    // batch that contains them is a caller error: say so here instead of returning a ladder of NaNs
+    auto all_finite = [](const double* a, int64_t m) {
+        for (int64_t i = 0; i < m; ++i)
+            if (!std::isfinite(a[i])) return false;
+        return true;
+    };
+    if (!all_finite(fix_tp, n_fix) || !all_finite(fix_pay, n_fix) || !all_finite(flt_tp, n_flt) ||
+        !all_finite(flt_ts, n_flt) || !all_finite(flt_te, n_flt) || !all_finite(flt_alpha, n_flt) ||
+        (flt_weight && !all_finite(flt_weight, n_flt)) || !all_finite(notional, n) || !all_finite(spread, n))
+        return fail(ADR_ERR_INVALID, "adr_trades_upload: times, amounts, accruals, notionals and spreads must be finite");
+
     std::vector<adr::TradeHeader> hdr(static_cast<size_t>(n));
     std::vector<int32_t> list_fast, list_long, list_general;
     if (n > INT32_MAX) return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^31 trades in one batch");

@@ -88,6 +88,13 @@ def test_request_subsets_and_small_pillar_curve(gpu_ctx):
     with pytest.raises(LibError):
         _native.price(gpu_ctx, no_h, dt)
     assert np.array_equal(_native.price(gpu_ctx, no_h, dt, want_gamma=False)["delta"], full["delta"])
+    # non-finite trade inputs are refused at upload, with a message
+    import copy
+    for field, value in (("flt_tp", np.nan), ("fix_pay", np.inf), ("notional", np.nan)):
+        bad = copy.deepcopy(batch)
+        getattr(bad, field)[0] = value
+        with pytest.raises(LibError, match="finite"):
+            _native.DeviceTrades(gpu_ctx, bad)
 
 
 def test_edge_cases_empty_single_long(gpu_ctx):
