@@ -90,7 +90,7 @@ def main():
     from adrates_amd.market.curves.curve_tables import build_engine_curve
     from adrates_amd.trades import synthetic
     from adrates_amd.utils import InterpTypes
-    from tests._fixtures import README_VALUE_DT, gbp_model
+    from adrates_amd.trades.market_data import README_VALUE_DT, gbp_model
 
     reqs = {r.strip().lower() for r in args.requests.split(",")}
     want_gamma = "gamma" in reqs
@@ -126,7 +126,7 @@ def main():
     if n_x > 0:
         from adrates_amd.market.position.engine import Engine
         from adrates_amd.trades import synthetic_xccy
-        from tests._fixtures import GBP_PX, TENORS, USD_PX
+        from adrates_amd.trades.market_data import GBP_PX, TENORS, USD_PX
         market = synthetic_xccy.build_market(README_VALUE_DT, GBP_PX, USD_PX, TENORS)
         _native.set_default_context(ctx)                # the engine uploads the book's curves through this rank's context
         parts, _ = synthetic_xccy.synthesize_book(Engine(market), README_VALUE_DT, n_x, seed=synthetic.DEFAULT_SEED + 1000 + rank)

@@ -6,7 +6,7 @@ import torch
 from adrates_amd import _native
 from adrates_amd.market.curves.curve_tables import build_engine_curve
 from adrates_amd.trades import synthetic
-from tests._fixtures import README_VALUE_DT, gbp_model
+from adrates_amd.trades.market_data import README_VALUE_DT, gbp_model
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 kind = sys.argv[2] if len(sys.argv) > 2 else "offgrid"

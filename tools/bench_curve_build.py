@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from adrates_amd import _native
 from adrates_amd.market.curves.curve_tables import build_engine_curve
-from tests._fixtures import gbp_model
+from adrates_amd.trades.market_data import gbp_model
 
 curve = gbp_model().curves.GBP_OIS_SONIA
 base = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)

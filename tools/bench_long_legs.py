@@ -8,7 +8,7 @@ from adrates_amd import _native
 from adrates_amd.market.curves.curve_tables import build_engine_curve
 from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
 from adrates_amd.utils import BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes
-from tests._fixtures import README_VALUE_DT as vd, gbp_model
+from adrates_amd.trades.market_data import README_VALUE_DT as vd, gbp_model
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 mode = sys.argv[2] if len(sys.argv) > 2 else "long"
 mask = int(sys.argv[3]) if len(sys.argv) > 3 else 7       # 1 value, 3 value+delta, 7 value+delta+gamma       # "long": quarterly 10-30Y; "lag": annual, 2-day payment lag

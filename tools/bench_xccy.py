@@ -9,7 +9,7 @@ import numpy as np, torch
 from adrates_amd import _native
 from adrates_amd.market.position.engine import Engine
 from adrates_amd.trades import synthetic_xccy as SX
-from tests._fixtures import GBP_PX, README_VALUE_DT as vd, TENORS, USD_PX
+from adrates_amd.trades.market_data import GBP_PX, README_VALUE_DT as vd, TENORS, USD_PX
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 mask = int(sys.argv[2]) if len(sys.argv) > 2 else 3

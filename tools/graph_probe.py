@@ -7,7 +7,7 @@ import numpy as np, torch
 from adrates_amd import _native
 from adrates_amd.market.position.scenarios import ScenarioGrid, bump_ladder
 from adrates_amd.trades import synthetic
-from tests._fixtures import README_VALUE_DT as vd, TENORS, readme_model
+from adrates_amd.trades.market_data import README_VALUE_DT as vd, TENORS, readme_model
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 m = readme_model()

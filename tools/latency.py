@@ -3,7 +3,7 @@
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adrates_amd.utils import RequestTypes, CollateralType
-from tests._fixtures import README_VALUE_DT as vd, make_swap, readme_model
+from adrates_amd.trades.market_data import README_VALUE_DT as vd, make_swap, readme_model
 
 REQ = [RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA]
 
@@ -27,7 +27,7 @@ out = {"model_build_curve_ms": build_ms, "ois_first_compute_ms": first_ms, "ois_
        "ois_compute_same_position_ms": same_pos_ms}
 
 from adrates_amd.trades import synthetic_xccy as SX
-from tests._fixtures import GBP_PX, TENORS, USD_PX
+from adrates_amd.trades.market_data import GBP_PX, TENORS, USD_PX
 t0 = time.perf_counter()
 mx = SX.build_market(vd, GBP_PX, USD_PX, TENORS)
 out["xccy_market_build_ms"] = 1e3 * (time.perf_counter() - t0)

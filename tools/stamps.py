@@ -6,7 +6,7 @@ import numpy as np, torch
 from adrates_amd import _native
 from adrates_amd.market.curves.curve_tables import build_engine_curve
 from adrates_amd.trades import synthetic
-from tests._fixtures import README_VALUE_DT, gbp_model
+from adrates_amd.trades.market_data import README_VALUE_DT, gbp_model
 n = 1_000_000
 curve = gbp_model().curves.GBP_OIS_SONIA
 host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
