@@ -139,6 +139,13 @@ int adr_init(int device_ordinal, adr_ctx** out) {
         hipFree(ctx->partials); hipStreamDestroy(ctx->stream); delete ctx;
         return fail_hip(e, "hipMalloc(dump)");
     }
+    // Dynamic-LDS ceiling of every kernel instantiation, once per device: the whole 160 KiB of a CU.  (Setting it per
+    // uploaded curve to that curve's need would LOWER it below what an earlier, larger curve's launches request.)
+    e = adr::set_kernel_lds_limits(kLdsBudget, kLdsBudget);
+    if (e != hipSuccess) {
+        hipFree(ctx->dump); hipFree(ctx->partials); hipStreamDestroy(ctx->stream); delete ctx;
+        return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
 #ifdef ADR_STAMPS
     hipMalloc(reinterpret_cast<void**>(&ctx->stamps), sizeof(unsigned long long) * ctx->max_blocks * 16 * 8);
     hipMemset(ctx->stamps, 0, sizeof(unsigned long long) * ctx->max_blocks * 16 * 8);
@@ -283,8 +290,6 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
         fast_lds = adr::fast_kernel_lds_bytes(c->dev, t.has_hess);
         if (fast_lds > kLdsBudget) { c->dev.packed_ok = 0; fast_lds = 0; }
     }
-    e = adr::set_kernel_lds_limits(lds, std::max(fast_lds, lds));
-    if (e != hipSuccess) { adr_free_curve(c); return fail_hip(e, "hipFuncSetAttribute(LDS)"); }
     *out = c;
     return ADR_OK;
 }
@@ -386,8 +391,6 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
         fast_lds = adr::fast_kernel_lds_bytes(c, plan->has_hess);
         if (fast_lds > kLdsBudget) { c.packed_ok = 0; d.packed_ok = 0; fast_lds = 0; }
     }
-    e = adr::set_kernel_lds_limits(lds, std::max(fast_lds, lds));
-    if (e != hipSuccess) { adr_free_curve_plan(plan); return fail_hip(e, "hipFuncSetAttribute(LDS)"); }
     *out = plan;
     return ADR_OK;
 }
@@ -524,9 +527,16 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     if (n < 0) return fail(ADR_ERR_INVALID, "adr_trades_upload: negative trade count");
     if (n > 0 && (!fix_off || !flt_off || !notional || !spread || !fix_sign || !flt_sign))
         return fail(ADR_ERR_INVALID, "adr_trades_upload: null per-trade array");
+    if (n > INT32_MAX) return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^31 trades in one batch");
     const int64_t n_fix = n ? fix_off[n] : 0, n_flt = n ? flt_off[n] : 0;
     if (n > 0 && (fix_off[0] != 0 || flt_off[0] != 0))
         return fail(ADR_ERR_INVALID, "adr_trades_upload: offsets must start at 0");
+    // the offsets index the caller's arrays: check them before anything walks those arrays
+    for (int64_t t = 0; t < n; ++t) {
+        const int64_t mf = fix_off[t + 1] - fix_off[t], ml = flt_off[t + 1] - flt_off[t];
+        if (mf < 0 || ml < 0 || mf > INT16_MAX || ml > INT16_MAX)
+            return fail(ADR_ERR_INVALID, "adr_trades_upload: offsets must be non-decreasing, <= 32767 flows per leg");
+    }
     if (n_fix > INT32_MAX || n_flt > INT32_MAX)
         return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^31 cash flows in one batch; shard the portfolio");
     if ((n_fix > 0 && (!fix_tp || !fix_pay)) || (n_flt > 0 && (!flt_tp || !flt_ts || !flt_te || !flt_alpha)))
@@ -544,9 +554,8 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         (flt_weight && !all_finite(flt_weight, n_flt)) || !all_finite(notional, n) || !all_finite(spread, n))
         return fail(ADR_ERR_INVALID, "adr_trades_upload: times, amounts, accruals, notionals and spreads must be finite");
 
-    std::vector<adr::TradeHeader> hdr(static_cast<size_t>(n));
     std::vector<int32_t> list_fast, list_long, list_general;
-    if (n > INT32_MAX) return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^31 trades in one batch");
+    std::vector<adr::TradeHeader> hdr(static_cast<size_t>(n));
     constexpr int64_t kMaxChain = 4;     // rows per trade in the chained table: legs of up to 128 coupons
     auto rows_of = [&](int64_t t) {
         const int64_t m = std::max(flt_off[t + 1] - flt_off[t], fix_off[t + 1] - fix_off[t]);
@@ -561,8 +570,6 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     }
     for (int64_t t = 0; t < n; ++t) {
         const int64_t mf = fix_off[t + 1] - fix_off[t], ml = flt_off[t + 1] - flt_off[t];
-        if (mf < 0 || ml < 0 || mf > INT16_MAX || ml > INT16_MAX)
-            return fail(ADR_ERR_INVALID, "adr_trades_upload: offsets must be non-decreasing, <= 32767 flows per leg");
         if (!(fix_sign[t] == 1.0 || fix_sign[t] == -1.0) || !(flt_sign[t] == 1.0 || flt_sign[t] == -1.0))
             return fail(ADR_ERR_INVALID, "adr_trades_upload: leg signs must be +1 or -1");
         adr::TradeHeader& h = hdr[static_cast<size_t>(t)];

@@ -222,9 +222,14 @@ bool build_packed_layout(CurveTables& t) {
         if (__builtin_popcount(support[c]) >= 3) core |= support[c];
 
     const int Pc = t.Pc = __builtin_popcount(core);
-    // A curve without a core (every knot depends on at most two pillars: a two- or three-pillar toy curve) has no
-    // packed tables to speak of - the fast kernel's core arrays would be empty.  Curves with a handful of core
-    // pillars gain nothing from the LDS-resident layout either; the general kernel prices both.
+    // Curves with fewer than kMinCorePillars core pillars go to the general kernel.  For 1 <= Pc < 8 this is a
+    // performance choice only (a handful of core pillars gains nothing from the LDS-resident layout).  For Pc == 0
+    // (every knot depends on at most two pillars: a two- or three-pillar toy curve) it used to be a fault: with no
+    // core pairs the slot choice below still picks an "exact" variant (cpg = epg - 2), `hub_layout` refuses Pc < 1 and
+    // leaves `core_pos` EMPTY, the upload then passes a null `CurveDev::core_pos`, and the exact kernel variants
+    // read `cv.core_pos[l + 32 * i]` for their per-lane row positions (kernels_fast.hip, "pos[i] = HUB ? ...") -
+    // a null-pointer load on every lane.  The slot choice now also falls back to the universal variant (which never
+    // reads core_pos) whenever the hub layout cannot be built, so the guard is no longer what prevents the fault.
     if (Pc < kMinCorePillars) return false;
     t.pc_pad = (Pc + 2) & ~1;
     t.pillar_to_core.assign(kPillarPad, static_cast<int16_t>(Pc));
@@ -275,13 +280,22 @@ bool build_packed_layout(CurveTables& t) {
         if (core_slots_min * kGroupLanes + n_fringe <= epg * kGroupLanes) { t.epg = epg; t.cpg = epg; break; }
     }
     if (t.epg == 0) return false;
-    const int fringe_start = (t.cpg < t.epg ? t.cpg : core_slots_min) * kGroupLanes;
 
     // position of a core pair in a convexity row: packed_index order unless the hub layout rearranges it
     t.lcc_pq.assign(t.ent_pq.begin(), t.ent_pq.end());
     t.core_pos.clear();
     t.hub = false;
-    if (t.cpg < t.epg && hub_layout(Pc, core_pillars, t.cpg, t)) {
+    const bool hub_ok = t.cpg < t.epg && hub_layout(Pc, core_pillars, t.cpg, t);
+    if (t.cpg < t.epg && !hub_ok) {
+        // no star decomposition for this curve: the exact variants would index an empty core_pos (see above).
+        // Take the first universal variant the entries fit, or leave the curve to the general kernel.
+        t.epg = 0;
+        for (int epg : kEpgChoices)
+            if (core_slots_min * kGroupLanes + n_fringe <= epg * kGroupLanes) { t.epg = t.cpg = epg; break; }
+        if (t.epg == 0) return false;
+    }
+    const int fringe_start = (t.cpg < t.epg ? t.cpg : core_slots_min) * kGroupLanes;
+    if (hub_ok) {
         // ent_pq / core_pos / lcc_pq now describe the star decomposition; redo entry_of for the core pairs
         for (int e = 0; e < t.cpg * kGroupLanes; ++e) {
             if (!t.core_real[e]) continue;

@@ -48,15 +48,19 @@ class Engine:
         hit = self._curve_cache.get(key)
         if hit is not None:
             return hit
+        # object-level cache, valid for exactly these quotes, this scheme and this context (a curve whose
+        # rates or scheme were changed after the first pricing, or a second device in the process, rebuilds)
+        ctx = _native.default_context()
         shared = getattr(ir_model, "_adr_device_curve", None)
+        if shared is not None and (shared.get("key") != key or shared["ctx"] is not ctx):
+            shared = None
         if shared is None:
             method = ir_model._interp_type.value
             if method not in _SUPPORTED_INTERP:
                 raise LibError("Invalid interpolation scheme.")   # interpolator_ad.py:237
             host = build_engine_curve(ir_model.swap_rates, ir_model.swap_times, ir_model.year_fracs)
-            ctx = _native.default_context()
             dev = _native.DeviceCurve(ctx, method, host.times, host.dfs, host.jac, host.hess)
-            shared = dict(ctx=ctx, host=host, dev=dev, tenors=to_tenor(list(ir_model.swap_times)))
+            shared = dict(key=key, ctx=ctx, host=host, dev=dev, tenors=to_tenor(list(ir_model.swap_times)))
             ir_model._adr_device_curve = shared
         self._curve_cache[key] = shared
         return shared

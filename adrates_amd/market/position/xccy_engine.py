@@ -175,10 +175,12 @@ def _xccy_device_curve(ctx, xccy):
     """The XCCY curve's tables as an `adr_curve` (cached on the curve object).  The fast kernel's packed layout
     wants an even pillar count (16-byte gamma stores), so an odd basis ladder gets one all-zero pillar appended
     here and dropped again from the results (`_trim`)."""
-    hit = getattr(xccy, "_adr_device_curve", None)
-    if hit is not None:
-        return hit
     times, dfs = np.asarray(xccy._times, dtype=np.float64), np.asarray(xccy._dfs, dtype=np.float64)
+    # valid for exactly these knots, this scheme and this context
+    key = (times.tobytes(), dfs.tobytes(), xccy._interp_type.value)
+    hit = getattr(xccy, "_adr_device_curve", None)
+    if hit is not None and hit[0] == key and hit[1] is ctx:
+        return hit[2]
     jac = getattr(xccy, "_jac_basis", None)
     hess = getattr(xccy, "_hess_basis", None) if jac is not None else None
     jac = np.zeros((times.size, 2)) if jac is None else np.asarray(jac, dtype=np.float64)
@@ -186,8 +188,9 @@ def _xccy_device_curve(ctx, xccy):
     if jac.shape[1] % 2:
         jac = np.pad(jac, ((0, 0), (0, 1)))
         hess = None if hess is None else np.pad(hess, ((0, 0), (0, 1), (0, 1)))
-    xccy._adr_device_curve = _native.DeviceCurve(ctx, xccy._interp_type.value, times, dfs, jac, hess)
-    return xccy._adr_device_curve
+    dev = _native.DeviceCurve(ctx, xccy._interp_type.value, times, dfs, jac, hess)
+    xccy._adr_device_curve = (key, ctx, dev)
+    return dev
 
 
 def _trim(a, kind, P):

@@ -70,3 +70,29 @@ def synthesize(value_dt, n, kind="offgrid", seed=DEFAULT_SEED, dc_type=DayCountT
                      floating_index=curve_type, currency=currency, float_freq_type=freq, float_dc_type=dc_type,
                      bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
     return compile_ois_terms(terms, value_dt)
+
+
+def shard_of_portfolio(value_dt, n_total, rank, world_size, kind="offgrid", seed=DEFAULT_SEED, **kw):
+    """Rank ``rank``'s contiguous share of ONE synthetic portfolio of ``n_total`` trades, cut where
+    `adrates_amd.distributed.shard_batch` cuts it (near-equal cash-flow counts), without compiling the other
+    ranks' trades: the cash-flow counts follow from the drawn maturities alone (annual legs with a front stub:
+    ceil(months / 12) coupons per leg), so only the slice ``lo:hi`` of the terms is compiled.  Equal, bit for bit,
+    to ``shard_batch(synthesize(value_dt, n_total, ...), rank, world_size)`` (tests/test_synthetic.py).
+    Returns ``(batch, (lo, hi))``."""
+    from ..distributed import shard_bounds
+    freq = kw.get("freq", FrequencyTypes.ANNUAL)
+    if freq != FrequencyTypes.ANNUAL:
+        raise ValueError("shard_of_portfolio counts coupons for annual legs only")
+    months, coupon, notional, pay_fixed = draw_terms(n_total, kind, seed)
+    coupons = (months + 11) // 12
+    cum = np.concatenate(([0], np.cumsum(coupons))).astype(np.int64)
+    lo, hi = shard_bounds(cum, cum, world_size)[rank]
+    dc_type = kw.get("dc_type", DayCountTypes.ACT_365F)
+    curve_type = kw.get("curve_type", CurveTypes.GBP_OIS_SONIA)
+    currency = kw.get("currency", CurrencyTypes.GBP)
+    tenor_of = {int(m): f"{int(m)}M" for m in np.unique(months[lo:hi])}
+    terms = OISTerms(effective_dt=value_dt, tenor=[tenor_of[int(m)] for m in months[lo:hi]], coupon=coupon[lo:hi],
+                     notional=notional[lo:hi], pay_fixed=pay_fixed[lo:hi], fixed_freq_type=freq, fixed_dc_type=dc_type,
+                     floating_index=curve_type, currency=currency, float_freq_type=freq, float_dc_type=dc_type,
+                     bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
+    return compile_ois_terms(terms, value_dt), (lo, hi)

@@ -75,9 +75,11 @@ def take(batch: TradeBatch, pick, scale) -> TradeBatch:
                       cols[4] if weighted else None)
 
 
-def synthesize_book(engine, value_dt, n, seed=20240430):
+def synthesize_book(engine, value_dt, n, seed=20240430, rank=0, world_size=1):
     """The three trade batches of a book of ``n`` swaps (see `xccy_engine.compile_xccy`) and their device curves:
-    ``[(batch, device curve)] * 3`` in the order domestic, foreign rates, foreign flows, plus ``spot``."""
+    ``[(batch, device curve)] * 3`` in the order domestic, foreign rates, foreign flows, plus ``spot``.
+    With ``world_size > 1``: rank ``rank``'s contiguous share of that ONE book, cut by coupon count
+    (`distributed.shard_by_work`)."""
     from ..market.position import xccy_engine as XE
     templates = template_swaps(value_dt)
     dom_model, for_model, xccy, dom_cur, for_cur, x_dev = XE._curves(engine, templates)
@@ -86,5 +88,10 @@ def synthesize_book(engine, value_dt, n, seed=20240430):
     rng = np.random.default_rng(seed)
     pick = rng.integers(0, len(templates), n)
     scale = np.round(rng.uniform(1.0, 50.0, n), 1)
+    if world_size > 1:
+        from ..distributed import shard_by_work
+        work = (np.diff(dom.flt_off) + np.diff(rates.flt_off) + np.diff(flows.fix_off))[pick]
+        lo, hi = shard_by_work(work, world_size)[rank]
+        pick, scale = pick[lo:hi], scale[lo:hi]
     return [(take(dom, pick, scale), dom_cur["dev"]), (take(rates, pick, scale), for_cur["dev"]),
             (take(flows, pick, scale), x_dev)], spot

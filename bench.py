@@ -2,14 +2,18 @@
 """Throughput benchmark of the OIS PV + delta + gamma path on MI355X.
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.
-For N > 1 it is launched under ``torch.distributed.run`` (one rank per GPU, RCCL).
+For N > 1 it runs one rank per GPU over RCCL: either the driver launches it under ``torch.distributed.run``
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or - called plainly with ``--gpus N`` - it starts
+those N ranks itself as a child ``torch.distributed.run`` BEFORE anything touches the GPU and relays the child's
+output and exit code (a process that has initialised HIP is never re-exec'ed).
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): per GPU a synthetic
 portfolio of 1,000,000 spot-starting OIS on the README 32-pillar GBP SONIA curve (SURVEY.md section 8(d):
 maturity U{1..360} months, annual ACT/365F legs with a front stub, coupon U(1%,7%), notional
-round(U(1e6,5e7),-5), pay/receive 50/50, seed 20240430 + rank); one step = PV, 32-pillar delta ladder and
+round(U(1e6,5e7),-5), pay/receive 50/50, seed 20240430); one step = PV, 32-pillar delta ladder and
 full 32x32 gamma of every trade written to HBM, plus the portfolio aggregate, all-reduced over the ranks.
-Inputs are resident in HBM before the timed region; weak scaling (per-GPU work fixed).
+Inputs are resident in HBM before the timed region; weak scaling: ONE portfolio of N x 1,000,000 trades is cut
+into N contiguous shards of near-equal cash-flow count (adrates_amd/distributed.py), one per rank.
 """
 import argparse
 import json
@@ -23,7 +27,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -38,7 +42,30 @@ def parse():
                          "OIS workload only")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0,
                     help="approximate CPU time budget of the baseline leg (0 disables it)")
-    return ap.parse_args()
+    ap.add_argument("--print-spawn-command", action="store_true",
+                    help="with --gpus N > 1 and no WORLD_SIZE: print the launcher command instead of running it")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args, argv):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as a child process group.  Nothing in
+    this process has touched the GPU yet (`torch.cuda.device_count()` does not initialise HIP on this image), and
+    the child is a fresh interpreter, so no GPU-holding process is ever replaced."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
+          [a for a in argv if a != "--print-spawn-command"]
+    if args.print_spawn_command:
+        print(" ".join(cmd), flush=True)
+        return 0
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but only {have} HIP device(s) are visible", file=sys.stderr)
+        return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(curve, value_dt, interp_value, want_gamma, budget_s):
@@ -52,24 +79,32 @@ def cpu_baseline(curve, value_dt, interp_value, want_gamma, budget_s):
 
 
 def measured_traffic(n, want_gamma, kind, interp):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command
-    (tools/profile.sh + tools/profile_summary.py -> profiles/*_traffic.json), or None when the workload
-    differs from the profiled one.  bench.py cannot run the profiler on itself."""
+    """(HBM bytes per launch, where the figure comes from): the committed rocprofv3 PMC summary of this same
+    command (tools/profile.sh + tools/profile_summary.py -> profiles/*_traffic.json), or (None, reason) when the
+    workload differs from the profiled one.  bench.py cannot run the profiler on itself, so this is a figure
+    read from a file, not measured in this run - `traffic_source` in the JSON line says so."""
     import glob
     if not (n == 1_000_000 and want_gamma and kind == "offgrid" and interp == "LINEAR_ZERO_RATES"):
-        return None
+        return None, "none: no committed PMC pass for this workload"
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
-        return None
+        return None, "none: profiles/r*_traffic.json missing"
     try:
         with open(files[-1]) as f:
-            return float(json.load(f)["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+            return float(json.load(f)["hbm_bytes_per_launch"]), (
+                f"profiles/{os.path.basename(files[-1])}: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command on "
+                "an earlier box, read from the file - not measured in this run")
+    except Exception as exc:
+        return None, f"none: {exc}"
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args, argv))      # this process never touches the GPU
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -77,8 +112,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) "
+                         "or call bench.py without a launcher")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     # ADR_BENCH_FORCE_DIST=1 runs the process-group code path with a single rank (a one-GPU box can rehearse
     # the collective calls the N > 1 runs make; needs MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE in the env)
@@ -106,8 +145,11 @@ def main():
     ctx = _native.Context(local_rank)
     dev_curve = _native.DeviceCurve(ctx, interp.value, host_curve.times, host_curve.dfs, host_curve.jac,
                                     host_curve.hess)
-    n = args.trades
-    batch = synthetic.synthesize(README_VALUE_DT, n, kind=args.kind, seed=synthetic.DEFAULT_SEED + rank)
+    # ONE portfolio of world x --trades trades; this rank compiles and uploads its contiguous shard only (the cut
+    # points are those of distributed.shard_batch: near-equal cash-flow counts)
+    n_total = world * args.trades
+    batch, (lo, hi) = synthetic.shard_of_portfolio(README_VALUE_DT, n_total, rank, world, kind=args.kind)
+    n = batch.n_trades
     dev_trades = _native.DeviceTrades(ctx, batch)
     in_bytes = dev_trades.input_bytes
     out_bytes = 8 * n * (1 + (P if want_delta else 0) + (P * P if want_gamma else 0))
@@ -129,7 +171,9 @@ def main():
         from adrates_amd.trades.market_data import GBP_PX, TENORS, USD_PX
         market = synthetic_xccy.build_market(README_VALUE_DT, GBP_PX, USD_PX, TENORS)
         _native.set_default_context(ctx)                # the engine uploads the book's curves through this rank's context
-        parts, _ = synthetic_xccy.synthesize_book(Engine(market), README_VALUE_DT, n_x, seed=synthetic.DEFAULT_SEED + 1000 + rank)
+        parts, _ = synthetic_xccy.synthesize_book(Engine(market), README_VALUE_DT, world * n_x,
+                                                  seed=synthetic.DEFAULT_SEED + 1000, rank=rank, world_size=world)
+        n_x = parts[0][0].n_trades                      # this rank's share of the world x --xccy-swaps book
         for b, cur in parts:
             Px = cur.n_pillars
             xccy.append((_native.DeviceTrades(ctx, b), cur, torch.empty(n_x, dtype=torch.float64, device=dev),
@@ -185,33 +229,40 @@ def main():
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    counts = torch.tensor([n, n_x], dtype=torch.int64, device=dev)
+    if use_dist:
+        dist.all_reduce(counts)                          # units all ranks processed per step
+    n_all, nx_all = int(counts[0].item()), int(counts[1].item())
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * (n + n_x) * args.steps / elapsed
+        value = (n_all + nx_all) * args.steps / elapsed
+        traffic, traffic_source = measured_traffic(n, want_gamma, args.kind, args.interp)
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "OIS trades/sec PV+delta+gamma, 32-pillar curve; achieved HBM GB/s",
             "value": value, "unit": "trades/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n} random-tenor OIS per GPU ({args.kind}), PV + {P}-pillar delta"
+            "config": {"workload": f"{args.trades} random-tenor OIS per GPU ({args.kind}), PV + {P}-pillar delta"
                                    + (f" + full {P}x{P} gamma" if want_gamma else "")
                                    + f", {args.interp}, README GBP SONIA curve (BASELINE configs[2])",
-                       "trades_per_gpu": n, "pillars": P, "knots": host_curve.n_knots,
-                       "requests": sorted(reqs), "parallelism": f"trade-axis shard x{world}, RCCL all-reduce of "
-                                                               f"{1 + P + P * P} doubles"},
+                       "trades_per_gpu": args.trades, "trades_total": n_all, "rank0_trades": n,
+                       "pillars": P, "knots": host_curve.n_knots,
+                       "requests": sorted(reqs), "parallelism": f"one portfolio cut into {world} contiguous shards of equal "
+                                                               f"cash-flow count, RCCL all-reduce of {agg_len} doubles"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(n, want_gamma, args.kind, args.interp),
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel_ms": kern_ms, "kernel": "rank 0's pricing launch, HIP events on the launch stream", "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_bytes_per_trade": algo_bytes / n},
         }
         if n_x > 0:
             line["metric"] = "OIS trades + XCCY swaps per second, PV+delta+gamma, aggregate ladders all-reduced"
-            line["config"]["workload"] += (f" + {n_x} GBP/USD basis swaps per GPU with SONIA / SOFR / basis ladders "
+            line["config"]["workload"] += (f" + {args.xccy_swaps} GBP/USD basis swaps per GPU with SONIA / SOFR / basis ladders "
                                            f"(BASELINE configs[4]; the roofline object is the OIS kernel alone)")
-            line["config"]["xccy_swaps_per_gpu"] = n_x
+            line["config"]["xccy_swaps_per_gpu"] = args.xccy_swaps
+            line["config"]["xccy_swaps_total"] = nx_all
             line["config"]["allreduce_doubles"] = agg_len
         if args.cpu_baseline_seconds > 0 and world == 1 and n_x == 0:
             line["cpu_baseline"] = cpu_baseline(curve, README_VALUE_DT, interp.value, want_gamma,

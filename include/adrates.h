@@ -211,6 +211,10 @@ int adr_price(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades,
  * caller.  This is the entry the throughput benchmark times.  The call neither
  * allocates nor synchronises, so a sequence of them (a scenario ladder, the pieces
  * of a cross-currency book) can be captured on `stream` into a HIP graph and replayed.
+ * Stream rule: a call with agg_dev != NULL stages its per-block partial sums in scratch
+ * owned by the ctx, so all aggregate-producing calls of one ctx must be ordered on ONE
+ * stream (or separated by a synchronisation); calls without agg_dev may run on any streams
+ * concurrently.  Use one ctx per stream for concurrent aggregates.
  */
 int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades,
                   uint32_t req_mask,

@@ -24,7 +24,7 @@
 #include <omp.h>
 #endif
 
-#define MAXLOC 512 /* distinct knots one trade may touch */
+#define MAXLOC 1024 /* distinct knots one trade may touch */
 
 typedef struct {
     int K, P, method;

@@ -30,3 +30,21 @@ def test_slice_rebases_offsets():
     assert s.n_trades == 15 and s.fix_off[0] == 0 and s.flt_off[0] == 0
     assert np.array_equal(s.flt_tp, b.flt_tp[b.flt_off[10]:b.flt_off[25]])
     assert b.slice(7, 7).n_trades == 0
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_rank_shards_of_one_portfolio_equal_shard_batch(world):
+    """bench.py's ranks compile only their own share of the global portfolio; the shares are exactly what
+    `distributed.shard_batch` cuts from the whole (same bounds, same arrays), and together they are the whole."""
+    from adrates_amd.distributed import shard_batch
+    vd = F.README_VALUE_DT
+    whole = synthetic.synthesize(vd, 4000, seed=5)
+    covered = 0
+    for rank in range(world):
+        mine, (lo, hi) = synthetic.shard_of_portfolio(vd, 4000, rank, world, seed=5)
+        want, bounds = shard_batch(whole, rank, world)
+        assert (lo, hi) == bounds and lo == covered
+        covered = hi
+        for f in FIELDS:
+            assert np.array_equal(getattr(mine, f), getattr(want, f)), f
+    assert covered == 4000
