@@ -57,6 +57,8 @@ _SIGNATURES = {
     "adr_price": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _dp, _dp, _dp, _dp]),
     "adr_price_dev": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
     "adr_allreduce_agg": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "adr_curve_df": (C.c_int, [_vp, _vp, C.c_int64, _dp, _dp]),
+    "adr_curve_df_dev": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -324,6 +326,15 @@ def price_dev(ctx: Context, curve: DeviceCurve, trades: DeviceTrades, mask: int,
     handle (0 = the context's own stream)."""
     _check(load().adr_price_dev(ctx._h, curve._h, trades._h, int(mask), _vp(pv_ptr or None), _vp(delta_ptr or None),
                                 _vp(gamma_ptr or None), _vp(agg_ptr or None), _vp(stream or None)), "adr_price_dev")
+
+
+def curve_df(ctx: Context, curve: DeviceCurve, t):
+    """Discount factors at the times ``t`` off an uploaded curve, evaluated on the GPU (adr_curve_df): the batched
+    `InterpolatorAd.simple_interpolate`.  Scalars in, scalar out."""
+    tt = _f64(np.atleast_1d(t))
+    out = np.empty_like(tt)
+    _check(load().adr_curve_df(ctx._h, curve._h, tt.size, _ptr(tt), _ptr(out)), "adr_curve_df")
+    return float(out[0]) if np.ndim(t) == 0 else out.reshape(np.shape(t))
 
 
 def curve_tables_host(times, dfs, jac, hess=None):

@@ -96,6 +96,11 @@ struct adr_trades {
     const int32_t* list_general = nullptr;
     adr::TradesDev chained{};        // row table of the longer trades as chains of 32-coupon rows (fast kernel, LONG)
     int chained_blocks = 0;          // the grid the chains were laid out for
+    // delta / PV-only requests: the trades without payment lag and at most 45 coupons per leg as 16-slot rows of the
+    // lite kernel (the trades of the 32-slot row table); list_nonlite = every other trade (for curves without a packed layout)
+    adr::LiteRowsDev lite{};
+    int64_t n_lite = 0, n_nonlite = 0;
+    const int32_t* list_nonlite = nullptr;
     std::vector<void*> allocations;
 };
 
@@ -130,7 +135,7 @@ int adr_init(int device_ordinal, adr_ctx** out) {
                                                            : prop.sharedMemPerBlock;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail_hip(e, "hipStreamCreate"); }
-    ctx->max_blocks = std::max(1, ctx->n_cu) * 8;
+    ctx->max_blocks = std::max(1, ctx->n_cu) * 16;
     e = hipMalloc(reinterpret_cast<void**>(&ctx->partials),
                   sizeof(double) * static_cast<size_t>(ctx->max_blocks) * adr::kAggStride);
     if (e != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return fail_hip(e, "hipMalloc(partials)"); }
@@ -291,6 +296,39 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
         if (fast_lds > kLdsBudget) { c->dev.packed_ok = 0; fast_lds = 0; }
     }
     *out = c;
+    return ADR_OK;
+}
+
+// ------------------------------------------------------------------------------ batched curve lookups
+int adr_curve_df_dev(adr_ctx* ctx, const adr_curve* curve, int64_t n, const double* t_dev, double* df_dev, void* stream_v) {
+    if (!ctx || !curve) return fail(ADR_ERR_INVALID, "adr_curve_df: null ctx/curve");
+    if (curve->ctx != ctx) return fail(ADR_ERR_INVALID, "adr_curve_df: the curve was uploaded through another ctx");
+    if (n < 0 || (n > 0 && (!t_dev || !df_dev))) return fail(ADR_ERR_INVALID, "adr_curve_df: bad count / null array");
+    ADR_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
+    ADR_HIP(adr::launch_curve_df(curve->dev, n, t_dev, df_dev, ctx->n_cu, stream));
+    return ADR_OK;
+}
+
+int adr_curve_df(adr_ctx* ctx, const adr_curve* curve, int64_t n, const double* t, double* df) {
+    if (!ctx || !curve) return fail(ADR_ERR_INVALID, "adr_curve_df: null ctx/curve");
+    if (n < 0 || (n > 0 && (!t || !df))) return fail(ADR_ERR_INVALID, "adr_curve_df: bad count / null array");
+    if (n == 0) return ADR_OK;
+    for (int64_t i = 0; i < n; ++i)
+        if (!std::isfinite(t[i])) return fail(ADR_ERR_INVALID, "adr_curve_df: times must be finite");
+    ADR_HIP(hipSetDevice(ctx->device));
+    double *d_t = nullptr, *d_df = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_t), sizeof(double) * static_cast<size_t>(n));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_df), sizeof(double) * static_cast<size_t>(n));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_t, t, sizeof(double) * static_cast<size_t>(n), hipMemcpyHostToDevice, ctx->stream);
+    int rc = ADR_OK;
+    if (e == hipSuccess) rc = adr_curve_df_dev(ctx, curve, n, d_t, d_df, nullptr);
+    if (e == hipSuccess && rc == ADR_OK)
+        e = hipMemcpyAsync(df, d_df, sizeof(double) * static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == ADR_OK) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d_t); hipFree(d_df);
+    if (rc != ADR_OK) return rc;
+    if (e != hipSuccess) return fail_hip(e, "adr_curve_df");
     return ADR_OK;
 }
 
@@ -702,6 +740,79 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         tr->chained_blocks = blocks;
         build_rows(pieces, tr->chained);
     }
+    {   // lite table (kernels.hpp, LiteRowsDev): segments of 3-, 2- and 1-row trades, longest coupon counts first
+        constexpr int S = adr::kLiteSlots, C = adr::kLiteCoupons, G = 64 / adr::kLiteSlots;
+        auto lite_rows = [&](int64_t t) {
+            const int64_t m = std::max(flt_off[t + 1] - flt_off[t], fix_off[t + 1] - fix_off[t]);
+            return std::max<int64_t>(1, (m + C - 1) / C);
+        };
+        std::vector<int32_t> seg_trades[adr::kLiteSegments], nonlite;
+        for (int64_t t = 0; t < n; ++t) {
+            bool general = false;
+            for (int64_t j = flt_off[t]; j < flt_off[t + 1] && !general; ++j)
+                general = (flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j]) || (flt_weight && flt_weight[j] != 1.0);
+            const int64_t rows = lite_rows(t);
+            // the same trades as the 32-slot row table holds (at most 32 coupons per leg, i.e. up to 3 lite rows);
+            // longer ones keep their chained rows
+            if (general || rows_of(t) > 1 || rows > adr::kLiteSegments) nonlite.push_back(static_cast<int32_t>(t));
+            else seg_trades[adr::kLiteSegments - rows].push_back(static_cast<int32_t>(t));     // segment 0: 3 rows
+        }
+        tr->n_nonlite = static_cast<int64_t>(nonlite.size());
+        tr->list_nonlite = static_cast<const int32_t*>(put(nonlite.data(), nonlite.size() * sizeof(int32_t)));
+        adr::LiteRowsDev& lt = tr->lite;
+        int64_t units = 0, rows = 0;
+        for (int k = 0; k < adr::kLiteSegments; ++k) {
+            std::stable_sort(seg_trades[k].begin(), seg_trades[k].end(), [&](int32_t a, int32_t b) {
+                return hdr[static_cast<size_t>(a)].n_flt > hdr[static_cast<size_t>(b)].n_flt;
+            });
+            tr->n_lite += static_cast<int64_t>(seg_trades[k].size());
+            lt.seg_rows[k] = adr::kLiteSegments - k;
+            lt.seg_unit0[k] = units;
+            lt.seg_row0[k] = rows;
+            const int64_t seg_units = (static_cast<int64_t>(seg_trades[k].size()) + G - 1) / G;
+            units += seg_units;
+            rows += seg_units * G * lt.seg_rows[k];
+        }
+        lt.n_units = units;
+        if (rows * S > static_cast<int64_t>(UINT32_MAX)) {      // the kernel indexes the row arrays with 32 bits
+            adr_free_trades(tr);
+            return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^28 rows in the delta-only table; shard the portfolio");
+        }
+        const size_t n_slots = static_cast<size_t>(units) * G, n_rows = static_cast<size_t>(rows);
+        std::vector<double> r_tp(n_rows * S, 0.0), r_ts(n_rows * S, 0.0), r_al(n_rows * S, 0.0), r_xtp(n_rows * S, 0.0),
+            r_xpay(n_rows * S, 0.0), r_n(n_slots, 0.0), r_sp(n_slots, 0.0);
+        std::vector<int32_t> r_meta(n_slots, 0), r_trade(n_slots, -1);
+        for (int k = 0; k < adr::kLiteSegments; ++k) {
+            const int R = lt.seg_rows[k];
+            for (size_t i = 0; i < seg_trades[k].size(); ++i) {
+                const int64_t t = seg_trades[k][i];
+                const size_t slot = static_cast<size_t>(lt.seg_unit0[k]) * G + i;
+                const size_t row0 = static_cast<size_t>(lt.seg_row0[k]) + i * static_cast<size_t>(R);
+                const int64_t ml = flt_off[t + 1] - flt_off[t], mf = fix_off[t + 1] - fix_off[t];
+                for (int64_t j = 0; j < ml; ++j) {
+                    const size_t at = (row0 + static_cast<size_t>(j / C)) * S + static_cast<size_t>(j % C);
+                    r_tp[at] = flt_tp[flt_off[t] + j]; r_ts[at] = flt_ts[flt_off[t] + j]; r_al[at] = flt_alpha[flt_off[t] + j];
+                }
+                for (int64_t j = 0; j < mf; ++j) {
+                    const size_t at = (row0 + static_cast<size_t>(j / C)) * S + static_cast<size_t>(j % C);
+                    r_xtp[at] = fix_tp[fix_off[t] + j]; r_xpay[at] = fix_pay[fix_off[t] + j];
+                }
+                r_n[slot] = notional[t]; r_sp[slot] = spread[t];
+                r_trade[slot] = static_cast<int32_t>(t);
+                r_meta[slot] = static_cast<int32_t>(ml | (mf << 8) | ((flt_sign[t] < 0.0) ? 0x10000 : 0) |
+                                                    ((fix_sign[t] < 0.0) ? 0x20000 : 0));
+            }
+        }
+        lt.tp = static_cast<const double*>(put(r_tp.data(), r_tp.size() * sizeof(double)));
+        lt.ts = static_cast<const double*>(put(r_ts.data(), r_ts.size() * sizeof(double)));
+        lt.alpha = static_cast<const double*>(put(r_al.data(), r_al.size() * sizeof(double)));
+        lt.xtp = static_cast<const double*>(put(r_xtp.data(), r_xtp.size() * sizeof(double)));
+        lt.xpay = static_cast<const double*>(put(r_xpay.data(), r_xpay.size() * sizeof(double)));
+        lt.notional = static_cast<const double*>(put(r_n.data(), r_n.size() * sizeof(double)));
+        lt.spread = static_cast<const double*>(put(r_sp.data(), r_sp.size() * sizeof(double)));
+        lt.meta = static_cast<const int32_t*>(put(r_meta.data(), r_meta.size() * sizeof(int32_t)));
+        lt.trade = static_cast<const int32_t*>(put(r_trade.data(), r_trade.size() * sizeof(int32_t)));
+    }
     if (e != hipSuccess) { adr_free_trades(tr); return fail_hip(e, "adr_trades_upload: copying trades"); }
     *out = tr;
     return ADR_OK;
@@ -734,16 +845,34 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     o.delta = (req_mask & ADR_REQ_DELTA) ? delta_dev : nullptr;
     o.gamma = want_gamma ? gamma_dev : nullptr;
 
-    // Trades without payment lag go to the fast kernel when the curve has the packed layout (those with more
-    // than 32 coupons per leg as chains of rows, in a launch of their own); everything else to the general kernel.
+    // Routing.  With GAMMA: trades without payment lag go to the fast kernel when the curve has the packed layout
+    // (those with more than 32 coupons per leg as chains of rows, in a launch of their own), everything else to the
+    // general kernel.  Without GAMMA (PV / PV + delta): the lite kernel takes every trade without payment lag and
+    // with at most 45 coupons per leg on either log-linear scheme, whatever the curve's structure; the rest goes to
+    // the chained fast kernel (packed layout) or the general kernel.
     const bool use_fast = curve->dev.packed_ok != 0;
+    const bool use_lite = !want_gamma && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES && trades->lite.n_units > 0;
     adr::TradesDev fast = trades->dev, chained = trades->chained, general = trades->dev;
-    if (use_fast) {
+    if (use_lite) {
+        fast.n_rows = 0;                                   // the lite table holds exactly the 32-slot row table's trades
+        if (use_fast) {                                    // long trades keep their chained rows
+            general.list = trades->list_general; general.n_list = trades->n_general;
+        } else {                                           // no packed layout: long trades join the general list
+            chained.n_rows = 0;
+            general.list = trades->list_nonlite; general.n_list = trades->n_nonlite;
+        }
+    } else if (use_fast) {
         general.list = trades->list_general; general.n_list = trades->n_general;
     } else {
         fast.n_rows = 0; chained.n_rows = 0;   // general walks all n trades through the identity list
     }
-    int blocks_fast = 0, blocks_chained = 0, blocks_general = 0;
+    int blocks_fast = 0, blocks_chained = 0, blocks_general = 0, blocks_lite = 0;
+    if (use_lite) {
+        const size_t lds = adr::lite_kernel_lds_bytes(curve->dev, want_delta);
+        const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
+        const int64_t need = (trades->lite.n_units + adr::kLiteThreads / 64 - 1) / (adr::kLiteThreads / 64);
+        blocks_lite = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * per_cu));
+    }
     if (fast.n_rows > 0) {
         const size_t lds = adr::fast_kernel_lds_bytes(curve->dev, want_gamma);
         const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
@@ -756,25 +885,30 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         const int64_t need = (general.n_list + adr::kGeneralThreads / 64 - 1) / (adr::kGeneralThreads / 64);
         blocks_general = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * 4));
     }
-    if (blocks_fast + blocks_chained + blocks_general > ctx->max_blocks)
+    if (blocks_lite + blocks_fast + blocks_chained + blocks_general > ctx->max_blocks)
         return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
     auto partials_at = [&](int first_block) {
         return agg_dev ? ctx->partials + static_cast<size_t>(first_block) * adr::kAggStride : nullptr;
     };
-    if (blocks_fast > 0) {
+    if (blocks_lite > 0) {
         o.block_partials = partials_at(0);
+        ADR_HIP(adr::launch_price_lite(curve->dev, trades->lite, o, want_delta, blocks_lite, stream));
+    }
+    if (blocks_fast > 0) {
+        o.block_partials = partials_at(blocks_lite);
         ADR_HIP(adr::launch_price_fast(curve->dev, fast, o, want_delta, want_gamma, blocks_fast, stream));
     }
     if (blocks_chained > 0) {
-        o.block_partials = partials_at(blocks_fast);
+        o.block_partials = partials_at(blocks_lite + blocks_fast);
         ADR_HIP(adr::launch_price_fast(curve->dev, chained, o, want_delta, want_gamma, blocks_chained, stream));
     }
     if (blocks_general > 0) {
-        o.block_partials = partials_at(blocks_fast + blocks_chained);
+        o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained);
         ADR_HIP(adr::launch_price_general(curve->dev, general, o, want_delta, want_gamma, blocks_general, stream));
     }
     if (agg_dev)
-        ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_fast + blocks_chained + blocks_general, P, agg_dev, stream));
+        ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_lite + blocks_fast + blocks_chained + blocks_general, P,
+                                            want_gamma, agg_dev, stream));
     return ADR_OK;
 }
 

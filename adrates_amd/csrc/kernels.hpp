@@ -18,6 +18,12 @@ constexpr int kAggStride = 1 + kPillarPad + kPillarPad * kPillarPad; // padded [
 constexpr int kGeneralThreads = 256;                                 // general kernel: 4 wavefronts per block
 constexpr int kFastThreads = ADR_FAST_THREADS;
 constexpr int kRowSlots = 32;                                        // cash-flow slots per row of the fast table
+// lite kernel (kernels_lite.hip): 4 trades per wavefront, rows of 16 slots = 15 coupons + a spare lane
+constexpr int kLiteThreads = 512;
+constexpr int kLiteWavesPerSimd = 4;                                 // 2 blocks of 8 waves per CU (105 VGPRs)
+constexpr int kLiteSlots = 16;
+constexpr int kLiteCoupons = 15;
+constexpr int kLiteSegments = 3;                                     // trades of 3, 2 and 1 rows (up to 45 coupons per leg)
 
 // Per-trade header, 32 bytes, read once per trade with scalar loads.
 struct TradeHeader {
@@ -62,6 +68,25 @@ struct TradesDev {
     const int32_t* row_meta;     // [n_rows] n_flt | n_fix << 8 | (float leg pays) << 16 | (fixed leg pays) << 17 |
                                  //          (the trade continues in the group's next row) << 18
     const int32_t* row_trade;    // [n_rows] index of the trade in the batch (where its results go)
+};
+
+// Row table of the lite kernel: the trades without payment lag and with at most 45 coupons per leg, grouped into
+// segments of equal row count (3, 2, 1 rows per trade; inside a segment sorted by coupon count), every segment padded
+// to a multiple of 4 trades (one unit = the 4 trades of a wavefront) with empty slots (trade = -1).
+struct LiteRowsDev {
+    int64_t n_units;                  // units of 4 trade slots
+    int64_t seg_unit0[kLiteSegments]; // first unit of segment k
+    int64_t seg_row0[kLiteSegments];  // first row of segment k
+    int seg_rows[kLiteSegments];      // rows per trade in segment k
+    const double* tp;                 // [n_rows][kLiteSlots] float payment times
+    const double* ts;                 //                      accrual start times
+    const double* alpha;              //                      accrual fractions
+    const double* xtp;                //                      fixed payment times
+    const double* xpay;               //                      fixed payment amounts
+    const double* notional;           // [4 * n_units]
+    const double* spread;
+    const int32_t* meta;              // n_flt | n_fix << 8 | (float leg pays) << 16 | (fixed leg pays) << 17 (whole trade)
+    const int32_t* trade;             // index of the trade in the batch, -1 for an empty slot
 };
 
 // Curve tables in HBM.
@@ -136,6 +161,12 @@ hipError_t launch_price_general(const CurveDev& cv, const TradesDev& tr, const O
                                 bool want_gamma, int n_blocks, hipStream_t stream);
 hipError_t launch_price_fast(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                              bool want_gamma, int n_blocks, hipStream_t stream);
-hipError_t launch_reduce_partials(const double* partials, int n_blocks, int P, double* agg, hipStream_t stream);
+hipError_t launch_curve_df(const CurveDev& cv, int64_t n, const double* t_dev, double* df_dev, int n_cu, hipStream_t stream);
+size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta);
+hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const OutputsDev& out, bool want_delta,
+                             int n_blocks, hipStream_t stream);
+// has_gamma == false: the gamma part of the partials was not written (no gamma requested); agg's gamma part is zeroed
+hipError_t launch_reduce_partials(const double* partials, int n_blocks, int P, bool has_gamma, double* agg,
+                                  hipStream_t stream);
 
 }  // namespace adr

@@ -49,6 +49,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "curve_lookup.hpp"
 #include "kernels.hpp"
 
 namespace adr {
@@ -109,61 +110,6 @@ struct CurveLds {
     const int16_t* knot_class;  // [Kc]
     int K, method, pc_pad, ec_stride;
 };
-
-struct Lookup {
-    int ka, kb;        // compact knots
-    double ba, bb;     // D = exp(ba*L[ka] + bb*L[kb]); bb == 0: single knot
-};
-
-// InterpolatorAd.simple_interpolate for one time (interpolator_ad.py:210-243) in weight form.
-__device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
-    const int K = c.K;
-    // j = first knot with x > t, searched inside the index range the time's bucket allows
-    const double tb = t * kLutPerYear;
-    const int bucket = tb > 0.0 ? (tb < static_cast<double>(c.n_lut) ? static_cast<int>(tb) : c.n_lut - 1) : 0;
-    int lo = c.lut[2 * bucket], hi = c.lut[2 * bucket + 1];
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (c.x[mid] > t) hi = mid; else lo = mid + 1;
-    }
-    const int j = lo;
-    // nearest knot; the first of equal candidates wins, the lower one on a distance tie (argmin)
-    double best_dist = 1e300;
-    int best = 0;
-    if (j > 0) { best = c.first_of[j - 1]; best_dist = fabs(t - c.x[j - 1]); }
-    if (j < K) {
-        const double dh = fabs(t - c.x[j]);
-        if (dh < best_dist) { best_dist = dh; best = j; }
-    }
-    Lookup r;
-    if (best_dist < 1e-10) {            // exact grid point: that knot's DF, gradient to that knot only
-        r.ka = r.kb = c.compact_of[best]; r.ba = 1.0; r.bb = 0.0;
-        return r;
-    }
-    const double tau = t + 1e-12;
-    const bool lzr = c.method == 4;
-    if (tau < c.x[0] || tau > c.x[K - 1]) {   // jnp.interp is constant outside the knot range
-        r.ka = r.kb = c.compact_of[tau < c.x[0] ? 0 : K - 1];
-        r.bb = 0.0;
-        r.ba = lzr ? t * c.inv_x[r.ka] : 1.0;
-        return r;
-    }
-    // no knot lies in (t, t + 1e-12] (it would have snapped), so searchsorted(tau, 'right') == j
-    const int i = min(max(j, 1), K - 1);
-    const double xa = c.x[i - 1], xb = c.x[i];
-    const double dx = xb - xa;
-    const double w = (fabs(dx) <= 0x1p-104) ? 0.0 : (tau - xa) / dx;   // jnp.interp: fp[i-1] when dx ~ 0
-    r.ka = c.compact_of[i - 1];
-    r.kb = c.compact_of[i];
-    if (lzr) {
-        r.ba = t * (1.0 - w) * c.inv_x[r.ka];
-        r.bb = t * w * c.inv_x[r.kb];
-    } else {
-        r.ba = 1.0 - w;
-        r.bb = w;
-    }
-    return r;
-}
 
 // Doubles of LDS per wavefront (see the carve-up in the kernel).
 __host__ __device__ constexpr int slot_doubles(bool gamma, int epg, int groups) {
@@ -727,11 +673,15 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 // Fixed-order sum of the block partials -> agg[1 + P + P*P]: one wavefront per output, lanes stride over
 // the blocks, then a fixed butterfly - the aggregate does not depend on scheduling.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* partials, int n_blocks, int P,
-                                                               double* agg) {
+                                                               int has_gamma, double* agg) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int n_out = 1 + P + P * P;
     if (i >= n_out) return;
+    if (!has_gamma && i >= 1 + P) {       // nothing was accumulated there: the launches ran without GAMMA
+        if (lane == 0) agg[i] = 0.0;
+        return;
+    }
     int src;
     if (i == 0) src = 0;
     else if (i < 1 + P) src = i;
@@ -810,17 +760,21 @@ hipError_t launch_price_fast(const CurveDev& cv, const TradesDev& tr, const Outp
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_partials(const double* partials, int n_blocks, int P, double* agg, hipStream_t stream) {
+hipError_t launch_reduce_partials(const double* partials, int n_blocks, int P, bool has_gamma, double* agg,
+                                  hipStream_t stream) {
     const int n_out = 1 + P + P * P;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_out + 3) / 4), dim3(256), 0, stream, partials, n_blocks, P,
-                       agg);
+                       has_gamma ? 1 : 0, agg);
     return hipGetLastError();
 }
 
 hipError_t set_general_kernel_lds_limit(size_t bytes);
+hipError_t set_lite_kernel_lds_limit(size_t bytes);
 
 hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes) {
     hipError_t e = set_general_kernel_lds_limit(general_bytes);
+    if (e != hipSuccess) return e;
+    e = set_lite_kernel_lds_limit(fast_bytes);
     if (e != hipSuccess) return e;
     std::vector<const void*> fns;
     collect_gamma_kernels<true, false>(fns);

@@ -1,0 +1,392 @@
+// CDNA4 (gfx950) LITE kernel: PV and the pillar delta ladder of OIS trades when no gamma is requested
+// (BASELINE.json configs[1]: PV + 32-pillar delta).
+//
+// Same mathematics as kernels_fast.hip (reference: cavour/market/position/engine.py:2414-2448 fixed leg, :2639-2728
+// float leg, :2541-2561 / :2899-2919 value and delta assembly; lookups: cavour/market/curves/interpolator_ad.py:186-249):
+// cash flows are folded into nodes (time, coefficient), every node is w = c * exp(ba L[ka] + bb L[kb]), and
+//
+//   PV = sum_nodes w,      dPV/dr = sum_nodes w (ba LJ[ka] + bb LJ[kb])  =  sum_knots c_k LJ[k]
+//
+// i.e. the reverse sweep stops at the knots: each node leaves two (coefficient, knot row) entries and the ladder is a
+// sparse combination of rows of LJ = d ln(knot DF) / d(par rates).
+//
+// Why a kernel of its own.  Without the gamma state the pass is bound by vector-ALU issue, not by LDS or HBM
+// (2 trades per wavefront at ~400 VALU instructions per trade), so the mapping is chosen to
+// spend as few wave-instructions per trade as possible:
+//   * a wavefront prices FOUR trades at a time, 16 lanes each, and a trade's coupons arrive as rows of 16 slots
+//     (15 coupons + a spare lane for the leg's start node; trades of 16-45 coupons are 2 or 3 consecutive rows), so
+//     half-empty 32-slot rows are neither loaded nor computed on: 512-byte coalesced loads, ~0.95 KB of row data per
+//     trade on the benchmark portfolio instead of 1.3 KB;
+//   * lanes = coupons for folding, lookup and exp; then every lane leaves its node as two 16-byte entries
+//     {w * b, byte offset of the knot's LJ row} in the wave's LDS slot and lane l accumulates pillars 2l and 2l + 1:
+//     per entry one broadcast b128 read, one b128 read of the row pair, two FMAs - no per-node decoding, no short-end
+//     special cases (the dense 32-wide LJ of all reachable knots fits LDS once the gamma tables are not needed);
+//   * neighbour moves and the 16-lane PV sum are DPP row operations (VALU, no LDS traffic).
+// Any curve of the two log-linear schemes qualifies (no packed layout, any pillar count up to 32).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "curve_lookup.hpp"
+#include "kernels.hpp"
+
+namespace adr {
+
+namespace {
+
+constexpr int kBlockThreads = kLiteThreads;
+constexpr int kWavesPerBlock = kBlockThreads / 64;
+constexpr int L = kLiteSlots;                 // lanes per trade
+constexpr int G = 64 / L;                     // trades per wavefront
+constexpr int kRecBytesPerWave = G * (2 * L + 2) * 16;  // per group: two 16-byte entries per lane + a pad entry
+constexpr int kBatch = 4;                               // entries whose LDS operands are fetched together
+
+typedef double nt_pair __attribute__((ext_vector_type(2)));
+
+// DPP moves inside rows of 16 lanes (= one trade): lane i receives lane i + 1 / i - 1 of its row; the row's last /
+// first lane keeps its own value.
+__device__ __forceinline__ double row_next(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), 0x101, 0xf, 0xf, false);   // row_shl:1
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), 0x101, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_prev(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), 0x111, 0xf, 0xf, false);   // row_shr:1
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), 0x111, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double row_perm(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// Sum over the 16 lanes of a row, result in every lane: quad butterflies, then the two mirrors.
+__device__ __forceinline__ double row_sum(double x) {
+    x += row_perm<0xB1>(x);      // quad_perm [1,0,3,2]
+    x += row_perm<0x4E>(x);      // quad_perm [2,3,0,1]
+    x += row_perm<0x141>(x);     // row_half_mirror
+    x += row_perm<0x140>(x);     // row_mirror
+    return x;
+}
+
+#ifdef ADR_STAMPS
+#define ADR_STAMP(slot_) do { const unsigned long long now_ = clock64(); stamp_sum[slot_] += now_ - stamp_t; stamp_t = now_; } while (0)
+#else
+#define ADR_STAMP(slot_) do {} while (0)
+#endif
+
+__device__ __forceinline__ void wave_lds_sync() {     // same-wave LDS hand-off, see kernels_fast.hip
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+struct CurveLds {
+    const double* x;            // [K]
+    const double* log_df;       // [Kc]
+    const double* inv_x;        // [Kc]
+    const int16_t* lut;         // [n_lut][2]
+    int n_lut;
+    const int16_t* first_of;    // [K]
+    const int16_t* compact_of;  // [K]
+    const double* inv_dx;       // [K]  1 / (x[i] - x[i-1]); 0 for i = 0 and where the two knot times coincide
+    int K, method;
+};
+
+template <bool DELTA>
+__global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
+                                                                                       OutputsDev out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    // LDS carve-up: per-wave entry slots (16-byte aligned), doubles, int16 tables
+    unsigned char* s_rec = smem_raw;
+    double* s_lj = reinterpret_cast<double*>(s_rec + (DELTA ? kWavesPerBlock * kRecBytesPerWave : 0));
+    double* s_x = s_lj + (DELTA ? cv.Kc * kPillarPad : 0);
+    double* s_log = s_x + cv.K;
+    double* s_invx = s_log + cv.Kc;
+    double* s_invdx = s_invx + cv.Kc;
+    int16_t* s_first = reinterpret_cast<int16_t*>(s_invdx + cv.K);
+    int16_t* s_comp = s_first + cv.K;
+    int16_t* s_lut = s_comp + cv.K;
+
+    if (DELTA)
+        for (int i = threadIdx.x; i < cv.Kc * kPillarPad; i += kBlockThreads) s_lj[i] = cv.lj[i];
+    for (int i = threadIdx.x; i < cv.K; i += kBlockThreads) {
+        s_x[i] = cv.x[i];
+        {   // jnp.interp returns fp[i-1] when |dx| <= 2^-104: weight 0
+            const double dx = i > 0 ? cv.x[i] - cv.x[i - 1] : 0.0;
+            s_invdx[i] = fabs(dx) <= 0x1p-104 ? 0.0 : 1.0 / dx;
+        }
+        s_first[i] = cv.first_of[i];
+        s_comp[i] = cv.compact_of[i];
+    }
+    for (int i = threadIdx.x; i < cv.Kc; i += kBlockThreads) {
+        s_log[i] = cv.log_df[i];
+        s_invx[i] = cv.inv_x[i];
+    }
+    for (int i = threadIdx.x; i < 2 * cv.n_lut; i += kBlockThreads) s_lut[i] = cv.lut[i];
+    __syncthreads();
+
+    CurveLds c;
+    c.x = s_x; c.log_df = s_log; c.inv_x = s_invx; c.lut = s_lut; c.n_lut = cv.n_lut;
+    c.first_of = s_first; c.compact_of = s_comp; c.inv_dx = s_invdx; c.K = cv.K; c.method = cv.method;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane / L, l = lane % L;
+    const int gbase = g * L;
+    const int P = cv.P;
+    // per wave: [4 groups][2 entries per lane + 1 pad entry] x 16 bytes; the pad shifts each group by 4 banks, so the
+    // four groups' broadcast reads of one entry index do not collide
+    unsigned char* rec_wave = s_rec + wave * kRecBytesPerWave;
+    const unsigned char* rec_group = rec_wave + g * ((2 * L + 1) * 16);
+    unsigned char* rec_mine = rec_wave + (g * (2 * L + 1) + 2 * l) * 16;
+    const unsigned char* lj_lane = reinterpret_cast<const unsigned char*>(s_lj) + l * 16;    // pillars 2l, 2l + 1
+
+    double tot_pv = 0.0, tot_d0 = 0.0, tot_d1 = 0.0;
+
+    // ---------------------------------------------------------------------------------------------------
+    // Main loop over (unit, row) steps.  A unit is 4 trade slots (one per group of 16 lanes); its trades have R rows
+    // each (R is uniform inside a segment).  The inputs of the NEXT step - the row slice and, at a unit's first row,
+    // the per-trade scalars - are requested before the current step is worked on, so the HBM round trip overlaps a
+    // whole step of lookups, exponentials and ladder work instead of heading every step's dependency chain.
+    // All index arithmetic is 32-bit and wave-uniform (scalar unit) except one multiply-add per lane.
+    const uint32_t n_units = static_cast<uint32_t>(tr.n_units);
+    const uint32_t wave_stride = gridDim.x * kWavesPerBlock;
+    uint32_t seg_u0[kLiteSegments], seg_at0[kLiteSegments];
+#pragma unroll
+    for (int k = 0; k < kLiteSegments; ++k) {
+        seg_u0[k] = static_cast<uint32_t>(tr.seg_unit0[k]);
+        seg_at0[k] = static_cast<uint32_t>(tr.seg_row0[k]) * L;
+    }
+    auto segment = [&](uint32_t u, int& R, uint32_t& at0) {       // rows per trade; array index of the unit's first slot
+        R = tr.seg_rows[0];
+        uint32_t unit0 = seg_u0[0];
+        at0 = seg_at0[0];
+#pragma unroll
+        for (int k = 1; k < kLiteSegments; ++k)
+            if (u >= seg_u0[k]) { R = tr.seg_rows[k]; unit0 = seg_u0[k]; at0 = seg_at0[k]; }
+        at0 += (u - unit0) * (G * L) * R;
+    };
+    double nx_tp = 0.0, nx_ts = 0.0, nx_al = 0.0, nx_xtp = 0.0, nx_xpay = 0.0, nx_N = 0.0, nx_spread = 0.0;
+    int nx_meta = 0, nx_trade = -1;
+    auto request_row = [&](uint32_t at0, int R, int r) {            // group g's row r: R rows per trade, 16 slots per row
+        const uint32_t at = at0 + r * L + __umul24(g, R * L) + l;
+        nx_tp = __builtin_nontemporal_load(tr.tp + at); nx_ts = __builtin_nontemporal_load(tr.ts + at);
+        nx_al = __builtin_nontemporal_load(tr.alpha + at);
+        nx_xtp = __builtin_nontemporal_load(tr.xtp + at); nx_xpay = __builtin_nontemporal_load(tr.xpay + at);
+    };
+    auto request_trade = [&](uint32_t u) {
+        // (scalar loads of the unit's four slots + a pick by group were tried: the wave then waits for the scalar
+        // data in this phase - slower than four broadcast vector loads)
+        const uint32_t slot = u * G + g;
+        nx_N = tr.notional[slot]; nx_spread = tr.spread[slot];
+        nx_meta = tr.meta[slot]; nx_trade = tr.trade[slot];
+    };
+
+    uint32_t unit = blockIdx.x * kWavesPerBlock + wave;
+    int R = 1, r = 0;
+    uint32_t at0 = 0;
+    if (unit < n_units) {
+        segment(unit, R, at0);
+        request_trade(unit);
+        request_row(at0, R, 0);
+    }
+    double N = 0.0, spread = 0.0, sl = 1.0, sf = 1.0;
+    int n_flt = 0, n_fix = 0, t = -1;
+    bool live = false;
+    double pv = 0.0, d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;     // two accumulator pairs: shorter FMA chains
+#ifdef ADR_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = clock64();
+#endif
+    while (unit < n_units) {
+        // ---- this step's inputs
+        const double tp = nx_tp, ts = nx_ts, al = nx_al, xtp = nx_xtp, xpay = nx_xpay;
+#ifdef ADR_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        ADR_STAMP(0);   // waiting for the step's inputs
+        if (r == 0) {
+            N = nx_N; spread = nx_spread; t = nx_trade; live = t >= 0;
+            n_flt = nx_meta & 0xff; n_fix = (nx_meta >> 8) & 0xff;
+            sl = (nx_meta & 0x10000) ? -1.0 : 1.0; sf = (nx_meta & 0x20000) ? -1.0 : 1.0;
+            pv = d0 = d1 = e0 = e1 = 0.0;
+        }
+        // ---- request the next step's inputs
+        const bool last_row = r + 1 == R;
+        const uint32_t next_unit = last_row ? unit + wave_stride : unit;
+        int next_R = R;
+        uint32_t next_at0 = at0;
+        if (last_row && next_unit < n_units) {
+            segment(next_unit, next_R, next_at0);
+            request_trade(next_unit);
+            request_row(next_at0, next_R, 0);
+        } else if (!last_row) {
+            request_row(at0, R, r + 1);
+        }
+        ADR_STAMP(5);   // requesting the next step's inputs
+        {
+            const int m_flt = min(max(n_flt - r * kLiteCoupons, 0), kLiteCoupons);   // coupons of this row
+            const int m_fix = min(max(n_fix - r * kLiteCoupons, 0), kLiteCoupons);
+
+            // ---- fold the coupons into nodes (lane l = coupon l of the row); same rules as kernels_fast.hip
+            const bool in = live && l < m_flt;
+            const double ntp = row_next(tp), nts = row_next(ts), nal = row_next(al);
+            const double ptp = row_prev(tp);
+            const bool valid = in && tp >= 0.0;
+            const bool accrues = al > 0.0;
+            double a_pay = valid ? sl * N * (spread * al - (accrues ? 1.0 : 0.0)) : 0.0;
+            if (in && l + 1 < m_flt && nal > 0.0 && ntp >= 0.0 && nts == tp) a_pay += sl * N;
+            const bool fix_in = live && l < m_fix;
+            const bool fix_merged = fix_in && in && xtp == tp;
+            if (fix_merged && xtp > 0.0) a_pay = fma(sf, xpay, a_pay);
+            bool own_start = valid && accrues && !(l > 0 && ptp == ts);
+            const bool own_fixed = fix_in && !fix_merged && xtp > 0.0 && sf * xpay != 0.0;
+
+            double qt = tp, qa = a_pay;
+            bool qon = in && a_pay != 0.0;
+            {   // the row's first start node moves to the row's spare lane (m_flt <= 15 < 16: there always is one)
+                const unsigned mine = static_cast<unsigned>(__ballot(own_start) >> gbase) & 0xffffu;
+                const int src = gbase + (mine ? __builtin_ctz(mine) : 0);
+                const double st = __shfl(ts, src, 64);
+                if (mine != 0 && l == m_flt) { qt = st; qa = sl * N; qon = true; }
+                if (mine != 0 && lane == src) own_start = false;
+            }
+            const bool more_starts = __ballot(own_start) != 0, more_fixed = __ballot(own_fixed) != 0;
+            ADR_STAMP(1);   // folding
+
+            for (int pass = 0; pass < 3; ++pass) {
+                if (pass == 1) {            // fixed coupons that did not merge into a float payment node
+                    if (!more_fixed) continue;
+                    qt = xtp; qa = sf * xpay; qon = own_fixed;
+                } else if (pass == 2) {     // further start nodes (accrual gaps)
+                    if (!more_starts) break;
+                    qt = ts; qa = sl * N; qon = own_start;
+                }
+                double ca = 0.0, cb = 0.0;
+                int off_a = 0, off_b = 0;
+                if (qon) {
+                    const Lookup q = curve_lookup<true>(c, qt);
+                    const double omega = qa * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
+                    pv += omega;
+                    ca = omega * q.ba; cb = omega * q.bb;
+                    off_a = q.ka * (kPillarPad * 8); off_b = q.kb * (kPillarPad * 8);
+                }
+                ADR_STAMP(2);   // lookup + exp
+                if (!DELTA) continue;
+                // ---- reverse sweep to the knots: every lane leaves its node as two entries {coefficient, byte
+                // offset of the knot's LJ row}.  Knot 0 is the value-time knot, whose row is all zero, so idle lanes
+                // and single-knot nodes need no flags.  (On curves whose pillar dates are runs of duplicate knots a
+                // node's right-hand knot - the first of a run - is never the next node's left-hand knot - the last of
+                // that run -, so merging neighbours' entries buys nothing: tried, slower.)
+                __builtin_amdgcn_wave_barrier();
+                {
+                    double2* wp = reinterpret_cast<double2*>(rec_mine);
+                    wp[0] = make_double2(ca, __hiloint2double(0, off_a));
+                    wp[1] = make_double2(cb, __hiloint2double(0, off_b));
+                }
+                wave_lds_sync();
+                unsigned long long any = __ballot(qon);
+                any |= any >> 32; any |= any >> 16;
+                const unsigned rows_any = static_cast<unsigned>(any) & 0xffffu;
+                if (!rows_any) continue;
+                const int n_e = 2 * (32 - __builtin_clz(rows_any));      // entries up to the highest live lane of any row
+                for (int e = 0; e < n_e; e += kBatch) {                   // lanes past n_e wrote zero entries
+                    double2 rc[kBatch], rw[kBatch];
+#pragma unroll
+                    for (int i = 0; i < kBatch; ++i) rc[i] = *reinterpret_cast<const double2*>(rec_group + (e + i) * 16);
+#pragma unroll
+                    for (int i = 0; i < kBatch; ++i) rw[i] = *reinterpret_cast<const double2*>(lj_lane + __double2loint(rc[i].y));
+#pragma unroll
+                    for (int i = 0; i < kBatch; ++i) {
+                        if (i & 1) { e0 = fma(rc[i].x, rw[i].x, e0); e1 = fma(rc[i].x, rw[i].y, e1); }
+                        else { d0 = fma(rc[i].x, rw[i].x, d0); d1 = fma(rc[i].x, rw[i].y, d1); }
+                    }
+                }
+                ADR_STAMP(3);   // entries + ladder
+            }
+        }
+        if (!last_row) { ++r; continue; }
+
+        // ---- results of the unit's trades
+        pv = row_sum(pv);
+        if (live && l == 0) {
+            if (out.pv) out.pv[t] = pv;
+            tot_pv += pv;
+        }
+        if (DELTA && live) {
+            d0 = (d0 + e0) * 1e-4; d1 = (d1 + e1) * 1e-4;
+            tot_d0 += d0; tot_d1 += d1;
+            if (out.delta) {
+                double* dst = out.delta + static_cast<int64_t>(t) * P + 2 * l;
+                if ((P & 1) == 0) {
+                    if (2 * l < P) { nt_pair pr; pr.x = d0; pr.y = d1; __builtin_nontemporal_store(pr, reinterpret_cast<nt_pair*>(dst)); }
+                } else {                 // odd pillar count: rows are not 16-byte aligned
+                    if (2 * l < P) dst[0] = d0;
+                    if (2 * l + 1 < P) dst[1] = d1;
+                }
+            }
+        }
+        unit = next_unit; R = next_R; at0 = next_at0; r = 0;
+        ADR_STAMP(4);   // outputs
+    }
+#ifdef ADR_STAMPS
+    if (out.stamps && lane == 0) {
+        unsigned long long* dst = out.stamps + (static_cast<size_t>(blockIdx.x) * kWavesPerBlock + wave) * 8;
+        for (int i = 0; i < 8; ++i) dst[i] = stamp_sum[i];
+    }
+#endif
+
+    // ------------------------------------------------------------------------ block partial of the aggregate
+    if (out.block_partials) {
+#pragma unroll
+        for (int off = L; off < 64; off <<= 1) {
+            tot_pv += __shfl_xor(tot_pv, off, 64);
+            tot_d0 += __shfl_xor(tot_d0, off, 64);
+            tot_d1 += __shfl_xor(tot_d1, off, 64);
+        }
+        __syncthreads();   // every wave is done with the tables; reuse the LDS
+        double* red = reinterpret_cast<double*>(smem_raw);          // [waves][1 + 32]
+        if (lane == 0) red[wave * 33] = tot_pv;
+        if (g == 0) { red[wave * 33 + 1 + 2 * l] = tot_d0; red[wave * 33 + 2 + 2 * l] = tot_d1; }
+        __syncthreads();
+        double* dst = out.block_partials + static_cast<size_t>(blockIdx.x) * kAggStride;
+        if (threadIdx.x < 1 + kPillarPad) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; ++w) s += red[w * 33 + threadIdx.x];
+            dst[threadIdx.x] = (DELTA || threadIdx.x == 0) ? s : 0.0;     // the gamma part is not read (no gamma requested)
+        }
+    }
+}
+
+}  // namespace
+
+size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta) {
+    size_t bytes = delta ? static_cast<size_t>(kWavesPerBlock) * kRecBytesPerWave + sizeof(double) * cv.Kc * kPillarPad : 0;
+    bytes += sizeof(double) * (2 * static_cast<size_t>(cv.K) + 2 * cv.Kc);
+    bytes += sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + 2 * static_cast<size_t>(cv.n_lut));
+    const size_t reduce = sizeof(double) * kWavesPerBlock * 33;
+    if (bytes < reduce) bytes = reduce;
+    return (bytes + 15) & ~static_cast<size_t>(15);
+}
+
+hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const OutputsDev& out, bool want_delta,
+                             int n_blocks, hipStream_t stream) {
+    const size_t lds = lite_kernel_lds_bytes(cv, want_delta);
+    if (want_delta) hipLaunchKernelGGL(price_lite_kernel<true>, dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out);
+    else hipLaunchKernelGGL(price_lite_kernel<false>, dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out);
+    return hipGetLastError();
+}
+
+hipError_t set_lite_kernel_lds_limit(size_t bytes) {
+    const void* fns[] = {reinterpret_cast<const void*>(&price_lite_kernel<true>),
+                         reinterpret_cast<const void*>(&price_lite_kernel<false>)};
+    for (const void* f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace adr

@@ -26,6 +26,8 @@ curve's own nodes with the Jacobian of the engine's knot grid, two different siz
 """
 from __future__ import annotations
 
+from dataclasses import dataclass
+
 import numpy as np
 
 from ... import _native
@@ -36,139 +38,189 @@ from ...utils.global_types import CurveTypes, InterpTypes, RequestTypes, SwapTyp
 from ...utils.helpers import times_from_dates, to_tenor
 
 
-def knot_df(times, dfs, t, method: int):
-    """`InterpolatorAd.simple_interpolate` (cavour/market/curves/interpolator_ad.py:186-249) for values:
-    snap to a knot within 1e-10 (first knot on ties), else interpolate at t + 1e-12, flat outside the grid."""
-    x = np.asarray(times, dtype=np.float64)
-    d = np.asarray(dfs, dtype=np.float64)
-    tt = np.atleast_1d(np.asarray(t, dtype=np.float64))
-    dist = np.abs(tt[:, None] - x[None, :])
-    k = np.argmin(dist, axis=1)
-    snapped = dist[np.arange(tt.size), k] < 1e-10
-    tau = tt + 1e-12
-    if method == InterpTypes.LINEAR_ZERO_RATES.value:
-        out = np.exp(-np.interp(tau, x, -np.log(d) / np.maximum(x, 1e-15)) * tt)
-    elif method == InterpTypes.FLAT_FWD_RATES.value:
-        out = np.exp(-np.interp(tau, x, -np.log(d)))
-    elif method == InterpTypes.LINEAR_FWD_RATES.value:
-        out = np.interp(tau, x, d)
-    else:
-        raise LibError("Invalid interpolation scheme.")
-    out = np.where(snapped, d[k], out)
-    return float(out[0]) if np.ndim(t) == 0 else out
-
-
 def _times(dts, value_dt, dc):
     return np.array([times_from_dates(d, value_dt, dc) for d in dts], dtype=np.float64)
-
-
-class _Csr:
-    """Flat cash-flow arrays of a batch under construction."""
-
-    def __init__(self, fields):
-        self.cols = {f: [] for f in fields}
-        self.off = [0]
-
-    def add(self, **cols):
-        n = None
-        for k, v in cols.items():
-            self.cols[k].append(np.asarray(v, dtype=np.float64).reshape(-1))
-            n = self.cols[k][-1].size
-        self.off.append(self.off[-1] + (n or 0))
-
-    def col(self, k):
-        return np.concatenate(self.cols[k]) if self.cols[k] else np.zeros(0)
-
-    def offsets(self):
-        return np.asarray(self.off, dtype=np.int64)
 
 
 def _sign(leg):
     return 1.0 if leg._leg_type == SwapTypes.RECEIVE else -1.0
 
 
-def compile_xccy(swaps, value_dt, xccy, for_times, for_dfs, for_method):
-    """The three trade batches of the assembly above, plus the per-swap PV of the flows dated at the value time.
+@dataclass
+class RawXccy:
+    """Times and per-swap terms of a book of basis swaps, before any curve is consulted (CSR over the coupons).
+    Domestic leg in its own day count; foreign payment / exchange times in the XCCY curve's day count, foreign
+    accrual times in the foreign leg's (engine.py:1500-1506, 1519-1520)."""
+    dom_off: np.ndarray; dom_tp: np.ndarray; dom_ts: np.ndarray; dom_te: np.ndarray; dom_al: np.ndarray
+    for_off: np.ndarray; for_tpx: np.ndarray; for_ts: np.ndarray; for_te: np.ndarray; for_al: np.ndarray
+    dom_exch_t: np.ndarray      # [n, 2] effective / maturity time, domestic day count
+    for_exch_t: np.ndarray      # [n, 2] the same in the XCCY curve's day count
+    dom_exch: np.ndarray; for_exch: np.ndarray          # [n] bool: the leg exchanges notional
+    dom_n: np.ndarray; for_n: np.ndarray; dom_spread: np.ndarray; for_spread: np.ndarray
+    dom_sign: np.ndarray; for_sign: np.ndarray
 
-    ``for_times, for_dfs``: the foreign OIS curve's engine grid (the reference projects the foreign forwards off
-    `_cached_curve`'s knots, engine.py:1640-1668).  Returns ``(domestic, foreign_rates, foreign_flows, pv_const,
-    spot)``; ``foreign_rates`` carries `flt_weight`."""
-    spot = xccy._spot_fx
-    x_times, x_dfs, x_method = np.asarray(xccy._times), np.asarray(xccy._dfs), xccy._interp_type.value
-    xdc = xccy._dc_type
-    n = len(swaps)
-    pv_const = np.zeros(n)
-    dom_fix, dom_flt = _Csr(("tp", "pay")), _Csr(("tp", "ts", "te", "al"))
-    for_flt = _Csr(("tp_x", "ts", "te", "al"))
-    exch = _Csr(("tp", "pay"))
-    for i, swap in enumerate(swaps):
+    @property
+    def n(self):
+        return int(self.dom_n.shape[0])
+
+
+def raw_from_swaps(swaps, value_dt, xdc) -> RawXccy:
+    """`RawXccy` of a list of `XccyBasisSwap` objects (one Python pass over the objects)."""
+    cols = {k: [] for k in ("dtp", "dts", "dte", "dal", "ftp", "fts", "fte", "fal")}
+    d_off, f_off = [0], [0]
+    d_ex, f_ex = [], []
+    for swap in swaps:
         dl, fl = swap._domestic_leg, swap._foreign_leg
         ddc, fdc = dl._dc_type, fl._dc_type
-        tp, pay = [], []
-        if dl._notional_exchange:
-            for t, amount in ((times_from_dates(swap._effective_dt, value_dt, ddc), -dl._notional),
-                              (times_from_dates(swap._maturity_dt, value_dt, ddc), dl._notional)):
-                if t > 0.0:
-                    tp.append(t); pay.append(amount)
-                elif t == 0.0:
-                    pv_const[i] += _sign(dl) * amount
-        dom_fix.add(tp=tp, pay=pay)
-        dom_flt.add(tp=_times(dl._payment_dts, value_dt, ddc), ts=_times(dl._start_accrued_dts, value_dt, ddc),
-                    te=_times(dl._end_accrued_dts, value_dt, ddc), al=dl._year_fracs)
-        for_flt.add(tp_x=_times(fl._payment_dts, value_dt, xdc), ts=_times(fl._start_accrued_dts, value_dt, fdc),
-                    te=_times(fl._end_accrued_dts, value_dt, fdc), al=fl._year_fracs)
-        tp, pay = [], []
-        if fl._notional_exchange:
-            for t, amount in ((times_from_dates(swap._effective_dt, value_dt, xdc), -fl._notional),
-                              (times_from_dates(swap._maturity_dt, value_dt, xdc), fl._notional)):
-                if t > 0.0:
-                    tp.append(t); pay.append(amount)
-                elif t == 0.0:
-                    pv_const[i] += _sign(fl) * amount / spot
-        exch.add(tp=tp, pay=pay)
-
+        cols["dtp"].append(_times(dl._payment_dts, value_dt, ddc)); cols["dts"].append(_times(dl._start_accrued_dts, value_dt, ddc))
+        cols["dte"].append(_times(dl._end_accrued_dts, value_dt, ddc)); cols["dal"].append(np.asarray(dl._year_fracs, dtype=np.float64))
+        cols["ftp"].append(_times(fl._payment_dts, value_dt, xdc)); cols["fts"].append(_times(fl._start_accrued_dts, value_dt, fdc))
+        cols["fte"].append(_times(fl._end_accrued_dts, value_dt, fdc)); cols["fal"].append(np.asarray(fl._year_fracs, dtype=np.float64))
+        d_off.append(d_off[-1] + cols["dtp"][-1].size)
+        f_off.append(f_off[-1] + cols["ftp"][-1].size)
+        d_ex.append([times_from_dates(swap._effective_dt, value_dt, ddc), times_from_dates(swap._maturity_dt, value_dt, ddc)])
+        f_ex.append([times_from_dates(swap._effective_dt, value_dt, xdc), times_from_dates(swap._maturity_dt, value_dt, xdc)])
+    cat = lambda k: np.concatenate(cols[k]) if cols[k] else np.zeros(0)
     f64 = lambda v: np.array(v, dtype=np.float64)
-    dom_n, dom_s = f64([s._domestic_leg._notional for s in swaps]), f64([_sign(s._domestic_leg) for s in swaps])
-    for_n, for_s = f64([s._foreign_leg._notional for s in swaps]), f64([_sign(s._foreign_leg) for s in swaps])
-    domestic = TradeBatch(dom_fix.offsets(), dom_flt.offsets(), dom_fix.col("tp"), dom_fix.col("pay"),
-                          dom_flt.col("tp"), dom_flt.col("ts"), dom_flt.col("te"), dom_flt.col("al"), dom_n,
-                          f64([s._domestic_leg._spread for s in swaps]), dom_s, dom_s)
+    return RawXccy(np.asarray(d_off, dtype=np.int64), cat("dtp"), cat("dts"), cat("dte"), cat("dal"),
+                   np.asarray(f_off, dtype=np.int64), cat("ftp"), cat("fts"), cat("fte"), cat("fal"),
+                   f64(d_ex).reshape(-1, 2), f64(f_ex).reshape(-1, 2),
+                   np.array([bool(s._domestic_leg._notional_exchange) for s in swaps], dtype=bool),
+                   np.array([bool(s._foreign_leg._notional_exchange) for s in swaps], dtype=bool),
+                   f64([s._domestic_leg._notional for s in swaps]), f64([s._foreign_leg._notional for s in swaps]),
+                   f64([s._domestic_leg._spread for s in swaps]), f64([s._foreign_leg._spread for s in swaps]),
+                   f64([_sign(s._domestic_leg) for s in swaps]), f64([_sign(s._foreign_leg) for s in swaps]))
+
+
+@dataclass
+class XccyTerms:
+    """Economic terms of n basis swaps on one currency pair (the `XccyBasisSwap` constructor arguments of the same
+    names; scalars broadcast, sequences have length n).  ``effective_dt``: `Date`s or integer Excel serials;
+    ``tenor``: tenor strings."""
+    effective_dt: object
+    tenor: object
+    domestic_notional: object
+    foreign_notional: object
+    domestic_spread: object
+    foreign_spread: object
+    domestic_freq_type: object
+    foreign_freq_type: object
+    domestic_dc_type: object
+    foreign_dc_type: object
+    domestic_floating_index: object
+    foreign_floating_index: object
+    domestic_currency: object
+    foreign_currency: object
+    domestic_payment_lag: object = 0
+    foreign_payment_lag: object = 0
+
+
+def raw_from_terms(terms: XccyTerms, value_dt, xdc) -> RawXccy:
+    """`RawXccy` of swaps given by their terms, without per-swap objects: one template swap per distinct combination
+    of schedule-defining terms (dates, frequencies, day counts, lags), per-swap arrays gathered with NumPy - the
+    cross-currency counterpart of `trades.compiler.compile_ois_terms`."""
+    from ...trades.compiler import _column
+    from ...trades.rates.xccy_basis_swap import XccyBasisSwap
+    from ...utils.date import Date
+    dom_n = np.asarray(terms.domestic_notional, dtype=np.float64).reshape(-1)
+    n = dom_n.shape[0]
+    col = lambda v, kind: _column(v, n, kind)
+    eff = col(terms.effective_dt, "date")
+    dlag, flag = col(terms.domestic_payment_lag, "int"), col(terms.foreign_payment_lag, "int")
+    coded = {k: col(v, "code") for k, v in (("tenor", terms.tenor), ("dfreq", terms.domestic_freq_type),
+                                             ("ffreq", terms.foreign_freq_type), ("ddc", terms.domestic_dc_type),
+                                             ("fdc", terms.foreign_dc_type))}
+    keys, inverse = np.unique(np.stack([eff, dlag, flag] + [coded[k][0] for k in coded], axis=1), axis=0, return_inverse=True)
+    inverse = inverse.reshape(-1)
+    one = lambda v: v[0] if isinstance(v, (list, tuple, np.ndarray)) else v
+    names = list(coded)
+    templates = []
+    for row in keys:
+        kw = {k: coded[k][1][int(row[3 + j])] for j, k in enumerate(names)}
+        swap = XccyBasisSwap(effective_dt=Date._from_serial(int(row[0])), term_dt_or_tenor=kw["tenor"],
+                             domestic_notional=1.0, foreign_notional=1.0, domestic_spread=0.0, foreign_spread=0.0,
+                             domestic_freq_type=kw["dfreq"], foreign_freq_type=kw["ffreq"], domestic_dc_type=kw["ddc"],
+                             foreign_dc_type=kw["fdc"], domestic_floating_index=one(terms.domestic_floating_index),
+                             foreign_floating_index=one(terms.foreign_floating_index),
+                             domestic_currency=one(terms.domestic_currency), foreign_currency=one(terms.foreign_currency),
+                             domestic_payment_lag=int(row[1]), foreign_payment_lag=int(row[2]))
+        templates.append(raw_from_swaps([swap], value_dt, xdc))
+
+    def gather(off_name, fields):
+        counts = np.array([int(getattr(t, off_name)[1]) for t in templates], dtype=np.int64)
+        lens = counts[inverse]
+        off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+        starts = np.concatenate(([0], np.cumsum(counts)))[:-1]
+        idx = np.repeat(starts[inverse] - off[:-1], lens) + np.arange(off[-1])
+        return off, [np.concatenate([getattr(t, f) for t in templates])[idx] for f in fields]
+
+    d_off, (dtp, dts, dte, dal) = gather("dom_off", ("dom_tp", "dom_ts", "dom_te", "dom_al"))
+    f_off, (ftp, fts, fte, fal) = gather("for_off", ("for_tpx", "for_ts", "for_te", "for_al"))
+    d_ex = np.concatenate([t.dom_exch_t for t in templates])[inverse]
+    f_ex = np.concatenate([t.for_exch_t for t in templates])[inverse]
+    yes = np.ones(n, dtype=bool)
+    return RawXccy(d_off, dtp, dts, dte, dal, f_off, ftp, fts, fte, fal, d_ex, f_ex, yes, yes,
+                   dom_n.copy(), col(terms.foreign_notional, "float"), col(terms.domestic_spread, "float"),
+                   col(terms.foreign_spread, "float"), np.ones(n), -np.ones(n))     # domestic received, foreign paid
+
+
+def _exchange_flows(t2, notional, on, sign, scale):
+    """Fixed flows (-N at the effective time, +N at maturity) of the legs that exchange notional: those strictly
+    after the value time as CSR arrays, those AT the value time (discount factor 1) as a PV constant per swap."""
+    amounts = np.stack([-notional, notional], axis=1)
+    keep = on[:, None] & (t2 > 0.0)
+    const = np.where(on[:, None] & (t2 == 0.0), sign[:, None] * amounts / scale, 0.0).sum(axis=1)
+    off = np.concatenate(([0], np.cumsum(keep.sum(axis=1)))).astype(np.int64)
+    return off, t2[keep], amounts[keep], const
+
+
+def compile_xccy(raw: RawXccy, spot, df_x, df_f):
+    """The three trade batches of the assembly above, plus the per-swap PV of the flows dated at the value time.
+
+    ``df_x(t)`` / ``df_f(t)``: discount factors off the XCCY curve and off the foreign OIS curve's engine grid at
+    arrays of times - on the product path the device lookups of `adr_curve_df` (the reference evaluates them inside
+    its leg function, engine.py:1640-1712).  Returns ``(domestic, foreign_rates, foreign_flows, pv_const)``;
+    ``foreign_rates`` carries `flt_weight`."""
+    n = raw.n
+    zeros_n, none = np.zeros(n), np.zeros(0)
+    dfix_off, dfix_tp, dfix_pay, pv_const = _exchange_flows(raw.dom_exch_t, raw.dom_n, raw.dom_exch, raw.dom_sign, 1.0)
+    domestic = TradeBatch(dfix_off, raw.dom_off, dfix_tp, dfix_pay, raw.dom_tp, raw.dom_ts, raw.dom_te, raw.dom_al,
+                          raw.dom_n, raw.dom_spread, raw.dom_sign, raw.dom_sign)
 
     # foreign coupons, all swaps at once: forwards off the foreign OIS grid, discount factors off the XCCY knots
-    off = for_flt.offsets()
+    off = raw.for_off
     owner = np.repeat(np.arange(n), np.diff(off))
-    tp_x, ts, te, al = for_flt.col("tp_x"), for_flt.col("ts"), for_flt.col("te"), for_flt.col("al")
-    c = knot_df(x_times, x_dfs, tp_x, x_method) / knot_df(x_times, x_dfs, 0.0, x_method)   # relative to the value time
+    tp_x, ts, te, al = raw.for_tpx, raw.for_ts, raw.for_te, raw.for_al
+    c = df_x(tp_x) / df_x(0.0)                                          # relative to the value time
     accrues = al > 0
-    fwd = np.where(accrues, (knot_df(for_times, for_dfs, ts, for_method) / knot_df(for_times, for_dfs, te, for_method)
-                             - 1.0) / np.where(accrues, al, 1.0), 0.0)
+    fwd = np.where(accrues, (df_f(ts) / df_f(te) - 1.0) / np.where(accrues, al, 1.0), 0.0)
     live = tp_x >= 0.0
     keep = live & accrues
     kept_off = np.concatenate(([0], np.cumsum(np.bincount(owner[keep], minlength=n)))).astype(np.int64)
-    zeros_n, none = np.zeros(n), np.zeros(0)
     foreign_rates = TradeBatch(np.zeros(n + 1, dtype=np.int64), kept_off, none, none, np.zeros(int(keep.sum())),
-                               ts[keep], te[keep], al[keep], for_n, zeros_n, for_s, for_s, flt_weight=c[keep])
+                               ts[keep], te[keep], al[keep], raw.for_n, zeros_n, raw.for_sign, raw.for_sign,
+                               flt_weight=c[keep])
 
-    spreads = f64([s._foreign_leg._spread for s in swaps])
-    amounts = (fwd + spreads[owner]) * al * for_n[owner]
+    amounts = (fwd + raw.for_spread[owner]) * al * raw.for_n[owner]
     at_value_time = live & (tp_x == 0.0)
-    np.add.at(pv_const, owner[at_value_time], (for_s[owner] * amounts)[at_value_time] / spot)
+    np.add.at(pv_const, owner[at_value_time], (raw.for_sign[owner] * amounts)[at_value_time] / spot)
+    e_off, e_tp, e_pay, e_const = _exchange_flows(raw.for_exch_t, raw.for_n, raw.for_exch, raw.for_sign, spot)
+    pv_const = pv_const + e_const
     later = live & (tp_x > 0.0)
     # per swap: its later coupons, then its exchanges
-    cnt = np.bincount(owner[later], minlength=n) + np.diff(exch.offsets())
+    cnt = np.bincount(owner[later], minlength=n) + np.diff(e_off)
     fix_off = np.concatenate(([0], np.cumsum(cnt))).astype(np.int64)
     flow_tp, flow_pay = np.empty(int(fix_off[-1])), np.empty(int(fix_off[-1]))
     c_owner = owner[later]                                  # sorted: the coupons are laid out swap by swap
     c_first = np.concatenate(([0], np.cumsum(np.bincount(c_owner, minlength=n))))[:-1]
     coupon_pos = fix_off[:-1][c_owner] + (np.arange(c_owner.size) - c_first[c_owner])     # from the swap's first slot
     flow_tp[coupon_pos], flow_pay[coupon_pos] = tp_x[later], amounts[later]
-    e_off = exch.offsets()
     e_owner = np.repeat(np.arange(n), np.diff(e_off))
     exch_pos = fix_off[1:][e_owner] - (e_off[1:][e_owner] - np.arange(e_off[-1]))         # back from its last slot
-    flow_tp[exch_pos], flow_pay[exch_pos] = exch.col("tp"), exch.col("pay")
+    flow_tp[exch_pos], flow_pay[exch_pos] = e_tp, e_pay
     foreign_flows = TradeBatch(fix_off, np.zeros(n + 1, dtype=np.int64), flow_tp, flow_pay, none, none, none, none,
-                               for_n, zeros_n, for_s, for_s)
-    return domestic, foreign_rates, foreign_flows, pv_const, spot
+                               raw.for_n, zeros_n, raw.for_sign, raw.for_sign)
+    return domestic, foreign_rates, foreign_flows, pv_const
 
 
 def _xccy_device_curve(ctx, xccy):
@@ -200,15 +252,20 @@ def _trim(a, kind, P):
 
 
 def _curves(engine, swaps):
-    model = engine.model
     first = swaps[0]
     for s in swaps:
         if (s._domestic_floating_index, s._foreign_floating_index, s._domestic_currency, s._foreign_currency) != \
            (first._domestic_floating_index, first._foreign_floating_index, first._domestic_currency, first._foreign_currency):
             raise LibError("a batch of cross-currency swaps must share its currencies and floating indices")
-    dom_model = getattr(model.curves, first._domestic_floating_index.name)
-    for_model = getattr(model.curves, first._foreign_floating_index.name)
-    name = f"{first._foreign_currency.name}_{first._domestic_currency.name}_BASIS"
+    return _curves_for(engine, first._domestic_floating_index, first._foreign_floating_index,
+                       first._domestic_currency, first._foreign_currency)
+
+
+def _curves_for(engine, dom_index, for_index, dom_ccy, for_ccy):
+    model = engine.model
+    dom_model = getattr(model.curves, dom_index.name)
+    for_model = getattr(model.curves, for_index.name)
+    name = f"{for_ccy.name}_{dom_ccy.name}_BASIS"
     try:
         xccy = getattr(model.curves, name)
     except AttributeError:
@@ -220,21 +277,40 @@ def _curves(engine, swaps):
     return dom_model, for_model, xccy, dom_cur, for_cur, x_dev
 
 
+def book_batches(engine, swaps):
+    """Curves and the three trade batches of a book given as `XccyBasisSwap` objects or as `XccyTerms`:
+    ``(dom_model, for_model, xccy, dom_cur, for_cur, x_dev, (domestic, foreign_rates, foreign_flows), pv_const, spot)``.
+    The per-coupon discount factors come from the device (`adr_curve_df` on the uploaded XCCY and foreign tables)."""
+    if isinstance(swaps, XccyTerms):
+        one = lambda v: v[0] if isinstance(v, (list, tuple, np.ndarray)) else v
+        cur = _curves_for(engine, one(swaps.domestic_floating_index), one(swaps.foreign_floating_index),
+                          one(swaps.domestic_currency), one(swaps.foreign_currency))
+    else:
+        swaps = list(swaps)
+        if not swaps:
+            raise LibError("price_xccy_batch needs at least one swap (the book's currency pair names its curves)")
+        cur = _curves(engine, swaps)
+    dom_model, for_model, xccy, dom_cur, for_cur, x_dev = cur
+    ctx = dom_cur["ctx"]
+    raw = (raw_from_terms(swaps, engine.model.value_dt, xccy._dc_type) if isinstance(swaps, XccyTerms)
+           else raw_from_swaps(swaps, engine.model.value_dt, xccy._dc_type))
+    spot = xccy._spot_fx
+    domestic, foreign_rates, foreign_flows, pv_const = compile_xccy(
+        raw, spot, lambda t: _native.curve_df(ctx, x_dev, t), lambda t: _native.curve_df(ctx, for_cur["dev"], t))
+    return cur + ((domestic, foreign_rates, foreign_flows), pv_const, spot)
+
+
 def price_xccy_batch(engine, swaps, reqs, per_trade=True, aggregate=False):
     """VALUE / DELTA / GAMMA of a book of cross-currency basis swaps on one currency pair: three launches.
+    ``swaps``: `XccyBasisSwap` objects, or `XccyTerms` (no per-swap objects: the vectorised compiler).
 
     Returns a dict: ``pv [n]``, ``delta_dom [n, P_d]``, ``delta_for [n, P_f]``, ``delta_basis [n, P_b]`` and the
     three ``gamma_*`` (per request, when ``per_trade``), ``agg_*`` sums over the book (when ``aggregate``);
     everything in domestic currency, per bp / bp^2."""
     reqs = set(reqs)
-    swaps = list(swaps)
-    if not swaps:
-        raise LibError("price_xccy_batch needs at least one swap (the book's currency pair names its curves)")
-    dom_model, for_model, xccy, dom_cur, for_cur, x_dev = _curves(engine, swaps)
+    (dom_model, for_model, xccy, dom_cur, for_cur, x_dev,
+     (domestic, foreign_rates, foreign_flows), pv_const, spot) = book_batches(engine, swaps)
     ctx = dom_cur["ctx"]
-    f_host = for_cur["host"]
-    domestic, foreign_rates, foreign_flows, pv_const, spot = compile_xccy(
-        swaps, engine.model.value_dt, xccy, f_host.times, f_host.dfs, for_model._interp_type.value)
     want_value = RequestTypes.VALUE in reqs
     want_gamma = RequestTypes.GAMMA in reqs
     want_delta = want_gamma or RequestTypes.DELTA in reqs
@@ -296,16 +372,16 @@ def compute_ois_xccy_collateral(engine, derivative, reqs, collateral_ccy):
     value_dt = model.value_dt
     fx, fl = derivative._fixed_leg, derivative._float_leg
     dc = fx._dc_type
-    x_times, x_dfs, x_method = np.asarray(xccy._times), np.asarray(xccy._dfs), xccy._interp_type.value
     ois_cur = engine._device_curve(ois_model)
-    ctx, o_host = ois_cur["ctx"], ois_cur["host"]
-    o_method = ois_model._interp_type.value
+    ctx = ois_cur["ctx"]
+    x_dev = _xccy_device_curve(ctx, xccy)
+    df_o = lambda t: _native.curve_df(ctx, ois_cur["dev"], t)       # forwards off the swap's own OIS tables
+    df_x = lambda t: _native.curve_df(ctx, x_dev, t)                # discounting off the XCCY tables
 
     tp, ts, te = (_times(d, value_dt, dc) for d in (fl._payment_dts, fl._start_accrued_dts, fl._end_accrued_dts))
     al = np.asarray(fl._year_fracs, dtype=np.float64)
     accrues, live = al > 0, tp >= 0.0
-    fwd = np.where(accrues, (knot_df(o_host.times, o_host.dfs, ts, o_method) / knot_df(o_host.times, o_host.dfs, te, o_method)
-                             - 1.0) / np.where(accrues, al, 1.0), 0.0)
+    fwd = np.where(accrues, (df_o(ts) / df_o(te) - 1.0) / np.where(accrues, al, 1.0), 0.0)
     amounts = _sign(fl) * (fwd + fl._spread) * al * fl._notional
     fixed_tp = _times(fx._payment_dts, value_dt, dc)
     fixed_pay = _sign(fx) * fx._cpn * np.asarray(fx._year_fracs, dtype=np.float64) * fx._notional
@@ -319,7 +395,6 @@ def compute_ois_xccy_collateral(engine, derivative, reqs, collateral_ccy):
                        one, zero, one, one)
     want_delta = RequestTypes.DELTA in reqs
     has_jac = getattr(xccy, "_jac_basis", None) is not None
-    x_dev = _xccy_device_curve(ctx, xccy)
     on_x = _price(ctx, x_dev, flows, dict(want_value=True, want_delta=want_delta and has_jac, want_gamma=False))
 
     value = delta = cashflows = None
@@ -327,7 +402,7 @@ def compute_ois_xccy_collateral(engine, derivative, reqs, collateral_ccy):
         value = Valuation(amount=float(on_x["pv"][0] + pv_const) / spot, currency=collateral_ccy)
     if want_delta:
         keep = live & accrues
-        weight = knot_df(x_times, x_dfs, tp[keep], x_method) / knot_df(x_times, x_dfs, 0.0, x_method)
+        weight = df_x(tp[keep]) / df_x(0.0)
         m = int(keep.sum())
         rates = TradeBatch(np.array([0, 0]), np.array([0, m]), none, none, np.zeros(m), ts[keep], te[keep], al[keep],
                            np.array([fl._notional]), zero, one, np.array([_sign(fl)]), flt_weight=weight)

@@ -2,10 +2,13 @@
 
 Market: the two 32-pillar quote sets of the reference's tests (GBP SONIA ACT/365F, USD SOFR ACT/360, both
 FLAT_FWD_RATES here) and a 17-pillar GBP/USD basis curve, 25 bp at 1Y rising linearly to 45 bp at 40Y.
-Book: basis swaps receive SONIA flat / pay SOFR + 30 bp, maturity 1-30 years, effective today or 4 / 9 months
-ago (a third each), annual domestic leg, annual or semi-annual foreign leg; 180 distinct swaps are compiled once
-(`xccy_engine.compile_xccy`) and a book of ``n`` swaps draws from them with notional multipliers
-round(U(1, 50), 1) - `numpy.random.default_rng(seed)`.
+Book (`synthesize_book`): every swap is drawn on its own - receive SONIA + U(0, 5 bp) / pay SOFR + U(10, 60 bp),
+remaining maturity U{12..360} whole months, effective today or 4 / 9 months ago (a third each), annual domestic leg,
+annual or semi-annual foreign leg, foreign notional round(U(1e6, 5e7), -5), domestic notional = spot x foreign -
+`numpy.random.default_rng(seed)`; about 2 000 distinct schedules, no two swaps alike.  The terms go through the
+vectorised compiler (`xccy_engine.raw_from_terms`: one template per distinct schedule, NumPy gathers) and the
+per-coupon discount factors through the device lookups (`adr_curve_df`).  `template_swaps` / `take` remain for the
+small object-path tests.
 """
 from __future__ import annotations
 
@@ -75,23 +78,48 @@ def take(batch: TradeBatch, pick, scale) -> TradeBatch:
                       cols[4] if weighted else None)
 
 
-def synthesize_book(engine, value_dt, n, seed=20240430, rank=0, world_size=1):
-    """The three trade batches of a book of ``n`` swaps (see `xccy_engine.compile_xccy`) and their device curves:
-    ``[(batch, device curve)] * 3`` in the order domestic, foreign rates, foreign flows, plus ``spot``.
-    With ``world_size > 1``: rank ``rank``'s contiguous share of that ONE book, cut by coupon count
-    (`distributed.shard_by_work`)."""
-    from ..market.position import xccy_engine as XE
-    templates = template_swaps(value_dt)
-    dom_model, for_model, xccy, dom_cur, for_cur, x_dev = XE._curves(engine, templates)
-    dom, rates, flows, _, spot = XE.compile_xccy(templates, value_dt, xccy, for_cur["host"].times, for_cur["host"].dfs,
-                                                 for_model._interp_type.value)
+def draw_terms(value_dt, n, seed=20240430):
+    """`xccy_engine.XccyTerms` of ``n`` distinct swaps, and an estimate of each swap's coupon count (for sharding)."""
+    from ..market.position.xccy_engine import XccyTerms
     rng = np.random.default_rng(seed)
-    pick = rng.integers(0, len(templates), n)
-    scale = np.round(rng.uniform(1.0, 50.0, n), 1)
+    months = rng.integers(12, 361, n)
+    back = np.array([0, 4, 9])[rng.integers(0, 3, n)]
+    semi = rng.random(n) < 0.5
+    for_n = np.round(rng.uniform(1e6, 5e7, n), -5)
+    eff_of = {int(b): int(value_dt.add_months(-int(b)).excel_dt()) for b in (0, 4, 9)}
+    tenor_of = {int(m): f"{int(m)}M" for m in np.unique(months + back)}
+    terms = XccyTerms(effective_dt=np.array([eff_of[int(b)] for b in back], dtype=np.int64),
+                      tenor=[tenor_of[int(m)] for m in months + back],
+                      domestic_notional=SPOT * for_n, foreign_notional=for_n,
+                      domestic_spread=np.round(rng.uniform(0.0, 0.0005, n), 6),
+                      foreign_spread=np.round(rng.uniform(0.0010, 0.0060, n), 6),
+                      domestic_freq_type=FrequencyTypes.ANNUAL,
+                      foreign_freq_type=[FrequencyTypes.SEMI_ANNUAL if x else FrequencyTypes.ANNUAL for x in semi],
+                      domestic_dc_type=DayCountTypes.ACT_365F, foreign_dc_type=DayCountTypes.ACT_360,
+                      domestic_floating_index=CurveTypes.GBP_OIS_SONIA, foreign_floating_index=CurveTypes.USD_OIS_SOFR,
+                      domestic_currency=CurrencyTypes.GBP, foreign_currency=CurrencyTypes.USD)
+    years = (months + back + 11) // 12
+    return terms, years * (2 + semi.astype(np.int64))
+
+
+def slice_terms(terms, lo, hi):
+    """Swaps lo..hi-1 of an `XccyTerms` (per-swap sequences are cut, scalars kept)."""
+    import dataclasses
+    n = len(np.asarray(terms.domestic_notional).reshape(-1))
+    cut = lambda v: v[lo:hi] if isinstance(v, (list, tuple, np.ndarray)) and len(v) == n else v
+    return dataclasses.replace(terms, **{f.name: cut(getattr(terms, f.name)) for f in dataclasses.fields(terms)})
+
+
+def synthesize_book(engine, value_dt, n, seed=20240430, rank=0, world_size=1):
+    """The three trade batches of a book of ``n`` distinct swaps (see `xccy_engine.compile_xccy`) and their device
+    curves: ``[(batch, device curve)] * 3`` in the order domestic, foreign rates, foreign flows, plus ``spot``.
+    With ``world_size > 1``: rank ``rank``'s contiguous share of that ONE book, cut by coupon count
+    (`distributed.shard_by_work`); only the share is compiled."""
+    from ..market.position import xccy_engine as XE
+    terms, work = draw_terms(value_dt, n, seed)
     if world_size > 1:
         from ..distributed import shard_by_work
-        work = (np.diff(dom.flt_off) + np.diff(rates.flt_off) + np.diff(flows.fix_off))[pick]
         lo, hi = shard_by_work(work, world_size)[rank]
-        pick, scale = pick[lo:hi], scale[lo:hi]
-    return [(take(dom, pick, scale), dom_cur["dev"]), (take(rates, pick, scale), for_cur["dev"]),
-            (take(flows, pick, scale), x_dev)], spot
+        terms = slice_terms(terms, lo, hi)
+    dom_model, for_model, xccy, dom_cur, for_cur, x_dev, (dom, rates, flows), pv_const, spot = XE.book_batches(engine, terms)
+    return [(dom, dom_cur["dev"]), (rates, for_cur["dev"]), (flows, x_dev)], spot

@@ -221,6 +221,16 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
                   double* pv_dev, double* delta_dev, double* gamma_dev, double* agg_dev,
                   void* stream);
 
+/*
+ * Discount factors at n query times off an uploaded curve: InterpolatorAd.simple_interpolate evaluated on the GPU
+ * (cavour/market/curves/interpolator_ad.py:186-249; same snap / + 1e-12 / duplicate-knot semantics as the pricing
+ * kernels, all three schemes).  Replaces the reference's df lookups inside the cross-currency leg function
+ * (cavour/market/position/engine.py:1640-1712: D_x(tp_j), D_f(ts_j), D_f(te_j)).  adr_curve_df takes and fills host
+ * arrays and blocks; adr_curve_df_dev takes device arrays and enqueues on `stream` (NULL = the ctx's own).
+ */
+int adr_curve_df(adr_ctx* ctx, const adr_curve* curve, int64_t n, const double* t, double* df);
+int adr_curve_df_dev(adr_ctx* ctx, const adr_curve* curve, int64_t n, const double* t_dev, double* df_dev, void* stream);
+
 /* Wait for everything enqueued on the ctx's own stream. */
 int adr_sync(adr_ctx* ctx);
 

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: the longer GPU cases (still part of -m gpu)")
 
 
 @pytest.fixture(scope="session")
@@ -25,4 +26,4 @@ def native_lib():
 @pytest.fixture(scope="session")
 def gpu_ctx(native_lib):
     from adrates_amd import _native
-    return _native.Context(0)
+    return _native.default_context(0)      # one context for the whole suite: the engine's uploads go through it too

@@ -98,7 +98,7 @@ def _mixed_aggregates(rank, world):
     from oracle import cavour_oracle as O
     from oracle import port
     from tests.test_gpu_xccy import VALUE_DT, _model
-    from tests.test_xccy_engine_host import _HostCurve, _HostTrades, _host_price
+    from tests.test_xccy_engine_host import _HostCurve, _HostTrades, _host_curve_df, _host_price
     m = _model()
     gbp = m.curves.GBP_OIS_SONIA
     cache = O.cached_curve(gbp.swap_rates, gbp.swap_times, gbp.year_fracs)
@@ -109,7 +109,8 @@ def _mixed_aggregates(rank, world):
     book = _mixed_book()
     lo, hi = D.shard_by_work([len(s._foreign_leg._payment_dts) + len(s._domestic_leg._payment_dts) for s in book], world)[rank]
     with mock.patch.object(_native, "DeviceCurve", _HostCurve), mock.patch.object(_native, "DeviceTrades", _HostTrades), \
-         mock.patch.object(_native, "price", _host_price), mock.patch.object(_native, "default_context", lambda: None):
+         mock.patch.object(_native, "price", _host_price), mock.patch.object(_native, "default_context", lambda: None), \
+         mock.patch.object(_native, "curve_df", _host_curve_df):
         x = xccy_engine.price_xccy_batch(Engine(m), book[lo:hi], {RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA},
                                          per_trade=False, aggregate=True)
     out.update({k: v for k, v in x.items() if k.startswith("agg_")})

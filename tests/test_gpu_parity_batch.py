@@ -81,13 +81,16 @@ def test_request_subsets_and_small_pillar_curve(gpu_ctx):
     only_v = _native.price(gpu_ctx, dc, dt, want_delta=False, want_gamma=False)
     only_d = _native.price(gpu_ctx, dc, dt, want_gamma=False)
     assert set(only_v) == {"pv"} and set(only_d) == {"pv", "delta"}
-    assert np.array_equal(only_v["pv"], full["pv"]) and np.array_equal(only_d["delta"], full["delta"])
+    # requests without GAMMA run on the lite kernel (kernels_lite.hip): same numbers up to summation order
+    assert_batch_parity(only_v, ref, batch.notional)
+    assert_batch_parity(only_d, ref, batch.notional)
+    assert np.allclose(only_d["delta"], full["delta"], rtol=1e-12, atol=1e-9)
     # a curve uploaded without the Hessian cannot serve GAMMA
     no_h = _native.DeviceCurve(gpu_ctx, 4, host.times, host.dfs, host.jac, None)
     from adrates_amd.utils import LibError
     with pytest.raises(LibError):
         _native.price(gpu_ctx, no_h, dt)
-    assert np.array_equal(_native.price(gpu_ctx, no_h, dt, want_gamma=False)["delta"], full["delta"])
+    assert np.array_equal(_native.price(gpu_ctx, no_h, dt, want_gamma=False)["delta"], only_d["delta"])
     # non-finite trade inputs are refused at upload, with a message
     import copy
     for field, value in (("flt_tp", np.nan), ("fix_pay", np.inf), ("notional", np.nan)):
@@ -241,9 +244,9 @@ def test_payment_lag_portfolio_vs_c_oracle(gpu_ctx, interp):
     assert np.allclose(got["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
     assert np.allclose(got["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
     assert np.allclose(got["agg_pv"], ref["pv"].sum(), rtol=1e-10, atol=1e-3)
-    # value-only request: same PVs from the small kernels
-    assert np.array_equal(_native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), want_delta=False,
-                                        want_gamma=False)["pv"], got["pv"])
+    # value-only request (lite kernel for the trades without payment lag): same PVs up to summation order
+    only_v = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), want_delta=False, want_gamma=False)
+    assert_batch_parity(only_v, ref, batch.notional)
     print(f"{interp.name}: worst error {worst:.2e}")
 
 
@@ -276,8 +279,9 @@ def test_long_legs_as_row_chains_vs_c_oracle(gpu_ctx):
     assert np.allclose(got["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
     assert np.allclose(got["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
     assert np.allclose(got["agg_pv"], ref["pv"].sum(), rtol=1e-10, atol=1e-3)
-    only_d = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), want_gamma=False)
-    assert np.array_equal(only_d["delta"], got["delta"]) and np.array_equal(only_d["pv"], got["pv"])
+    only_d = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), want_gamma=False, aggregate=True)
+    assert_batch_parity(only_d, ref, batch.notional)       # short trades: lite kernel, chains: fast kernel, 200 coupons: general
+    assert np.allclose(only_d["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6) and np.all(only_d["agg_gamma"] == 0.0)
     print(f"long legs: worst error {worst:.2e}")
 
 

@@ -14,12 +14,12 @@ out = {"tag": tag}
 for name in ("fetch", "write"):
     vals = {}
     for r in csv.DictReader(open(newest(f"{base}/{name}/*/*counter_collection.csv"))):
-        if "price_fast" in r["Kernel_Name"] or "price_general" in r["Kernel_Name"]:
+        if "price_" in r["Kernel_Name"]:
             vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for k, v in vals.items():
         out[k + "_KiB_per_launch"] = sum(v) / len(v)
 for r in csv.DictReader(open(stats)):
-    if "price_fast" in r["Name"]:
+    if "price_" in r["Name"] and "kernel" not in out:
         out["kernel"] = r["Name"].split("(")[0]
         out["avg_ns"] = float(r["AverageNs"]); out["calls"] = int(r["Calls"])
         out["min_ns"] = float(r["MinNs"]); out["max_ns"] = float(r["MaxNs"])
