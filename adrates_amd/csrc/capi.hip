@@ -779,9 +779,8 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
             return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^28 rows in the delta-only table; shard the portfolio");
         }
         const size_t n_slots = static_cast<size_t>(units) * G, n_rows = static_cast<size_t>(rows);
-        std::vector<double> r_tp(n_rows * S, 0.0), r_ts(n_rows * S, 0.0), r_al(n_rows * S, 0.0), r_xtp(n_rows * S, 0.0),
-            r_xpay(n_rows * S, 0.0), r_n(n_slots, 0.0), r_sp(n_slots, 0.0);
-        std::vector<int32_t> r_meta(n_slots, 0), r_trade(n_slots, -1);
+        std::vector<double> r_tpts(n_rows * S * 2, 0.0), r_alxtp(n_rows * S * 2, 0.0), r_xpay(n_rows * S, 0.0);
+        std::vector<adr::LiteTrade> r_slot(n_slots, adr::LiteTrade{0.0, 0.0, 0, -1, 0});
         for (int k = 0; k < adr::kLiteSegments; ++k) {
             const int R = lt.seg_rows[k];
             for (size_t i = 0; i < seg_trades[k].size(); ++i) {
@@ -791,27 +790,23 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
                 const int64_t ml = flt_off[t + 1] - flt_off[t], mf = fix_off[t + 1] - fix_off[t];
                 for (int64_t j = 0; j < ml; ++j) {
                     const size_t at = (row0 + static_cast<size_t>(j / C)) * S + static_cast<size_t>(j % C);
-                    r_tp[at] = flt_tp[flt_off[t] + j]; r_ts[at] = flt_ts[flt_off[t] + j]; r_al[at] = flt_alpha[flt_off[t] + j];
+                    r_tpts[2 * at] = flt_tp[flt_off[t] + j]; r_tpts[2 * at + 1] = flt_ts[flt_off[t] + j];
+                    r_alxtp[2 * at] = flt_alpha[flt_off[t] + j];
                 }
                 for (int64_t j = 0; j < mf; ++j) {
                     const size_t at = (row0 + static_cast<size_t>(j / C)) * S + static_cast<size_t>(j % C);
-                    r_xtp[at] = fix_tp[fix_off[t] + j]; r_xpay[at] = fix_pay[fix_off[t] + j];
+                    r_alxtp[2 * at + 1] = fix_tp[fix_off[t] + j]; r_xpay[at] = fix_pay[fix_off[t] + j];
                 }
-                r_n[slot] = notional[t]; r_sp[slot] = spread[t];
-                r_trade[slot] = static_cast<int32_t>(t);
-                r_meta[slot] = static_cast<int32_t>(ml | (mf << 8) | ((flt_sign[t] < 0.0) ? 0x10000 : 0) |
-                                                    ((fix_sign[t] < 0.0) ? 0x20000 : 0));
+                r_slot[slot].notional = notional[t]; r_slot[slot].spread = spread[t];
+                r_slot[slot].trade = static_cast<int32_t>(t);
+                r_slot[slot].meta = static_cast<int32_t>(ml | (mf << 8) | ((flt_sign[t] < 0.0) ? 0x10000 : 0) |
+                                                         ((fix_sign[t] < 0.0) ? 0x20000 : 0));
             }
         }
-        lt.tp = static_cast<const double*>(put(r_tp.data(), r_tp.size() * sizeof(double)));
-        lt.ts = static_cast<const double*>(put(r_ts.data(), r_ts.size() * sizeof(double)));
-        lt.alpha = static_cast<const double*>(put(r_al.data(), r_al.size() * sizeof(double)));
-        lt.xtp = static_cast<const double*>(put(r_xtp.data(), r_xtp.size() * sizeof(double)));
+        lt.tp_ts = static_cast<const double*>(put(r_tpts.data(), r_tpts.size() * sizeof(double)));
+        lt.al_xtp = static_cast<const double*>(put(r_alxtp.data(), r_alxtp.size() * sizeof(double)));
         lt.xpay = static_cast<const double*>(put(r_xpay.data(), r_xpay.size() * sizeof(double)));
-        lt.notional = static_cast<const double*>(put(r_n.data(), r_n.size() * sizeof(double)));
-        lt.spread = static_cast<const double*>(put(r_sp.data(), r_sp.size() * sizeof(double)));
-        lt.meta = static_cast<const int32_t*>(put(r_meta.data(), r_meta.size() * sizeof(int32_t)));
-        lt.trade = static_cast<const int32_t*>(put(r_trade.data(), r_trade.size() * sizeof(int32_t)));
+        lt.slot = static_cast<const adr::LiteTrade*>(put(r_slot.data(), r_slot.size() * sizeof(adr::LiteTrade)));
     }
     if (e != hipSuccess) { adr_free_trades(tr); return fail_hip(e, "adr_trades_upload: copying trades"); }
     *out = tr;

@@ -37,9 +37,14 @@ std::string build_curve_tables(int K, int P, const double* times, const double* 
         const int n_lut = std::min(kLutMax, static_cast<int>(t_last * kLutPerYear) + 2);
         out.lut.assign(2 * static_cast<size_t>(n_lut), 0);
         auto first_later = [&](double tau) { return static_cast<int>(std::upper_bound(times, times + K, tau) - times); };
+        auto first_at_or_later = [&](double tau) { return static_cast<int>(std::lower_bound(times, times + K, tau) - times); };
+        // A time t in bucket b satisfies b/4 <= t < (b+1)/4 (the scaling by 4 is exact), so the first knot later than t
+        // is no earlier than the first knot later than b/4 and no later than the first knot AT OR AFTER (b+1)/4.  The
+        // upper end matters: pillar dates sit on whole years = bucket boundaries and are runs of up to 17 duplicate
+        // knots - bounded by "later than (b+1)/4" every search in the quarter before a pillar date had to walk the run.
         for (int b = 0; b < n_lut; ++b) {
             out.lut[2 * b] = static_cast<int16_t>(b == 0 ? 0 : first_later(b / kLutPerYear));
-            out.lut[2 * b + 1] = static_cast<int16_t>(b + 1 == n_lut ? K : first_later((b + 1) / kLutPerYear));
+            out.lut[2 * b + 1] = static_cast<int16_t>(b + 1 == n_lut ? K : first_at_or_later((b + 1) / kLutPerYear));
         }
     }
 

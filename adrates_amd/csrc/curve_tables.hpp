@@ -46,8 +46,8 @@ struct CurveTables {
     bool packed_ok = false;            // packed layout below is usable
     std::vector<double> x;             // [K]   knot times (full grid, for the search)
     // search accelerator: bucket b = [b / kLutPerYear, (b + 1) / kLutPerYear) of time; the first knot later than
-    // a time in the bucket has an index in [lut[2b], lut[2b + 1]] (bucket 0 also takes negative times, the last
-    // bucket everything later)
+    // a time in the bucket has an index in [lut[2b], lut[2b + 1]] = [first knot later than the bucket's start, first
+    // knot at or after its end] (bucket 0 also takes negative times, the last bucket everything later)
     std::vector<int16_t> lut;          // [n_lut][2]
     std::vector<int32_t> first_of;     // [K]   first index of the run of equal times containing k
     std::vector<int32_t> compact_of;   // [K]   row of knot k in the compact tables, -1 if unreachable

@@ -15,8 +15,8 @@
 // spend as few wave-instructions per trade as possible:
 //   * a wavefront prices FOUR trades at a time, 16 lanes each, and a trade's coupons arrive as rows of 16 slots
 //     (15 coupons + a spare lane for the leg's start node; trades of 16-45 coupons are 2 or 3 consecutive rows), so
-//     half-empty 32-slot rows are neither loaded nor computed on: 512-byte coalesced loads, ~0.95 KB of row data per
-//     trade on the benchmark portfolio instead of 1.3 KB;
+//     half-empty 32-slot rows are neither loaded nor computed on: ~0.95 KB of row data per trade on the benchmark
+//     portfolio instead of 1.3 KB, fetched as 16-byte-per-lane loads of pair-interleaved arrays;
 //   * lanes = coupons for folding, lookup and exp; then every lane leaves its node as two 16-byte entries
 //     {w * b, byte offset of the knot's LJ row} in the wave's LDS slot and lane l accumulates pillars 2l and 2l + 1:
 //     per entry one broadcast b128 read, one b128 read of the row pair, two FMAs - no per-node decoding, no short-end
@@ -171,16 +171,18 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
     int nx_meta = 0, nx_trade = -1;
     auto request_row = [&](uint32_t at0, int R, int r) {            // group g's row r: R rows per trade, 16 slots per row
         const uint32_t at = at0 + r * L + __umul24(g, R * L) + l;
-        nx_tp = __builtin_nontemporal_load(tr.tp + at); nx_ts = __builtin_nontemporal_load(tr.ts + at);
-        nx_al = __builtin_nontemporal_load(tr.alpha + at);
-        nx_xtp = __builtin_nontemporal_load(tr.xtp + at); nx_xpay = __builtin_nontemporal_load(tr.xpay + at);
+        const nt_pair a = __builtin_nontemporal_load(reinterpret_cast<const nt_pair*>(tr.tp_ts) + at);
+        const nt_pair b = __builtin_nontemporal_load(reinterpret_cast<const nt_pair*>(tr.al_xtp) + at);
+        nx_tp = a.x; nx_ts = a.y; nx_al = b.x; nx_xtp = b.y;
+        nx_xpay = __builtin_nontemporal_load(tr.xpay + at);
     };
     auto request_trade = [&](uint32_t u) {
         // (scalar loads of the unit's four slots + a pick by group were tried: the wave then waits for the scalar
         // data in this phase - slower than four broadcast vector loads)
-        const uint32_t slot = u * G + g;
-        nx_N = tr.notional[slot]; nx_spread = tr.spread[slot];
-        nx_meta = tr.meta[slot]; nx_trade = tr.trade[slot];
+        const LiteTrade* rec = tr.slot + (u * G + g);
+        const nt_pair a = *reinterpret_cast<const nt_pair*>(&rec->notional);
+        const int2 b = *reinterpret_cast<const int2*>(&rec->meta);
+        nx_N = a.x; nx_spread = a.y; nx_meta = b.x; nx_trade = b.y;
     };
 
     uint32_t unit = blockIdx.x * kWavesPerBlock + wave;
