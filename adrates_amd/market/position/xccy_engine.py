@@ -21,8 +21,14 @@ Piece 2 is one trade per swap whose coupons carry a per-coupon notional multipli
 Flows dated exactly at the value time follow the reference's masks: coupons and exchanges count (``>=``), and
 since their discount factor is 1 they are added to the PV on the host (the kernels' fixed-flow mask is ``>``).
 
-The reference's cross-gamma block (:1895-1960) is not reproduced: it contracts a tensor indexed by the foreign
-curve's own nodes with the Jacobian of the engine's knot grid, two different sizes.
+Cross-gamma foreign OIS x basis (`cross_gamma_for_basis`): the mixed second derivative of the PV w.r.t. the foreign
+par rates and the basis spreads with the two curves' knot discount factors as the channels,
+``(sign / spot) sum_j grad_r[N D_f(ts_j) / D_f(te_j)] (x) grad_s[D_x(tp_j)]`` - per coupon an outer product of two
+ladders the kernels already produce (each coupon priced as a trade of its own on the foreign tables and on the XCCY
+tables).  This is NOT the reference's block (:1895-1960), which keeps only the term that comes from the XCCY
+bootstrap's own dependence on the foreign curve and contracts a tensor indexed by the foreign curve's OWN nodes with
+the Jacobian of the engine's knot grid (two different sizes whenever the curve has more than annual points); see
+DESIGN.md section 9.
 """
 from __future__ import annotations
 
@@ -31,7 +37,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from ... import _native
-from ...requests.results import AnalyticsResult, Delta, Gamma, Risk, Valuation
+from ...requests.results import AnalyticsResult, CrossGamma, Delta, Gamma, Risk, Valuation
 from ...trades.compiler import TradeBatch
 from ...utils.error import LibError
 from ...utils.global_types import CurveTypes, InterpTypes, RequestTypes, SwapTypes
@@ -223,6 +229,59 @@ def compile_xccy(raw: RawXccy, spot, df_x, df_f):
     return domestic, foreign_rates, foreign_flows, pv_const
 
 
+def cross_gamma_batches(raw: RawXccy):
+    """Every foreign coupon that accrues and is paid after the value time as a trade of its own, twice: on the foreign
+    OIS tables (notional N, accrual ts -> te, paid at time 0: value N D_f(ts) / D_f(te)) and on the XCCY tables (a unit
+    flow at tp).  Returns ``(rates_batch, flows_batch, owner)``; ``owner[j]`` is the swap of coupon j."""
+    n = raw.n
+    owner = np.repeat(np.arange(n), np.diff(raw.for_off))
+    keep = (raw.for_tpx > 0.0) & (raw.for_al > 0)
+    m = int(keep.sum())
+    own = owner[keep]
+    off, zero_off, none = np.arange(m + 1, dtype=np.int64), np.zeros(m + 1, dtype=np.int64), np.zeros(0)
+    ones, zeros = np.ones(m), np.zeros(m)
+    rates = TradeBatch(zero_off, off, none, none, zeros.copy(), raw.for_ts[keep], raw.for_te[keep], raw.for_al[keep],
+                       raw.for_n[own], zeros.copy(), ones, ones.copy())
+    flows = TradeBatch(off, zero_off, raw.for_tpx[keep], ones.copy(), none, none, none, none, ones.copy(), zeros.copy(),
+                       ones.copy(), ones.copy())
+    return rates, flows, own
+
+
+def cross_gamma_for_basis(ctx, for_dev, x_dev, raw: RawXccy, spot, n_basis, per_trade=True, aggregate=False, chunk=256):
+    """d2 PV / d(foreign par rate) d(basis spread), per bp^2, domestic currency: ``[n, P_for, P_basis]`` per swap and /
+    or the book's sum.  Two delta-only launches over the coupons (lite / general kernels) and a contraction."""
+    rates, flows, own = cross_gamma_batches(raw)
+    out = {}
+    p_for = for_dev.n_pillars
+    if rates.n_trades == 0:
+        if per_trade:
+            out["cross_for_basis"] = np.zeros((raw.n, p_for, n_basis))
+        if aggregate:
+            out["agg_cross_for_basis"] = np.zeros((p_for, n_basis))
+        return out
+    kw = dict(want_value=False, want_delta=True, want_gamma=False)
+    d_r = np.asarray(_price(ctx, for_dev, rates, kw)["delta"])                    # 1e-4 grad_r [N D_f(ts)/D_f(te)]
+    d_s = _trim(_price(ctx, x_dev, flows, kw)["delta"], "delta", n_basis)          # 1e-4 grad_s D_x(tp)
+    scale = (raw.for_sign / spot)[own]
+    d_r = d_r * scale[:, None]
+    if aggregate:
+        out["agg_cross_for_basis"] = d_r.T @ d_s
+    if per_trade:
+        cross = np.zeros((raw.n, p_for, n_basis))
+        first = np.searchsorted(own, np.arange(raw.n + 1))                         # coupons are laid out swap by swap
+        for lo in range(0, raw.n, chunk):
+            hi = min(lo + chunk, raw.n)
+            a, b = first[lo], first[hi]
+            if a == b:
+                continue
+            outer = d_r[a:b, :, None] * d_s[a:b, None, :]
+            starts = first[lo:hi] - a
+            live = np.flatnonzero(np.diff(np.append(starts, b - a)) > 0)           # reduceat needs non-empty segments
+            cross[lo + live] = np.add.reduceat(outer, starts[live], axis=0)
+        out["cross_for_basis"] = cross
+    return out
+
+
 def _xccy_device_curve(ctx, xccy):
     """The XCCY curve's tables as an `adr_curve` (cached on the curve object).  The fast kernel's packed layout
     wants an even pillar count (16-byte gamma stores), so an odd basis ladder gets one all-zero pillar appended
@@ -279,7 +338,8 @@ def _curves_for(engine, dom_index, for_index, dom_ccy, for_ccy):
 
 def book_batches(engine, swaps):
     """Curves and the three trade batches of a book given as `XccyBasisSwap` objects or as `XccyTerms`:
-    ``(dom_model, for_model, xccy, dom_cur, for_cur, x_dev, (domestic, foreign_rates, foreign_flows), pv_const, spot)``.
+    ``(dom_model, for_model, xccy, dom_cur, for_cur, x_dev, (domestic, foreign_rates, foreign_flows), pv_const, spot,
+    raw)``.
     The per-coupon discount factors come from the device (`adr_curve_df` on the uploaded XCCY and foreign tables)."""
     if isinstance(swaps, XccyTerms):
         one = lambda v: v[0] if isinstance(v, (list, tuple, np.ndarray)) else v
@@ -297,19 +357,20 @@ def book_batches(engine, swaps):
     spot = xccy._spot_fx
     domestic, foreign_rates, foreign_flows, pv_const = compile_xccy(
         raw, spot, lambda t: _native.curve_df(ctx, x_dev, t), lambda t: _native.curve_df(ctx, for_cur["dev"], t))
-    return cur + ((domestic, foreign_rates, foreign_flows), pv_const, spot)
+    return cur + ((domestic, foreign_rates, foreign_flows), pv_const, spot, raw)
 
 
-def price_xccy_batch(engine, swaps, reqs, per_trade=True, aggregate=False):
+def price_xccy_batch(engine, swaps, reqs, per_trade=True, aggregate=False, cross_gamma=False):
     """VALUE / DELTA / GAMMA of a book of cross-currency basis swaps on one currency pair: three launches.
     ``swaps``: `XccyBasisSwap` objects, or `XccyTerms` (no per-swap objects: the vectorised compiler).
 
     Returns a dict: ``pv [n]``, ``delta_dom [n, P_d]``, ``delta_for [n, P_f]``, ``delta_basis [n, P_b]`` and the
     three ``gamma_*`` (per request, when ``per_trade``), ``agg_*`` sums over the book (when ``aggregate``);
+    with ``cross_gamma`` and GAMMA also ``cross_for_basis [n, P_f, P_b]`` (`cross_gamma_for_basis`);
     everything in domestic currency, per bp / bp^2."""
     reqs = set(reqs)
     (dom_model, for_model, xccy, dom_cur, for_cur, x_dev,
-     (domestic, foreign_rates, foreign_flows), pv_const, spot) = book_batches(engine, swaps)
+     (domestic, foreign_rates, foreign_flows), pv_const, spot, raw) = book_batches(engine, swaps)
     ctx = dom_cur["ctx"]
     want_value = RequestTypes.VALUE in reqs
     want_gamma = RequestTypes.GAMMA in reqs
@@ -327,6 +388,8 @@ def price_xccy_batch(engine, swaps, reqs, per_trade=True, aggregate=False):
             out[f"{pre}{kind}_dom"] = np.asarray(dom[pre + kind])
             out[f"{pre}{kind}_for"] = np.asarray(rates[pre + kind]) / spot
             out[f"{pre}{kind}_basis"] = _trim(frn[pre + kind], kind, len(xccy.swap_times)) / spot
+    if cross_gamma and want_gamma:
+        out.update(cross_gamma_for_basis(ctx, for_cur["dev"], x_dev, raw, spot, len(xccy.swap_times), per_trade, aggregate))
     out["tenors"] = (to_tenor(list(dom_model.swap_times)), to_tenor(list(for_model.swap_times)),
                      to_tenor(list(xccy.swap_times)))
     return out
@@ -337,7 +400,7 @@ def compute_xccy(engine, derivative, reqs):
         # the reference's block for this request (engine.py:1970-1986) ends in a NameError (`risk_ccy` is never
         # assigned in _compute_xccy), so there is no behaviour to mirror
         raise NotImplementedError("CASHFLOWS is not available for cross-currency swaps")
-    res = price_xccy_batch(engine, [derivative], reqs)
+    res = price_xccy_batch(engine, [derivative], reqs, cross_gamma=True)
     ccy = derivative._domestic_currency
     curves = (derivative._domestic_floating_index, derivative._foreign_floating_index, CurveTypes.USD_GBP_BASIS)
     value = delta = gamma = None
@@ -347,8 +410,12 @@ def compute_xccy(engine, derivative, reqs):
         delta = Risk([Delta(np.array(res[k][0]), t, ccy, c)
                       for k, t, c in zip(("delta_dom", "delta_for", "delta_basis"), res["tenors"], curves)])
     if RequestTypes.GAMMA in reqs:
+        cross = CrossGamma(risk_matrix=np.array(res["cross_for_basis"][0]), tenors_curve1=res["tenors"][1],
+                           tenors_curve2=res["tenors"][2], curve_type_1=derivative._foreign_floating_index,
+                           curve_type_2=CurveTypes.USD_GBP_BASIS, currency=ccy)
         gamma = Risk([Gamma(np.array(res[k][0]), t, ccy, c)
-                      for k, t, c in zip(("gamma_dom", "gamma_for", "gamma_basis"), res["tenors"], curves)])
+                      for k, t, c in zip(("gamma_dom", "gamma_for", "gamma_basis"), res["tenors"], curves)],
+                     cross_gammas=[cross])
     return AnalyticsResult(value=value, risk=delta, gamma=gamma)
 
 

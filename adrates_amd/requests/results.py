@@ -212,6 +212,38 @@ class Gamma(_LadderBase):
         return pd.DataFrame(g, index=self.tenors, columns=self.tenors)
 
 
+@dataclass(frozen=True)
+class CrossGamma:
+    """Cross-curve second-order sensitivity (cavour/requests/results.py:608-836): ``risk_matrix[i, j]`` =
+    d2 PV / d(curve 1 rate i) d(curve 2 rate j), per bp^2."""
+    risk_matrix: Any                    # [N1, N2]
+    tenors_curve1: Any
+    tenors_curve2: Any
+    curve_type_1: Any
+    curve_type_2: Any
+    currency: Any
+
+    def __post_init__(self):
+        arr = np.asarray(self.risk_matrix, dtype=np.float64)
+        object.__setattr__(self, "risk_matrix", arr)
+        if arr.ndim != 2:
+            raise ValueError(f"CrossGamma risk_matrix must be 2D, got {arr.ndim}D")
+        n1, n2 = arr.shape
+        if n1 != len(self.tenors_curve1):
+            raise ValueError(f"Expected {n1} tenors for curve 1, got {len(self.tenors_curve1)}")
+        if n2 != len(self.tenors_curve2):
+            raise ValueError(f"Expected {n2} tenors for curve 2, got {len(self.tenors_curve2)}")
+
+    @property
+    def value(self):
+        return Value(amount=float(np.sum(self.risk_matrix)), currency=self.currency)
+
+    @property
+    def to_dict(self) -> dict:
+        return {t1: {t2: float(self.risk_matrix[i, j]) for j, t2 in enumerate(self.tenors_curve2)}
+                for i, t1 in enumerate(self.tenors_curve1)}
+
+
 class Risk:
     """Several per-curve ladders addressed by curve name or `CurveTypes`."""
 

@@ -121,5 +121,5 @@ def synthesize_book(engine, value_dt, n, seed=20240430, rank=0, world_size=1):
         from ..distributed import shard_by_work
         lo, hi = shard_by_work(work, world_size)[rank]
         terms = slice_terms(terms, lo, hi)
-    dom_model, for_model, xccy, dom_cur, for_cur, x_dev, (dom, rates, flows), pv_const, spot = XE.book_batches(engine, terms)
+    dom_model, for_model, xccy, dom_cur, for_cur, x_dev, (dom, rates, flows), pv_const, spot, _ = XE.book_batches(engine, terms)
     return [(dom, dom_cur["dev"]), (rates, for_cur["dev"]), (flows, x_dev)], spot

@@ -193,7 +193,15 @@ def xccy_analytics(swap, value_dt, dom_cache, dom_method, for_cache, for_method,
     v_dom, d_dom, g_dom = _chain(pv_dom, dom_cache["dfs"], dom_cache["jac"], dom_cache["hess"])
     v_for, d_for, g_for = _chain(lambda f: pv_for(x_fixed, f), for_cache["dfs"], for_cache["jac"], for_cache["hess"])
     _, d_bas, g_bas = _chain(lambda x: pv_for(x, f_fixed), x_dfs, xccy_curve._jac_basis, xccy_curve._hess_basis)
-    return dict(value=v_dom + v_for / spot, delta_dom=d_dom * 1e-4, delta_for=d_for * 1e-4 / spot,
+    # mixed second derivative foreign OIS rates x basis spreads with both curves' knot DFs as the only channels
+    # (the XCCY curve's own dependence on the foreign curve through its bootstrap held fixed - the part
+    # engine.py:1895-1960 computes instead): J_for^T (d2 PV / d d_f d d_x) J_basis, [P_for, P_basis]
+    from torch.func import jacrev as _jacrev
+    mixed = _jacrev(grad(pv_for, argnums=1), argnums=0)(x_fixed, f_fixed)                 # [K_for, K_x]
+    J_f = torch.as_tensor(np.asarray(for_cache["jac"]), dtype=_F64)
+    J_b = torch.as_tensor(np.asarray(xccy_curve._jac_basis), dtype=_F64)
+    cross = (J_f.T @ mixed @ J_b).numpy()
+    return dict(cross_for_basis=cross * 1e-8 / spot, value=v_dom + v_for / spot, delta_dom=d_dom * 1e-4, delta_for=d_for * 1e-4 / spot,
                 delta_basis=d_bas * 1e-4 / spot, gamma_dom=g_dom * 1e-8, gamma_for=g_for * 1e-8 / spot,
                 gamma_basis=g_bas * 1e-8 / spot)
 

@@ -39,8 +39,23 @@ def _swap(tenor, spread, lag=0, effective=VALUE_DT, freq=FrequencyTypes.ANNUAL, 
                          foreign_currency=CurrencyTypes.USD)
 
 
+_FLOOR = {1.0: 1e-4, 1e-4: 1e-8, 1e-6: 1e-12}
+
+
 def _close(got, want, scale):
-    assert np.max(np.abs(np.asarray(got) - np.asarray(want))) <= TOL * max(1.0, scale)
+    """The parity metric of tests/_parity.py (`ladder_err`): max |a - b| relative to the ladder's own largest entry,
+    with a floor per unit notional (1e-4 N for PV, 1e-8 N for delta, 1e-12 N for gamma) below which a ladder counts as
+    rounding noise.  ``scale`` = notional x {1, 1e-4, 1e-6} names the kind (PV, delta, gamma) as before.  The oracle's
+    curve Jacobians / Hessians are the product's own (`build_engine_curve`), which tests/test_curve_tables.py checks
+    against autodiff of the bootstrap separately."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    kind = min(_FLOOR, key=lambda k: abs(np.log(max(scale, 1e-300)) - np.log(k * max(_close.notional, 1.0))))
+    floor = _FLOOR[kind] * _close.notional
+    assert np.max(np.abs(got - want)) <= TOL * max(float(np.max(np.abs(want))), floor), \
+        (float(np.max(np.abs(got - want))), float(np.max(np.abs(want))), floor)
+
+
+_close.notional = 1.0
 
 
 @pytest.mark.parametrize("case", ["par_5y", "off_market_7y_lagged", "semi_annual_10y", "forward_start", "seasoned"])
@@ -60,7 +75,7 @@ def test_basis_swap_value_delta_gamma(case):
     gbp, usd, x = m.curves.GBP_OIS_SONIA, m.curves.USD_OIS_SOFR, m.curves.USD_GBP_BASIS
     want = XO.xccy_analytics(swap, VALUE_DT, _cache(gbp), gbp._interp_type.value, _cache(usd), usd._interp_type.value,
                              x, times_from_dates)
-    scale = abs(swap._domestic_leg._notional)
+    scale = _close.notional = abs(swap._domestic_leg._notional)
     _close(res.value.amount, want["value"], scale)
     curves = (CurveTypes.GBP_OIS_SONIA, CurveTypes.USD_OIS_SOFR, CurveTypes.USD_GBP_BASIS)
     for curve, key in zip(curves, ("delta_dom", "delta_for", "delta_basis")):
@@ -68,6 +83,11 @@ def test_basis_swap_value_delta_gamma(case):
         assert np.any(res.risk(curve).risk_ladder != 0.0)
     for curve, key in zip(curves, ("gamma_dom", "gamma_for", "gamma_basis")):
         _close(res.gamma(curve).risk_ladder, want[key], scale * 1e-6)
+    # cross-gamma foreign OIS x basis: the mixed term through the two curves' knot DFs (xccy_engine.cross_gamma_for_basis)
+    cross = res.gamma.cross_gamma(CurveTypes.USD_OIS_SOFR, CurveTypes.USD_GBP_BASIS)
+    assert cross.risk_matrix.shape == (32, len(x.swap_times)) and np.any(cross.risk_matrix != 0.0)
+    _close(cross.risk_matrix, want["cross_for_basis"], scale * 1e-6)
+    assert cross.curve_type_1 == CurveTypes.USD_OIS_SOFR and cross.currency == CurrencyTypes.GBP
 
 
 def test_value_only_and_missing_curve():
@@ -95,7 +115,7 @@ def test_other_interpolation_schemes_on_all_three_curves(interp):
     gbp, usd, x = m.curves.GBP_OIS_SONIA, m.curves.USD_OIS_SOFR, m.curves.USD_GBP_BASIS
     want = XO.xccy_analytics(swap, VALUE_DT, _cache(gbp), gbp._interp_type.value, _cache(usd), usd._interp_type.value,
                              x, times_from_dates)
-    scale = abs(swap._domestic_leg._notional)
+    scale = _close.notional = abs(swap._domestic_leg._notional)
     _close(res.value.amount, want["value"], scale)
     for curve, d, g in ((CurveTypes.GBP_OIS_SONIA, "delta_dom", "gamma_dom"), (CurveTypes.USD_OIS_SOFR, "delta_for", "gamma_for"),
                         (CurveTypes.USD_GBP_BASIS, "delta_basis", "gamma_basis")):
@@ -117,16 +137,18 @@ def test_book_in_three_launches_per_trade_and_aggregate():
     wants = [XO.xccy_analytics(s, VALUE_DT, _cache(gbp), gbp._interp_type.value, _cache(usd), usd._interp_type.value,
                                x, times_from_dates) for s in book]
     for i, (s, w) in enumerate(zip(book, wants)):
-        scale = abs(s._domestic_leg._notional)
+        scale = _close.notional = abs(s._domestic_leg._notional)
         _close(out["pv"][i], w["value"], scale)
         for k in ("delta_dom", "delta_for", "delta_basis"):
             _close(out[k][i], w[k], scale * 1e-4)
         for k in ("gamma_dom", "gamma_for", "gamma_basis"):
             _close(out[k][i], w[k], scale * 1e-6)
-    total = sum(abs(s._domestic_leg._notional) for s in book)
+    total = _close.notional = sum(abs(s._domestic_leg._notional) for s in book)
     _close(out["agg_pv"], sum(w["value"] for w in wants), total)
-    for k in ("delta_dom", "delta_for", "delta_basis", "gamma_dom", "gamma_for", "gamma_basis"):
+    for k in ("delta_dom", "delta_for", "delta_basis"):
         _close(out["agg_" + k], sum(w[k] for w in wants), total * 1e-4)
+    for k in ("gamma_dom", "gamma_for", "gamma_basis"):
+        _close(out["agg_" + k], sum(w[k] for w in wants), total * 1e-6)
     # delta-only request of BASELINE.json's config 3: same ladders, no gamma keys
     d = price_xccy_batch(Engine(m), book, {RequestTypes.DELTA}, per_trade=True)
     assert "gamma_dom" not in d and "pv" not in d

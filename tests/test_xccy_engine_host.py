@@ -356,3 +356,43 @@ def test_two_curves_with_identical_pillar_times_do_not_collide(host_engine):
     engine = Engine(m)
     a, b = engine._device_curve(gbp), engine._device_curve(usd)
     assert a is not b and not np.array_equal(a["host"].dfs, b["host"].dfs)
+
+
+def test_cross_gamma_is_the_bump_of_the_basis_delta(host_engine):
+    """`Risk.cross_gamma(foreign OIS, basis)`: d2 PV / d r_for d s_basis with the XCCY curve's knot DFs and basis
+    Jacobian held as they are - so it must equal the central difference of the basis delta ladder when one foreign
+    quote is bumped and the SAME XCCY curve object is kept (the curve is not re-bootstrapped: that coupling is the
+    other, reference-only, term - DESIGN.md section 9).  Also against the autodiff restatement, and the book form."""
+    from adrates_amd.market.position.engine import Engine
+    from adrates_amd.models.models import Model
+    from adrates_amd.utils import BusDayAdjustTypes, DayCountTypes, InterpTypes, SwapTypes
+    from tests.test_gpu_xccy import TENORS, USD
+    m = host_engine
+    swap = _swap("7Y", 0.0045, lag=2, notional=25_000_000, freq=FrequencyTypes.SEMI_ANNUAL)
+    reqs = {RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA}
+    res = swap.position(m).compute(list(reqs))
+    cross = res.gamma.cross_gamma(CurveTypes.USD_OIS_SOFR, CurveTypes.USD_GBP_BASIS)
+    want = _oracle(m, swap)["cross_for_basis"]
+    scale = max(np.max(np.abs(want)), 1e-12 * 25e6)
+    assert np.max(np.abs(cross.risk_matrix - want)) <= 1e-10 * scale
+    assert abs(cross.value.amount - want.sum()) <= 1e-9 * np.abs(want).sum()
+    assert res.gamma.has_cross_gamma(CurveTypes.USD_OIS_SOFR, CurveTypes.USD_GBP_BASIS)
+    assert res.gamma.cross_gamma(CurveTypes.GBP_OIS_SONIA, CurveTypes.USD_GBP_BASIS) is None
+
+    def basis_delta(shift_bp, tenor):
+        usd = m.scenario("USD_OIS_SOFR", {tenor: shift_bp * 0.01}).curves.USD_OIS_SOFR
+        bumped = Model(VALUE_DT)
+        bumped._curves_dict.update(GBP_OIS_SONIA=m.curves.GBP_OIS_SONIA, USD_OIS_SOFR=usd, USD_GBP_BASIS=m.curves.USD_GBP_BASIS)
+        return swap.position(bumped).compute([RequestTypes.DELTA]).risk(CurveTypes.USD_GBP_BASIS).risk_ladder
+    for tenor in ("2Y", "5Y", "7Y"):
+        l = TENORS.index(tenor)
+        fd = (basis_delta(+1.0, tenor) - basis_delta(-1.0, tenor)) / 2.0           # per bp of the foreign quote
+        assert np.max(np.abs(cross.risk_matrix[l] - fd)) <= 1e-6 * np.max(np.abs(cross.risk_matrix)), tenor
+    # a book: per swap and aggregated
+    book = _book()
+    out = xccy_engine.price_xccy_batch(Engine(m), book, reqs, per_trade=True, aggregate=True, cross_gamma=True)
+    wants = [_oracle(m, s)["cross_for_basis"] for s in book]
+    for i, w in enumerate(wants):
+        assert np.max(np.abs(out["cross_for_basis"][i] - w)) <= 1e-10 * max(np.max(np.abs(w)), 1e-12 * abs(book[i]._domestic_leg._notional))
+    tot = sum(wants)
+    assert np.max(np.abs(out["agg_cross_for_basis"] - tot)) <= 1e-10 * np.max(np.abs(tot))
