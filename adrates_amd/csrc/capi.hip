@@ -248,7 +248,7 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     int16_t *d_first = nullptr, *d_comp = nullptr, *d_class = nullptr, *d_p2c = nullptr, *d_omap = nullptr;
     int16_t* d_smap = nullptr;
     uint8_t* d_pq = nullptr;
-    int16_t* d_cpos = nullptr;
+    int16_t *d_cpos = nullptr, *d_lpos = nullptr;
     adr::MiniKnot* d_mini = nullptr;
     hipError_t e = hipSuccess;
     auto track = [&](hipError_t r, void* p) { if (p) c->allocations.push_back(p); if (e == hipSuccess) e = r; };
@@ -275,6 +275,7 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
         track(upload(t.store_map, &d_smap), d_smap);
         track(upload(t.ent_pq, &d_pq), d_pq);
         track(upload(t.core_pos, &d_cpos), d_cpos);
+        track(upload(t.lcc_pos, &d_lpos), d_lpos);
         track(upload(t.mini, &d_mini), d_mini);
     }
     if (e != hipSuccess) { adr_free_curve(c); return fail_hip(e, "adr_curve_upload: copying tables"); }
@@ -286,9 +287,9 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     // Hessian term (kernels_general.hip, `Lookup`)
     c->dev.packed_ok = (t.packed_ok && t.P % 2 == 0 && interp_method != ADR_INTERP_LINEAR_FWD_RATES) ? 1 : 0;
     c->dev.Pc = t.Pc; c->dev.pc_pad = t.pc_pad; c->dev.Ec = t.Ec; c->dev.Eu = t.Eu; c->dev.epg = t.epg; c->dev.cpg = t.cpg; c->dev.hub = t.hub ? 1 : 0;
-    c->dev.Kcore = t.Kcore; c->dev.n_mini = t.n_mini;
+    c->dev.Kcore = t.Kcore; c->dev.n_mini = t.n_mini; c->dev.fringe_start = t.fringe_start;
     c->dev.ljc = d_ljc; c->dev.lcc = d_lcc; c->dev.mini = d_mini; c->dev.knot_class = d_class;
-    c->dev.pillar_to_core = d_p2c; c->dev.out_map = d_omap; c->dev.store_map = d_smap; c->dev.ent_pq = d_pq; c->dev.core_pos = d_cpos;
+    c->dev.pillar_to_core = d_p2c; c->dev.out_map = d_omap; c->dev.store_map = d_smap; c->dev.ent_pq = d_pq; c->dev.core_pos = d_cpos; c->dev.lcc_pos = d_lpos;
     // the packed tables must fit the LDS of a CU next to the search arrays, else the general kernel serves all
     size_t fast_lds = 0;
     if (c->dev.packed_ok) {
@@ -382,7 +383,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     int16_t *d_first = nullptr, *d_comp = nullptr, *d_class = nullptr, *d_p2c = nullptr, *d_omap = nullptr;
     int16_t* d_smap = nullptr;
     uint8_t *d_pq = nullptr, *d_lccpq = nullptr;
-    int16_t* d_cpos = nullptr;
+    int16_t *d_cpos = nullptr, *d_lpos = nullptr;
     auto track = [&](hipError_t r, void* p) { if (p) plan->allocations.push_back(p); if (e == hipSuccess) e = r; };
     track(upload(acc_v, &d_acc), d_acc);
     track(upload(pil_v, &d_pil), d_pil);
@@ -408,6 +409,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
         track(upload(t.ent_pq, &d_pq), d_pq);
         track(upload(t.lcc_pq, &d_lccpq), d_lccpq);
         track(upload(t.core_pos, &d_cpos), d_cpos);
+        track(upload(t.lcc_pos, &d_lpos), d_lpos);
     }
     if (e != hipSuccess) { adr_free_curve_plan(plan); return fail_hip(e, "adr_curve_plan_create: copying tables"); }
 
@@ -422,8 +424,8 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     c.x = d_x; c.inv_x = d_invx; c.first_of = d_first; c.compact_of = d_comp; c.lc_block_mask = d_lcmask;
     c.lut = d_lut; c.n_lut = static_cast<int>(t.lut.size() / 2);
     c.packed_ok = d.packed_ok;
-    c.Pc = t.Pc; c.pc_pad = t.pc_pad; c.Ec = t.Ec; c.Eu = t.Eu; c.epg = t.epg; c.cpg = t.cpg; c.hub = t.hub ? 1 : 0; c.Kcore = t.Kcore; c.n_mini = t.n_mini;
-    c.knot_class = d_class; c.pillar_to_core = d_p2c; c.out_map = d_omap; c.store_map = d_smap; c.ent_pq = d_pq; c.core_pos = d_cpos;
+    c.Pc = t.Pc; c.pc_pad = t.pc_pad; c.Ec = t.Ec; c.Eu = t.Eu; c.epg = t.epg; c.cpg = t.cpg; c.hub = t.hub ? 1 : 0; c.Kcore = t.Kcore; c.n_mini = t.n_mini; c.fringe_start = t.fringe_start;
+    c.knot_class = d_class; c.pillar_to_core = d_p2c; c.out_map = d_omap; c.store_map = d_smap; c.ent_pq = d_pq; c.core_pos = d_cpos; c.lcc_pos = d_lpos;
     size_t fast_lds = 0;
     if (c.packed_ok) {
         fast_lds = adr::fast_kernel_lds_bytes(c, plan->has_hess);
@@ -877,8 +879,9 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     }
     if (chained.n_rows > 0) blocks_chained = trades->chained_blocks;   // the chains are laid out for this grid
     if (general.n_list > 0) {
-        const int64_t need = (general.n_list + adr::kGeneralThreads / 64 - 1) / (adr::kGeneralThreads / 64);
-        blocks_general = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * 4));
+        const int threads = adr::general_kernel_threads(curve->dev, want_gamma);     // 512: LDS-resident convexity rows
+        const int64_t need = (general.n_list + threads / 64 - 1) / (threads / 64);
+        blocks_general = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * (threads == adr::kGeneralThreads ? 4 : 2)));
     }
     if (blocks_lite + blocks_fast + blocks_chained + blocks_general > ctx->max_blocks)
         return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");

@@ -299,7 +299,7 @@ bool build_packed_layout(CurveTables& t) {
             if (core_slots_min * kGroupLanes + n_fringe <= epg * kGroupLanes) { t.epg = t.cpg = epg; break; }
         if (t.epg == 0) return false;
     }
-    const int fringe_start = (t.cpg < t.epg ? t.cpg : core_slots_min) * kGroupLanes;
+    const int fringe_start = t.fringe_start = (t.cpg < t.epg ? t.cpg : core_slots_min) * kGroupLanes;
     if (hub_ok) {
         // ent_pq / core_pos / lcc_pq now describe the star decomposition; redo entry_of for the core pairs
         for (int e = 0; e < t.cpg * kGroupLanes; ++e) {
@@ -355,6 +355,16 @@ bool build_packed_layout(CurveTables& t) {
         t.mini.push_back(m);
     }
     t.n_mini = static_cast<int>(t.mini.size());
+
+    t.lcc_pos.assign(kPillarPad * kPillarPad, static_cast<int16_t>(-1));
+    for (int pos = 0; pos < Ec; ++pos) {
+        const int a = t.lcc_pq[2 * pos], b = t.lcc_pq[2 * pos + 1];
+        t.lcc_pos[a * kPillarPad + b] = t.lcc_pos[b * kPillarPad + a] = static_cast<int16_t>(pos);
+    }
+    for (int e = fringe_start; e < t.Eu; ++e) {
+        const int a = t.ent_pq[2 * e], b = t.ent_pq[2 * e + 1];
+        t.lcc_pos[a * kPillarPad + b] = t.lcc_pos[b * kPillarPad + a] = static_cast<int16_t>(Ec + 1 + (e - fringe_start));
+    }
 
     // one extra all-zero row (index Kcore) stands in for knots nothing depends on, so the kernel's hot loop
     // needs no branch for them

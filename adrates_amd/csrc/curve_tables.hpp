@@ -66,6 +66,7 @@ struct CurveTables {
     int Eu = 0;                        // all packed entries: core pairs, padding to a multiple of 32, fringe pairs
     int epg = 0;                       // packed entries per group lane the kernel is instantiated for (Eu <= 32*epg)
     int cpg = 0;                       // of which slots that read convexity rows: epg - 2 (exact) or epg (universal)
+    int fringe_start = 0;              // first packed entry of the fringe pairs
     int Kcore = 0;                     // rows of ljc / lcc
     int n_mini = 0;                    // knots with at most two pillars outside the core
     std::vector<int16_t> pillar_to_core;   // [32]   core column of pillar p; Pc (the zero column) outside the core
@@ -77,6 +78,8 @@ struct CurveTables {
     std::vector<int16_t> core_pos;         // [32*cpg]         hub layout: position of core entry e in a lcc row
     std::vector<char> core_real;           // [32*cpg]         hub layout: entry e is a real pair (not padding)
     std::vector<uint8_t> lcc_pq;           // [Ec][2]          pillars of the pair stored at position pos of a lcc row
+    std::vector<int16_t> lcc_pos;          // [32*32]          flat index of pair (r, c), either order: position in a lcc row (core),
+                                           //                  Ec + 1 + (entry - fringe_start) (fringe), -1 for pairs no node creates
     std::vector<int16_t> out_map;          // [32*32]          packed entry feeding gamma[r][c] (32-wide rows), -1 if none
     std::vector<int16_t> store_map;        // [32*32]          the same by flat index r*P + c; -2 beyond P*P
     std::vector<MiniKnot> mini;            // [n_mini]

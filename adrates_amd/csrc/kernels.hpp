@@ -16,6 +16,7 @@ namespace adr {
 
 constexpr int kAggStride = 1 + kPillarPad + kPillarPad * kPillarPad; // padded [pv, delta, gamma] record
 constexpr int kGeneralThreads = 256;                                 // general kernel: 4 wavefronts per block
+constexpr int kGeneralLdsThreads = 512;                              // ... 8 with LDS-resident convexity rows (1 block per CU)
 constexpr int kFastThreads = ADR_FAST_THREADS;
 constexpr int kRowSlots = 32;                                        // cash-flow slots per row of the fast table
 // lite kernel (kernels_lite.hip): 4 trades per wavefront, rows of 16 slots = 15 coupons + a spare lane
@@ -111,6 +112,7 @@ struct CurveDev {
     const unsigned long long* lc_block_mask;  // [Kc] lanes whose 4x4 block of LC_k is not structurally zero
     // fast kernels: packed layout (curve_tables.hpp), valid when packed_ok
     int packed_ok, Pc, pc_pad, Ec, Eu, epg, cpg, hub, Kcore, n_mini;
+    int fringe_start;            // first packed entry of the fringe pairs (entries fringe_start .. Eu - 1)
     const double* ljc;           // [Kcore][pc_pad]
     const double* lcc;           // [Kcore][Ec + 1] (last entry of every row is 0), null without gamma
     const MiniKnot* mini;        // [n_mini]
@@ -120,6 +122,8 @@ struct CurveDev {
     const int16_t* store_map;    // [32*32] packed entry by flat index r*P + c of the caller's matrix; -2 beyond P*P
     const uint8_t* ent_pq;       // [Eu][2]
     const int16_t* core_pos;     // [32*cpg] hub layout only: row position of core entry e
+    const int16_t* lcc_pos;      // [32*32] flat index of pair (r, c) for the general kernel's LDS rows: its position in a
+                                 //         lcc row (core pairs), Ec + 1 + (entry - fringe_start) (fringe pairs), -1 otherwise
 };
 
 struct OutputsDev {
@@ -160,6 +164,7 @@ hipError_t launch_curve_build(const CurveBuildPlanDev& plan, int n_scen, const d
                               hipStream_t stream);
 
 size_t general_kernel_lds_bytes(int K, int Kc);
+int general_kernel_threads(const CurveDev& cv, bool gamma);          // block size of the variant launch_price_general picks
 size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma);
 int fast_kernel_groups();
 hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes);

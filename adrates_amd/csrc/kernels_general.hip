@@ -35,8 +35,10 @@ namespace adr {
 
 namespace {
 
-constexpr int kBlockThreads = kGeneralThreads;
-constexpr int kWavesPerBlock = kBlockThreads / 64;
+constexpr int kThreadsL2 = kGeneralThreads;      // convexity tiles streamed from L2: 2 blocks of 4 waves per CU
+constexpr int kThreadsLds = kGeneralLdsThreads;  // convexity rows resident in LDS: 1 block of 8 waves per CU
+constexpr int kConvSlices = 3;                   // 64-entry slices of a packed convexity row (at most 192 core pairs)
+constexpr int kConvStage = 64 * kConvSlices;     // doubles per wave for handing the flat convexity sums to the blocks
 
 __device__ __forceinline__ int readlane_i(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
 
@@ -149,32 +151,56 @@ struct Ladders {
     double pv;                 // lane-partial, reduced at the end of the trade
     double delta;              // lane p (and p + 32, duplicated) holds pillar p
     double gamma[GAMMA ? kGammaPerLane : 1];
+    double conv[GAMMA ? kConvSlices : 1];   // LDS path: sum_k coef_k * LC_k on the packed core pairs, entry lane + 64 s
     __device__ void clear() {
         pv = 0.0; delta = 0.0;
 #pragma unroll
         for (int e = 0; e < (GAMMA ? kGammaPerLane : 1); ++e) gamma[e] = 0.0;
+#pragma unroll
+        for (int e = 0; e < (GAMMA ? kConvSlices : 1); ++e) conv[e] = 0.0;
     }
+};
+
+// Where the curve-convexity term sum_i coef_i LC[k_i] comes from.  L2 path: dense 8 KB tiles per knot (any curve).
+// LDS path (curves with the packed tables of curve_tables.cpp): the packed core-pair rows the fast kernel uses,
+// resident in LDS; the term is linear in LC and independent of the rank-one part, so it is accumulated in the rows'
+// own flat layout - lane l adds row[l], row[l + 64], row[l + 128], three conflict-free reads per knot instead of a
+// 16-entry gather per lane - and scattered to the 4x4 blocks once per trade.  Short-end knots (at most two pillars)
+// carry their one to three numbers in 64-byte records; they go to flat entries behind the core pairs (the fringe
+// pairs of the packed layout), which the same scatter serves.
+struct ConvLds {
+    const double* lcc;          // [Kcore + 1][ec_stride]
+    const MiniKnot* mini;       // [n_mini]
+    int ec_stride;              // Ec + 1
+    const int16_t* flat_of;     // [32*32] flat index of pair (r, c) (CurveDev::lcc_pos; read for short-end knots only)
 };
 
 // Add the nodes held by the lanes in `mask` to the trade's ladders.  A node is NK (knot, weight) pairs
 // and a coefficient*exp() value `omega`; NK is 2 for plain nodes and 6 for ratio nodes.
 // CF: the convexity coefficients of the entries come from `cf` (final values: the caller has summed the weights
 // of the nodes that share a knot) instead of omega * b; without CF the argument is ignored.
-template <int NK, bool DELTA, bool GAMMA, bool CF = false>
+// LDSLC: the knot words carry the knot's class (curve_tables.hpp, knot_class) in their high half, `conv` is used.
+template <int NK, bool DELTA, bool GAMMA, bool CF = false, bool LDSLC = false>
 __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k)[NK], const double (&b)[NK],
                                           double omega, const CurveLds& c, const double* __restrict__ lc_lanes,
                                           const unsigned long long* lc_block_mask,
-                                          double* vbuf, int lane, Ladders<GAMMA>& acc, const double (&cf)[NK]) {
+                                          double* vbuf, int lane, Ladders<GAMMA>& acc, const double (&cf)[NK],
+                                          const ConvLds& conv = ConvLds{}) {
     const int p = lane & 31;
     const int bi = lane >> 3, bj = lane & 7;
     while (mask) {
         const int n = __builtin_ctzll(mask);
         mask &= mask - 1;
         const double om = readlane_d(omega, n);
-        int kk[NK];
+        int kk[NK], cls[NK];
         double bb[NK];
 #pragma unroll
-        for (int i = 0; i < NK; ++i) { kk[i] = readlane_i(k[i], n); bb[i] = readlane_d(b[i], n); }
+        for (int i = 0; i < NK; ++i) {
+            const int word = readlane_i(k[i], n);
+            kk[i] = LDSLC ? (word & 0xffff) : word;
+            cls[i] = LDSLC ? (word >> 16) : 0;
+            bb[i] = readlane_d(b[i], n);
+        }
         double cc[NK];
 #pragma unroll
         for (int i = 0; i < NK; ++i) cc[i] = (CF && GAMMA) ? readlane_d(cf[i], n) : om * bb[i];
@@ -191,6 +217,32 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
+            if constexpr (LDSLC) {
+                // curve-convexity part, flat: every lane, three consecutive-address reads per knot
+#pragma unroll
+                for (int i = 0; i < NK; ++i) {
+                    const double coef = cc[i];
+                    if (coef == 0.0 || cls[i] == -2) continue;                 // wave-uniform
+                    if (cls[i] >= 0) {
+                        const double* row = conv.lcc + cls[i] * conv.ec_stride + lane;
+#pragma unroll
+                        for (int sl = 0; sl < kConvSlices; ++sl)
+                            if (lane + 64 * sl < conv.ec_stride) acc.conv[sl] = fma(coef, row[64 * sl], acc.conv[sl]);
+                    } else {                                // short-end knot: one to three numbers, on the fringe pairs
+                        const MiniKnot& m = conv.mini[-3 - cls[i]];   // that follow the core pairs in the flat layout
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const int pr = m.p[j == 2 ? 1 : 0], pc = m.p[j == 0 ? 0 : 1];     // (p0,p0), (p0,p1), (p1,p1)
+                            if (pr < 0 || pc < 0) continue;                     // single-pillar knot: one entry
+                            const int at = conv.flat_of[pr * kPillarPad + pc];  // a fringe pair, or a core pair (p1 may be core)
+                            if (at < 0) continue;
+                            const double add = (lane == (at & 63)) ? coef * m.lc[j] : 0.0;
+#pragma unroll
+                            for (int sl = 0; sl < kConvSlices; ++sl) acc.conv[sl] += (sl == (at >> 6)) ? add : 0.0;
+                        }
+                    }
+                }
+            }
             // gamma is symmetric: only the lanes holding a block on or above the diagonal accumulate (and read
             // LC tiles); the mirror blocks are written from their registers at output time
             if (bi > bj) continue;
@@ -202,6 +254,7 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) acc.gamma[i * 4 + jx] = fma(vr[i], vc[jx], acc.gamma[i * 4 + jx]);
             // curve-convexity part: sum_i om*b_i * LC[k_i]
+            if constexpr (!LDSLC)
 #pragma unroll
             for (int i = 0; i < NK; ++i) {
                 const double coef = cc[i];
@@ -226,25 +279,29 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
 // weight * (LJ[ka] - LJ[kb]) (LJ[ka] - LJ[kb])^T with weight = (term value) * (+1 numerator / -1 denominator) * kappa
 // (see `Lookup`).  It has no first-order and no convexity part, so it runs as a node without DELTA and with zero
 // convexity coefficients.
-template <bool GAMMA>
+template <bool GAMMA, bool LDSLC = false>
 __device__ __forceinline__ void add_df_correction(bool on, int ka, int kb, double weight, const CurveLds& c,
                                                   const double* __restrict__ lc_lanes,
                                                   const unsigned long long* lc_block_mask, double* vbuf, int lane,
                                                   Ladders<GAMMA>& acc) {
     if constexpr (GAMMA) {
-        const int k2[2] = {ka, kb};
+        const int k2[2] = {ka, kb};     // untagged is fine: the convexity coefficients are zero
         const double b2[2] = {1.0, -1.0}, none[2] = {0.0, 0.0};
         const double om = on ? weight : 0.0;
-        add_nodes<2, false, true, true>(__ballot(om != 0.0), k2, b2, om, c, lc_lanes, lc_block_mask, vbuf, lane, acc, none);
+        add_nodes<2, false, true, true, LDSLC>(__ballot(om != 0.0), k2, b2, om, c, lc_lanes, lc_block_mask, vbuf, lane, acc, none);
     }
 }
 
 // LINDF: the curve interpolates with LINEAR_FWD_RATES (a compile-time switch: the state of the corrections would
 // otherwise cost the log-linear instantiations registers - measured +9 % on the gamma paths)
-template <bool DELTA, bool GAMMA, bool LINDF>
-// Two blocks per CU fit in LDS (the curve tables are about 75 KB), i.e. two waves per SIMD: the register budget is
-// pinned to that (without the bound the gamma instantiation drifts to 256 VGPRs + AGPRs and one wave per SIMD).
-__global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
+// LDSLC: the convexity rows are LDS-resident (`ConvLds`): one 512-thread block per CU instead of two of 256.
+template <bool DELTA, bool GAMMA, bool LINDF, bool LDSLC>
+// Two waves per SIMD either way (two blocks of 4 waves, the curve tables being about 75 KB, or one block of 8 waves next
+// to 112 KB of convexity rows): the register budget is pinned to that (without the bound the gamma instantiation
+// drifts to 256 VGPRs + AGPRs and one wave per SIMD).
+__global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_general_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
+    constexpr int kBlockThreads = LDSLC ? kThreadsLds : kThreadsL2;
+    constexpr int kWavesPerBlock = kBlockThreads / 64;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS carve-up: doubles first (16-byte aligned base), then the int16 index tables
     double* s_x = reinterpret_cast<double*>(smem_raw);
@@ -255,9 +312,16 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
     // per-knot masks of the structurally non-zero LC blocks: read before every tile, so LDS-resident (a global
     // read here would put a second L2 round trip in front of each tile)
     unsigned long long* s_lcmask = reinterpret_cast<unsigned long long*>(s_vbuf + kWavesPerBlock * kPillarPad);
-    int16_t* s_first = reinterpret_cast<int16_t*>(s_lcmask + (GAMMA ? cv.Kc : 0));
+    // LDS path: packed convexity rows, the short-end records and the per-wave staging of the flat sums
+    const int ec_stride = cv.Ec + 1;
+    const int n_lcc = (LDSLC && GAMMA) ? (cv.Kcore + 1) * ec_stride : 0;
+    double* s_lcc = reinterpret_cast<double*>(s_lcmask + ((GAMMA && !LDSLC) ? cv.Kc : 0));
+    double* s_stage = s_lcc + n_lcc;
+    MiniKnot* s_mini = reinterpret_cast<MiniKnot*>(s_stage + ((LDSLC && GAMMA) ? kWavesPerBlock * kConvStage : 0));
+    int16_t* s_first = reinterpret_cast<int16_t*>(s_mini + ((LDSLC && GAMMA) ? cv.n_mini : 0));
     int16_t* s_comp = s_first + cv.K;
-    int16_t* s_lut = s_comp + cv.K;                      // [kLutMax][2] reserved
+    int16_t* s_class = s_comp + cv.K;
+    int16_t* s_lut = s_class + (LDSLC ? cv.Kc : 0);      // [kLutMax][2] reserved
 
     for (int i = threadIdx.x; i < cv.K; i += kBlockThreads) {
         s_x[i] = cv.x[i];
@@ -267,7 +331,14 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
     for (int i = threadIdx.x; i < cv.Kc; i += kBlockThreads) {
         s_log[i] = cv.log_df[i];
         s_invx[i] = cv.inv_x[i];
-        if (GAMMA) s_lcmask[i] = cv.lc_block_mask[i];
+        if (GAMMA && !LDSLC) s_lcmask[i] = cv.lc_block_mask[i];
+        if (LDSLC) s_class[i] = cv.knot_class[i];
+    }
+    for (int i = threadIdx.x; i < n_lcc; i += kBlockThreads) s_lcc[i] = cv.lcc[i];
+    if (LDSLC && GAMMA) {
+        const double* src = reinterpret_cast<const double*>(cv.mini);
+        double* dst = reinterpret_cast<double*>(s_mini);
+        for (int i = threadIdx.x; i < cv.n_mini * 8; i += kBlockThreads) dst[i] = src[i];
     }
     for (int i = threadIdx.x; i < 2 * cv.n_lut; i += kBlockThreads) s_lut[i] = cv.lut[i];
     for (int i = threadIdx.x; i < cv.Kc * kPillarPad; i += kBlockThreads) s_lj[i] = cv.lj[i];
@@ -285,6 +356,23 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
     const int P = cv.P;
     const double* __restrict__ lc_lanes = cv.lc_lanes;
     const unsigned long long* lc_block_mask = s_lcmask;
+    ConvLds conv;
+    conv.lcc = s_lcc; conv.mini = s_mini; conv.ec_stride = ec_stride; conv.flat_of = cv.lcc_pos;
+    double* stage = s_stage + wave * kConvStage;
+    // LDS path: the knot words handed to add_nodes carry the knot's class in their high half
+    auto tag = [&](int k) { return LDSLC ? (k | (static_cast<int>(s_class[k]) << 16)) : k; };
+    // ... and the flat convexity sums are scattered to this lane's 4x4 block once per trade: position of each of
+    // the block's 16 entries in a packed row (the row's trailing zero for pairs outside the core), two per register
+    int conv_pos[(LDSLC && GAMMA) ? kGammaPerLane / 2 : 1];
+    if constexpr (LDSLC && GAMMA) {
+        const int bi0 = lane >> 3, bj0 = lane & 7;
+#pragma unroll
+        for (int e = 0; e < kGammaPerLane; e += 2) {
+            const int r = 4 * bi0 + (e >> 2), q = 4 * bj0 + (e & 3);
+            const int p0 = cv.lcc_pos[r * kPillarPad + q], p1 = cv.lcc_pos[r * kPillarPad + q + 1];
+            conv_pos[e / 2] = (p0 < 0 ? cv.Ec : p0) | ((p1 < 0 ? cv.Ec : p1) << 16);
+        }
+    }
 
     Ladders<GAMMA> total;   // this wave's share of the portfolio aggregate
     total.clear();
@@ -361,8 +449,11 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
                     omega = sl * Nw * exp(linear_df ? q.ln_d : fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
                     acc.pv += omega;
                 }
-                add_nodes<2, DELTA, GAMMA>(__ballot(own_start), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b);
-                if constexpr (linear_df) add_df_correction<GAMMA>(own_start, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+                { int kt_[2];
+#pragma unroll
+                  for (int i_ = 0; i_ < 2; ++i_) kt_[i_] = tag(k[i_]);
+                  add_nodes<2, DELTA, GAMMA, false, LDSLC>(__ballot(own_start), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b, conv); }
+                if constexpr (linear_df) add_df_correction<GAMMA, LDSLC>(own_start, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
             }
             const bool own_ratio = valid && ratio;
             if (__ballot(own_ratio)) {   // payment lag: N D(ts) D(tp) / D(te) keeps all three lookups
@@ -436,22 +527,31 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
                 // paid on the value-time knot alone (the cross-currency assembly): the payment entries carry no
                 // sensitivity, the node is its four accrual entries
                 const bool pay_flat = k[4] == knot0 && b[5] == 0.0;
-                add_nodes<6, DELTA, GAMMA, true>(__ballot(own_ratio && !pay_flat), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf);
+                { int kt_[6];
+#pragma unroll
+                  for (int i_ = 0; i_ < 6; ++i_) kt_[i_] = tag(k[i_]);
+                  add_nodes<6, DELTA, GAMMA, true, LDSLC>(__ballot(own_ratio && !pay_flat), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf, conv); }
                 const unsigned long long flat_mask = __ballot(own_ratio && pay_flat);
                 if (flat_mask) {
                     int k4[4]; double b4[4], cf4[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { k4[i] = k[i]; b4[i] = b[i]; cf4[i] = cf[i]; }
-                    add_nodes<4, DELTA, GAMMA, true>(flat_mask, k4, b4, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf4);
+                    { int kt_[4];
+#pragma unroll
+                      for (int i_ = 0; i_ < 4; ++i_) kt_[i_] = tag(k4[i_]);
+                      add_nodes<4, DELTA, GAMMA, true, LDSLC>(flat_mask, kt_, b4, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf4, conv); }
                 }
                 if constexpr (linear_df) {
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
-                        add_df_correction<GAMMA>(own_ratio, kc[2 * q], kc[2 * q + 1], omega * kap[q], c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+                        add_df_correction<GAMMA, LDSLC>(own_ratio, kc[2 * q], kc[2 * q + 1], omega * kap[q], c, lc_lanes, lc_block_mask, vbuf, lane, acc);
                 }
             }
-            add_nodes<2, DELTA, GAMMA, true>(__ballot(pay_node), kp, bp, omega_p, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cfp);
-            if constexpr (linear_df) add_df_correction<GAMMA>(pay_node, kp[0], kp[1], omega_p * qpay.kappa, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+            { int kt_[2];
+#pragma unroll
+              for (int i_ = 0; i_ < 2; ++i_) kt_[i_] = tag(kp[i_]);
+              add_nodes<2, DELTA, GAMMA, true, LDSLC>(__ballot(pay_node), kt_, bp, omega_p, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cfp, conv); }
+            if constexpr (linear_df) add_df_correction<GAMMA, LDSLC>(pay_node, kp[0], kp[1], omega_p * qpay.kappa, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
         }
         // ---------------------------------------------------------------- fixed coupons not merged above
         for (int base = 0; base < n_fix; base += 64) {
@@ -474,8 +574,11 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
                 omega = a * exp(linear_df ? q.ln_d : fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
                 acc.pv += omega;
             }
-            add_nodes<2, DELTA, GAMMA>(__ballot(on), k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b);
-            if constexpr (linear_df) add_df_correction<GAMMA>(on, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+            { int kt_[2];
+#pragma unroll
+              for (int i_ = 0; i_ < 2; ++i_) kt_[i_] = tag(k[i_]);
+              add_nodes<2, DELTA, GAMMA, false, LDSLC>(__ballot(on), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b, conv); }
+            if constexpr (linear_df) add_df_correction<GAMMA, LDSLC>(on, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
         }
 
         // ---------------------------------------------------------------- results of this trade
@@ -488,6 +591,20 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
             const double d = acc.delta * 1e-4;
             if (lane < P && out.delta) out.delta[t * P + lane] = d;
             total.delta += d;
+        }
+        if constexpr (GAMMA && LDSLC) {
+            // scatter the flat convexity sums to the 4x4 blocks through the wave's staging slot
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int sl = 0; sl < kConvSlices; ++sl) stage[lane + 64 * sl] = acc.conv[sl];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int e = 0; e < kGammaPerLane; e += 2) {
+                acc.gamma[e] += stage[conv_pos[e / 2] & 0xffff];
+                acc.gamma[e + 1] += stage[conv_pos[e / 2] >> 16];
+            }
         }
         if (GAMMA) {
             const int bi = lane >> 3, bj = lane & 7;
@@ -566,6 +683,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void price_general_kernel(CurveDe
 }  // namespace
 
 size_t general_kernel_lds_bytes(int K, int Kc) {
+    constexpr int kWavesPerBlock = kThreadsL2 / 64;
     size_t tables = sizeof(double) * (static_cast<size_t>(K) + 3 * Kc + static_cast<size_t>(Kc) * kPillarPad +
                                       kWavesPerBlock * kPillarPad) + sizeof(int16_t) * (2 * static_cast<size_t>(K) + 2 * kLutMax);
     size_t reduce = sizeof(double) * kWavesPerBlock * kAggStride;
@@ -573,31 +691,65 @@ size_t general_kernel_lds_bytes(int K, int Kc) {
     return (need + 15) & ~static_cast<size_t>(15);
 }
 
+// LDS of the variant with resident convexity rows, or 0 when the curve has no packed tables
+size_t general_lds_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
+    if (!cv.lcc_pos || !cv.knot_class || (gamma && !cv.lcc)) return 0;
+    constexpr int kWavesPerBlock = kThreadsLds / 64;
+    size_t bytes = sizeof(double) * (static_cast<size_t>(cv.K) + 2 * cv.Kc + static_cast<size_t>(cv.Kc) * kPillarPad +
+                                     kWavesPerBlock * kPillarPad);
+    if (gamma)
+        bytes += sizeof(double) * (static_cast<size_t>(cv.Kcore + 1) * (cv.Ec + 1) + kWavesPerBlock * kConvStage) +
+                 sizeof(MiniKnot) * cv.n_mini;
+    bytes += sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + cv.Kc + 2 * kLutMax);
+    const size_t reduce = sizeof(double) * kWavesPerBlock * kAggStride;
+    if (bytes < reduce) bytes = reduce;
+    return (bytes + 15) & ~static_cast<size_t>(15);
+}
+
+bool general_kernel_uses_lds_rows(const CurveDev& cv, bool gamma) {
+    // worth it only for GAMMA (the rows are the convexity term); needs the packed tables and at most 192 core pairs
+    const size_t lds = general_lds_kernel_lds_bytes(cv, gamma);
+    return gamma && lds > 0 && lds <= 160 * 1024 && cv.Ec + 1 + (cv.Eu - cv.fringe_start) <= kConvStage;
+}
+
+int general_kernel_threads(const CurveDev& cv, bool gamma) {
+    return general_kernel_uses_lds_rows(cv, gamma) ? kThreadsLds : kThreadsL2;
+}
+
 hipError_t launch_price_general(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                                 bool want_gamma, int n_blocks, hipStream_t stream) {
-    const size_t lds = general_kernel_lds_bytes(cv.K, cv.Kc);
-    dim3 grid(n_blocks), block(kBlockThreads);
     const bool lin = cv.method == 2;
+    if (general_kernel_uses_lds_rows(cv, want_gamma)) {
+        const size_t lds = general_lds_kernel_lds_bytes(cv, true);
+        dim3 grid(n_blocks), block(kThreadsLds);
+        if (lin) hipLaunchKernelGGL((price_general_kernel<true, true, true, true>), grid, block, lds, stream, cv, tr, out);
+        else hipLaunchKernelGGL((price_general_kernel<true, true, false, true>), grid, block, lds, stream, cv, tr, out);
+        return hipGetLastError();
+    }
+    const size_t lds = general_kernel_lds_bytes(cv.K, cv.Kc);
+    dim3 grid(n_blocks), block(kThreadsL2);
     if (want_gamma) {
-        if (lin) hipLaunchKernelGGL((price_general_kernel<true, true, true>), grid, block, lds, stream, cv, tr, out);
-        else hipLaunchKernelGGL((price_general_kernel<true, true, false>), grid, block, lds, stream, cv, tr, out);
+        if (lin) hipLaunchKernelGGL((price_general_kernel<true, true, true, false>), grid, block, lds, stream, cv, tr, out);
+        else hipLaunchKernelGGL((price_general_kernel<true, true, false, false>), grid, block, lds, stream, cv, tr, out);
     } else if (want_delta) {
-        if (lin) hipLaunchKernelGGL((price_general_kernel<true, false, true>), grid, block, lds, stream, cv, tr, out);
-        else hipLaunchKernelGGL((price_general_kernel<true, false, false>), grid, block, lds, stream, cv, tr, out);
+        if (lin) hipLaunchKernelGGL((price_general_kernel<true, false, true, false>), grid, block, lds, stream, cv, tr, out);
+        else hipLaunchKernelGGL((price_general_kernel<true, false, false, false>), grid, block, lds, stream, cv, tr, out);
     } else {
-        if (lin) hipLaunchKernelGGL((price_general_kernel<false, false, true>), grid, block, lds, stream, cv, tr, out);
-        else hipLaunchKernelGGL((price_general_kernel<false, false, false>), grid, block, lds, stream, cv, tr, out);
+        if (lin) hipLaunchKernelGGL((price_general_kernel<false, false, true, false>), grid, block, lds, stream, cv, tr, out);
+        else hipLaunchKernelGGL((price_general_kernel<false, false, false, false>), grid, block, lds, stream, cv, tr, out);
     }
     return hipGetLastError();
 }
 
 hipError_t set_general_kernel_lds_limit(size_t bytes) {
-    const void* fns[] = {reinterpret_cast<const void*>(&price_general_kernel<true, true, false>),
-                         reinterpret_cast<const void*>(&price_general_kernel<true, false, false>),
-                         reinterpret_cast<const void*>(&price_general_kernel<false, false, false>),
-                         reinterpret_cast<const void*>(&price_general_kernel<true, true, true>),
-                         reinterpret_cast<const void*>(&price_general_kernel<true, false, true>),
-                         reinterpret_cast<const void*>(&price_general_kernel<false, false, true>)};
+    const void* fns[] = {reinterpret_cast<const void*>(&price_general_kernel<true, true, false, false>),
+                         reinterpret_cast<const void*>(&price_general_kernel<true, false, false, false>),
+                         reinterpret_cast<const void*>(&price_general_kernel<false, false, false, false>),
+                         reinterpret_cast<const void*>(&price_general_kernel<true, true, true, false>),
+                         reinterpret_cast<const void*>(&price_general_kernel<true, false, true, false>),
+                         reinterpret_cast<const void*>(&price_general_kernel<false, false, true, false>),
+                         reinterpret_cast<const void*>(&price_general_kernel<true, true, false, true>),
+                         reinterpret_cast<const void*>(&price_general_kernel<true, true, true, true>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
         if (e != hipSuccess) return e;

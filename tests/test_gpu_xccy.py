@@ -85,7 +85,7 @@ def test_basis_swap_value_delta_gamma(case):
         _close(res.gamma(curve).risk_ladder, want[key], scale * 1e-6)
     # cross-gamma foreign OIS x basis: the mixed term through the two curves' knot DFs (xccy_engine.cross_gamma_for_basis)
     cross = res.gamma.cross_gamma(CurveTypes.USD_OIS_SOFR, CurveTypes.USD_GBP_BASIS)
-    assert cross.risk_matrix.shape == (32, len(x.swap_times)) and np.any(cross.risk_matrix != 0.0)
+    assert cross.risk_matrix.shape == (len(usd.swap_times), len(x.swap_times)) and np.any(cross.risk_matrix != 0.0)
     _close(cross.risk_matrix, want["cross_for_basis"], scale * 1e-6)
     assert cross.curve_type_1 == CurveTypes.USD_OIS_SOFR and cross.currency == CurrencyTypes.GBP
 
