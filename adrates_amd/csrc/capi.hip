@@ -55,6 +55,8 @@ struct adr_ctx {
     double* dump = nullptr;                 // [32*32] store sink (kernels.hpp, OutputsDev::dump)
     unsigned long long* stamps = nullptr;   // diagnostic builds: [max_blocks*16][8]
     int max_blocks = 0;
+    double* lag_scratch = nullptr;          // payment-lag variant of the fast kernel: per-wave stash (kernels.hpp), allocated
+    int lag_blocks = 0;                     // with the first batch that has such trades; the grid it was sized for
 };
 
 struct adr_curve {
@@ -98,6 +100,11 @@ struct adr_trades {
     int chained_blocks = 0;          // the grid the chains were laid out for
     // delta / PV-only requests: the trades without payment lag and at most 45 coupons per leg as 16-slot rows of the
     // lite kernel (the trades of the 32-slot row table); list_nonlite = every other trade (for curves without a packed layout)
+    // gamma requests on curves with the packed layout: trades with payment lag or per-coupon notionals and at most 32
+    // coupons per leg as rows of the payment-lag variant of the fast kernel; list_rest = the general list without them
+    adr::TradesDev lagged{};
+    int64_t n_lagged = 0, n_rest = 0;
+    const int32_t* list_rest = nullptr;
     adr::LiteRowsDev lite{};
     int64_t n_lite = 0, n_nonlite = 0;
     const int32_t* list_nonlite = nullptr;
@@ -171,6 +178,7 @@ void adr_free_ctx(adr_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->dump) hipFree(ctx->dump);
+    if (ctx->lag_scratch) hipFree(ctx->lag_scratch);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -594,7 +602,7 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         (flt_weight && !all_finite(flt_weight, n_flt)) || !all_finite(notional, n) || !all_finite(spread, n))
         return fail(ADR_ERR_INVALID, "adr_trades_upload: times, amounts, accruals, notionals and spreads must be finite");
 
-    std::vector<int32_t> list_fast, list_long, list_general;
+    std::vector<int32_t> list_fast, list_long, list_general, list_lagged, list_rest;
     std::vector<adr::TradeHeader> hdr(static_cast<size_t>(n));
     constexpr int64_t kMaxChain = 4;     // rows per trade in the chained table: legs of up to 128 coupons
     auto rows_of = [&](int64_t t) {
@@ -607,6 +615,7 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
             general = (flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j])      // payment lag: ratio terms
                       || (flt_weight && flt_weight[j] != 1.0);              // per-coupon notionals
         (general ? list_general : rows_of(t) > 1 ? list_long : list_fast).push_back(static_cast<int32_t>(t));
+        if (general) (rows_of(t) == 1 ? list_lagged : list_rest).push_back(static_cast<int32_t>(t));
     }
     for (int64_t t = 0; t < n; ++t) {
         const int64_t mf = fix_off[t + 1] - fix_off[t], ml = flt_off[t + 1] - flt_off[t];
@@ -663,10 +672,11 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     // Row tables of the fast kernel (kernels.hpp): 32 zero-padded slots per row and array.  `pieces` lists, row
     // by row, (trade or -1 for an empty row, first coupon of the piece, "the trade continues" flag).
     struct Piece { int64_t trade; int64_t first; bool more; };
-    auto build_rows = [&](const std::vector<Piece>& pieces, adr::TradesDev& dst) {
+    auto build_rows = [&](const std::vector<Piece>& pieces, adr::TradesDev& dst, bool lagged = false) {
         const size_t rows = pieces.size(), S = adr::kRowSlots;
         std::vector<double> r_tp(rows * S, 0.0), r_ts(rows * S, 0.0), r_al(rows * S, 0.0), r_xtp(rows * S, 0.0),
-            r_xpay(rows * S, 0.0), r_n(rows, 0.0), r_sp(rows, 0.0);
+            r_xpay(rows * S, 0.0), r_n(rows, 0.0), r_sp(rows, 0.0), r_te(lagged ? rows * S : 0, 0.0),
+            r_w(lagged && flt_weight ? rows * S : 0, 1.0);
         std::vector<int32_t> r_meta(rows, 0), r_trade(rows, -1);
         for (size_t r = 0; r < rows; ++r) {
             const int64_t t = pieces[r].trade;
@@ -677,6 +687,8 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
             const int64_t mf = std::clamp<int64_t>(fix_off[t + 1] - f0, 0, adr::kRowSlots);
             for (int64_t j = 0; j < ml; ++j) {
                 r_tp[r * S + j] = flt_tp[l0 + j]; r_ts[r * S + j] = flt_ts[l0 + j]; r_al[r * S + j] = flt_alpha[l0 + j];
+                if (lagged) r_te[r * S + j] = flt_te[l0 + j];
+                if (lagged && flt_weight) r_w[r * S + j] = flt_weight[l0 + j];
             }
             for (int64_t j = 0; j < mf; ++j) { r_xtp[r * S + j] = fix_tp[f0 + j]; r_xpay[r * S + j] = fix_pay[f0 + j]; }
             r_n[r] = notional[t]; r_sp[r] = spread[t];
@@ -694,6 +706,9 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         dst.row_spread = static_cast<const double*>(put(r_sp.data(), r_sp.size() * sizeof(double)));
         dst.row_meta = static_cast<const int32_t*>(put(r_meta.data(), r_meta.size() * sizeof(int32_t)));
         dst.row_trade = static_cast<const int32_t*>(put(r_trade.data(), r_trade.size() * sizeof(int32_t)));
+        dst.rows_lagged = lagged ? 1 : 0;
+        dst.row_te = lagged ? static_cast<const double*>(put(r_te.data(), r_te.size() * sizeof(double))) : nullptr;
+        dst.row_w = (lagged && flt_weight) ? static_cast<const double*>(put(r_w.data(), r_w.size() * sizeof(double))) : nullptr;
     };
     {   // plain table: one row per trade, sorted by coupon count
         std::vector<Piece> pieces(list_fast.size());
@@ -741,6 +756,27 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         tr->chained.rows_chained = 1;
         tr->chained_blocks = blocks;
         build_rows(pieces, tr->chained);
+    }
+    tr->lagged = tr->dev;
+    tr->lagged.n_rows = 0;
+    tr->n_lagged = static_cast<int64_t>(list_lagged.size());
+    tr->n_rest = static_cast<int64_t>(list_rest.size());
+    tr->list_rest = static_cast<const int32_t*>(put(list_rest.data(), list_rest.size() * sizeof(int32_t)));
+    if (!list_lagged.empty()) {   // payment-lag rows: one row per trade, sorted by coupon count like the plain table
+        std::stable_sort(list_lagged.begin(), list_lagged.end(), [&](int32_t a, int32_t b) {
+            return hdr[static_cast<size_t>(a)].n_flt > hdr[static_cast<size_t>(b)].n_flt;
+        });
+        std::vector<Piece> pieces(list_lagged.size());
+        for (size_t r = 0; r < list_lagged.size(); ++r) pieces[r] = {list_lagged[r], 0, false};
+        tr->lagged.rows_chained = 0;
+        build_rows(pieces, tr->lagged, true);
+        const int blocks = std::max(1, ctx->n_cu) * 2;
+        if (e == hipSuccess && ctx->lag_blocks < blocks) {
+            if (ctx->lag_scratch) hipFree(ctx->lag_scratch);
+            ctx->lag_scratch = nullptr; ctx->lag_blocks = 0;
+            e = hipMalloc(reinterpret_cast<void**>(&ctx->lag_scratch), adr::fast_kernel_lag_scratch_bytes(blocks));
+            if (e == hipSuccess) ctx->lag_blocks = blocks;
+        }
     }
     {   // lite table (kernels.hpp, LiteRowsDev): segments of 3-, 2- and 1-row trades, longest coupon counts first
         constexpr int S = adr::kLiteSlots, C = adr::kLiteCoupons, G = 64 / adr::kLiteSlots;
@@ -835,7 +871,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         return ADR_OK;
     }
 
-    adr::OutputsDev o;
+    adr::OutputsDev o{};
     o.stamps = ctx->stamps;
     o.dump = ctx->dump;
     o.pv = (req_mask & ADR_REQ_VALUE) ? pv_dev : nullptr;
@@ -849,7 +885,9 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     // the chained fast kernel (packed layout) or the general kernel.
     const bool use_fast = curve->dev.packed_ok != 0;
     const bool use_lite = !want_gamma && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES && trades->lite.n_units > 0;
-    adr::TradesDev fast = trades->dev, chained = trades->chained, general = trades->dev;
+    adr::TradesDev fast = trades->dev, chained = trades->chained, general = trades->dev, lagged = trades->lagged;
+    const bool use_lag = want_gamma && use_fast && lagged.n_rows > 0 && ctx->lag_scratch != nullptr;
+    if (!use_lag) lagged.n_rows = 0;
     if (use_lite) {
         fast.n_rows = 0;                                   // the lite table holds exactly the 32-slot row table's trades
         if (use_fast) {                                    // long trades keep their chained rows
@@ -859,11 +897,18 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
             general.list = trades->list_nonlite; general.n_list = trades->n_nonlite;
         }
     } else if (use_fast) {
-        general.list = trades->list_general; general.n_list = trades->n_general;
+        general.list = use_lag ? trades->list_rest : trades->list_general;
+        general.n_list = use_lag ? trades->n_rest : trades->n_general;
     } else {
         fast.n_rows = 0; chained.n_rows = 0;   // general walks all n trades through the identity list
     }
-    int blocks_fast = 0, blocks_chained = 0, blocks_general = 0, blocks_lite = 0;
+    int blocks_fast = 0, blocks_chained = 0, blocks_general = 0, blocks_lite = 0, blocks_lag = 0;
+    if (lagged.n_rows > 0) {
+        const int waves = adr::fast_kernel_threads(true) / 64;
+        const int64_t units = (lagged.n_rows + adr::fast_kernel_groups() - 1) / adr::fast_kernel_groups();
+        const int64_t need = (units + waves - 1) / waves;
+        blocks_lag = static_cast<int>(std::min<int64_t>(need, std::min(ctx->lag_blocks, ctx->n_cu)));
+    }
     if (use_lite) {
         const size_t lds = adr::lite_kernel_lds_bytes(curve->dev, want_delta);
         const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
@@ -883,7 +928,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         const int64_t need = (general.n_list + threads / 64 - 1) / (threads / 64);
         blocks_general = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * (threads == adr::kGeneralThreads ? 4 : 2)));
     }
-    if (blocks_lite + blocks_fast + blocks_chained + blocks_general > ctx->max_blocks)
+    if (blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag > ctx->max_blocks)
         return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
     auto partials_at = [&](int first_block) {
         return agg_dev ? ctx->partials + static_cast<size_t>(first_block) * adr::kAggStride : nullptr;
@@ -904,9 +949,14 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained);
         ADR_HIP(adr::launch_price_general(curve->dev, general, o, want_delta, want_gamma, blocks_general, stream));
     }
+    if (blocks_lag > 0) {
+        o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general);
+        o.lag_scratch = ctx->lag_scratch;
+        ADR_HIP(adr::launch_price_fast(curve->dev, lagged, o, want_delta, want_gamma, blocks_lag, stream));
+    }
     if (agg_dev)
-        ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_lite + blocks_fast + blocks_chained + blocks_general, P,
-                                            want_gamma, agg_dev, stream));
+        ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag,
+                                            P, want_gamma, agg_dev, stream));
     return ADR_OK;
 }
 

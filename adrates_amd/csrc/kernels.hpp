@@ -19,6 +19,7 @@ constexpr int kGeneralThreads = 256;                                 // general 
 constexpr int kGeneralLdsThreads = 512;                              // ... 8 with LDS-resident convexity rows (1 block per CU)
 constexpr int kFastThreads = ADR_FAST_THREADS;
 constexpr int kRowSlots = 32;                                        // cash-flow slots per row of the fast table
+constexpr int kLagStashDoubles = 34;                                 // payment-lag variant: {v[32], omega, pad} per special node
 // lite kernel (kernels_lite.hip): 4 trades per wavefront, rows of 16 slots = 15 coupons + a spare lane
 constexpr int kLiteThreads = 512;
 constexpr int kLiteWavesPerSimd = 4;                                 // 2 blocks of 8 waves per CU (105 VGPRs)
@@ -59,6 +60,9 @@ struct TradesDev {
     // n_rows rows sorted by coupon count, kRowSlots zero-padded slots per row and array.
     int64_t n_rows;
     int rows_chained;            // rows are chains of 32-coupon pieces of longer trades (meta bit 18; see the kernel)
+    int rows_lagged;             // rows of trades with payment lag / per-coupon notionals (row_te, row_w; LAG kernel variant)
+    const double* row_te;        // [n_rows][kRowSlots] accrual end times (lagged rows only)
+    const double* row_w;         //                     per-coupon notional multipliers, or null (= 1)
     const double* row_tp;        // [n_rows][kRowSlots] float payment times
     const double* row_ts;        //                     accrual start times
     const double* row_alpha;     //                     accrual fractions
@@ -132,6 +136,7 @@ struct OutputsDev {
     double* gamma;           // [n*P*P] or null
     double* block_partials;  // [grid][kAggStride] or null
     double* dump;            // [32*32] sink for the gamma stores of the idle trade slot of a wave's last unit
+    double* lag_scratch;     // payment-lag variant: [grid waves][2 groups][32 nodes][kLagStashDoubles]
     unsigned long long* stamps;  // diagnostic builds only (ADR_STAMPS): [grid*waves][8] cycle sums per phase
 };
 
@@ -165,8 +170,10 @@ hipError_t launch_curve_build(const CurveBuildPlanDev& plan, int n_scen, const d
 
 size_t general_kernel_lds_bytes(int K, int Kc);
 int general_kernel_threads(const CurveDev& cv, bool gamma);          // block size of the variant launch_price_general picks
-size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma);
+size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma, bool lagged = false);
+int fast_kernel_threads(bool lagged);
 int fast_kernel_groups();
+size_t fast_kernel_lag_scratch_bytes(int n_blocks);
 hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes);
 hipError_t launch_price_general(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                                 bool want_gamma, int n_blocks, hipStream_t stream);

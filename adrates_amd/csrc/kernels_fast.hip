@@ -64,6 +64,7 @@ constexpr int kBlockThreads = kFastThreads;
 #endif
 constexpr int kOutParts = ADR_OUT_PARTS;      // the 8 output bands of a trade are gathered in this many batches
 constexpr int kWavesPerBlock = kBlockThreads / 64;
+constexpr int kLagThreads = 512;              // block size of the payment-lag variant
 
 __device__ __forceinline__ double shfl_d(double x, int src) { return __shfl(x, src, 64); }
 
@@ -78,6 +79,14 @@ __device__ __forceinline__ double from_prev_lane(double x) {
     const int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), 0x138, 0xf, 0xf, false);   // wave_shr:1
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), 0x138, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
+}
+
+// Broadcast of one lane of every quad to the quad (DPP quad_perm: 0x00, 0x55, 0xAA, 0xFF = lane 0, 1, 2, 3).
+template <int CTRL>
+__device__ __forceinline__ int quad_bcast_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ double quad_bcast_d(double x) {
+    return __hiloint2double(quad_bcast_i<CTRL>(__double2hiint(x)), quad_bcast_i<CTRL>(__double2loint(x)));
 }
 
 // Same-wave LDS hand-off.  The DS instructions of one wavefront are executed in issue order, so data written
@@ -128,8 +137,26 @@ __host__ __device__ constexpr int slot_doubles(bool gamma, int epg, int groups) 
 // group walks in consecutive iterations; a row whose meta word has bit 18 set is followed by another row of
 // the same trade, and the results are written after the last one.  (Cutting a leg into rows only forgoes the
 // merge of a start node into the previous payment node at the cut - same nodes, same sums.)
-template <bool DELTA, bool GAMMA, bool STORE, bool LONG, int EPG_, int CPG_, int G>
-__global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
+//
+// LAG: the table holds trades whose coupons accrue to a date other than their payment date (payment lag) and / or
+// carry a per-coupon notional multiplier (`row_te`, `row_w`).  Such a coupon is N w (D(ts) / D(te) - 1 + spread a)
+// D(tp): a RATIO node N w D(ts) D(tp) / D(te) - one exponential, up to six knots - plus the payment node
+// -N w (1 - spread a) D(tp).  Four lanes work on a coupon (eight coupons per pass): lanes 0-2 of a quad look up ts,
+// te and tp, lane 3 looks up tp again for the payment node; the quad shares its log discount factors through DPP
+// and every lane leaves ONE record, as in the plain kernel.  In the walk, the records of a ratio node only add to
+// `vacc` (and do their first-order and convexity work, both linear in the record) until the third one, which runs
+// the rank-one update with the whole v = v_s - v_e + v_p; the payment node follows as an ordinary node.  A ratio
+// node can couple a short-end start interval with a later payment interval - pairs of pillars the packed ladder
+// has no entry for (it holds the pairs one knot interval can create).  Such nodes ("special": at most a few per
+// trade) also leave {omega, v} in a per-wave scratch in global memory, and the output phase adds omega v_r v_c to
+// the elements without a packed entry while it expands the ladder.
+template <bool DELTA, bool GAMMA, bool STORE, bool LONG, bool LAG, int EPG_, int CPG_, int G>
+__global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
+    // the payment-lag variant keeps more state per lane (the patched elements' totals, the node under construction):
+    // 512-thread blocks, i.e. two waves per SIMD and up to 256 VGPRs, instead of 768 / three / 168
+    constexpr int kThreads = LAG ? kLagThreads : kBlockThreads;
+    constexpr int kWaves = kThreads / 64;
+    static_assert(!LAG || (GAMMA && DELTA && !LONG), "the payment-lag variant exists for gamma requests on plain rows");
     constexpr int L = 64 / G;                          // lanes per trade
     constexpr int PPL = kPillarPad / L;                // pillars per lane: l + L*k
     constexpr int EPG = GAMMA ? EPG_ : 1;              // packed entries per lane: l + L*i
@@ -158,7 +185,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     double* s_lcc = s_ljc + n_ljc;
     const int n_front = cv.K + 2 * cv.Kc + n_ljc + n_lcc + n_slack;
     double* s_slot = s_x + n_front + (n_front & 1);          // 16-byte aligned (the records are read as b128)
-    int16_t* s_first = reinterpret_cast<int16_t*>(s_slot + kWavesPerBlock * kSlotDoubles);
+    int16_t* s_first = reinterpret_cast<int16_t*>(s_slot + kWaves * kSlotDoubles);
     int16_t* s_comp = s_first + cv.K;
     int16_t* s_class = s_comp + cv.K;
     int16_t* s_lut = s_class + cv.Kc;
@@ -166,22 +193,22 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     {
         const double* src = reinterpret_cast<const double*>(cv.mini);
         double* dst = reinterpret_cast<double*>(s_mini);
-        for (int i = threadIdx.x; i < cv.n_mini * 8; i += kBlockThreads) dst[i] = src[i];
+        for (int i = threadIdx.x; i < cv.n_mini * 8; i += kThreads) dst[i] = src[i];
     }
-    for (int i = threadIdx.x; i < cv.K; i += kBlockThreads) {
+    for (int i = threadIdx.x; i < cv.K; i += kThreads) {
         s_x[i] = cv.x[i];
         s_first[i] = cv.first_of[i];
         s_comp[i] = cv.compact_of[i];
     }
-    for (int i = threadIdx.x; i < cv.Kc; i += kBlockThreads) {
+    for (int i = threadIdx.x; i < cv.Kc; i += kThreads) {
         s_log[i] = cv.log_df[i];
         s_invx[i] = cv.inv_x[i];
         s_class[i] = cv.knot_class[i];
     }
-    for (int i = threadIdx.x; i < 2 * cv.n_lut; i += kBlockThreads) s_lut[i] = cv.lut[i];
-    for (int i = threadIdx.x; i < n_ljc; i += kBlockThreads) s_ljc[i] = cv.ljc[i];
-    for (int i = threadIdx.x; i < n_lcc; i += kBlockThreads) s_lcc[i] = cv.lcc[i];
-    for (int i = threadIdx.x; i < n_slack; i += kBlockThreads) s_lcc[n_lcc + i] = 0.0;
+    for (int i = threadIdx.x; i < 2 * cv.n_lut; i += kThreads) s_lut[i] = cv.lut[i];
+    for (int i = threadIdx.x; i < n_ljc; i += kThreads) s_ljc[i] = cv.ljc[i];
+    for (int i = threadIdx.x; i < n_lcc; i += kThreads) s_lcc[i] = cv.lcc[i];
+    for (int i = threadIdx.x; i < n_slack; i += kThreads) s_lcc[n_lcc + i] = 0.0;
     __syncthreads();
 
     CurveLds c;
@@ -238,6 +265,22 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
         }
     }
 
+    // LAG: row and first column of this lane's pair of elements in each band (flat index 128 band + 2 lane of the
+    // [P][P] matrix), and the running totals of what the output phase adds to elements without a packed entry
+    int band_rc[LAG ? 8 : 1];
+    double tot_patch[LAG ? 16 : 1];
+    if (LAG) {
+#pragma unroll
+        for (int band = 0; band < 8; ++band) {
+            const int flat = band * 128 + 2 * lane;
+            band_rc[band] = (flat / P) | ((flat % P) << 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot_patch[i] = 0.0;
+    }
+    double* lag_scratch = LAG ? out.lag_scratch + (static_cast<size_t>(blockIdx.x) * kWaves + wave) * (G * L * kLagStashDoubles) +
+                                    g * (L * kLagStashDoubles) : nullptr;
+
     // running portfolio sums of this wave: pv per group (lane l == 0), delta per group lane/pillar,
     // gamma in the 64-lane packed layout (entry lane + 64 s)
     double tot_pv = 0.0, tot_delta[PPL], tot_gamma[GAMMA ? EPL : 1];
@@ -257,8 +300,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
     // memory operations of a wave retire in order, so a load issued behind 16 KB of stores would also wait
     // for those stores.
     const int64_t n_units = (tr.n_rows + G - 1) / G;
-    const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-    int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+    const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * kWaves;
+    int64_t unit = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
 
     double nx_tp = 0.0, nx_ts = 0.0, nx_al = 0.0, nx_xtp = 0.0, nx_xpay = 0.0, nx_N = 0.0, nx_spread = 0.0;
     int nx_meta = 0, nx_trade = -1;
@@ -269,8 +312,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
         if (u < n_units && row < tr.n_rows) {
             const int64_t at = row * kRowSlots + l;
             // read-once input stream and write-once outputs: non-temporal, they should not displace anything in L2
-            nx_tp = __builtin_nontemporal_load(tr.row_tp + at); nx_ts = __builtin_nontemporal_load(tr.row_ts + at);
-            nx_al = __builtin_nontemporal_load(tr.row_alpha + at);
+            nx_tp = __builtin_nontemporal_load(tr.row_tp + at);
+            if (!LAG) { nx_ts = __builtin_nontemporal_load(tr.row_ts + at); nx_al = __builtin_nontemporal_load(tr.row_alpha + at); }
             nx_xtp = __builtin_nontemporal_load(tr.row_xtp + at); nx_xpay = __builtin_nontemporal_load(tr.row_xpay + at);
             nx_N = tr.row_notional[row]; nx_spread = tr.row_spread[row];
             nx_meta = tr.row_meta[row]; nx_trade = tr.row_trade[row];
@@ -330,12 +373,12 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
         const bool fix_merged = fix_in && in && xtp == tp;
         if (fix_merged && xtp > 0.0) a_pay = fma(sf, xpay, a_pay);
         // own start node S_l unless it coincides with the previous payment node
-        bool own_start = valid && accrues && !(l > 0 && ptp == ts);
+        bool own_start = !LAG && valid && accrues && !(l > 0 && ptp == ts);
         const bool own_fixed = fix_in && !fix_merged && xtp > 0.0 && sf * xpay != 0.0;
 
         double qt = tp, qa = a_pay;               // this lane's query: time and coefficient
         bool qon = in && a_pay != 0.0;
-        {   // the group's first start node moves to the group's first spare lane, if there is one
+        if (!LAG) {   // the group's first start node moves to the group's first spare lane, if there is one
             const unsigned long long mine = (__ballot(own_start) >> gbase) & kGroupMask;
             const bool move = mine != 0 && n_flt < L;
             const int src = gbase + (mine ? __builtin_ctzll(mine) : 0);
@@ -343,6 +386,19 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             if (move && l == n_flt) { qt = st; qa = sl * N; qon = true; }
             if (move && lane == src) own_start = false;
         }
+        // LAG: the float coupons are walked eight at a time, four lanes per coupon (chunk passes), then the fixed
+        // coupons that did not merge (lane = coupon again)
+        int n_chunks = 0;
+        if (LAG) {
+            int m = live ? n_flt : 0;
+#pragma unroll
+            for (int off = L; off < 64; off <<= 1) m = max(m, __shfl_xor(m, off, 64));
+            n_chunks = (__builtin_amdgcn_readfirstlane(m) + 7) >> 3;
+        }
+        double vacc[PPL];                         // LAG: v of the ratio node under construction
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) vacc[k] = 0.0;
+        int n_special = 0;                        // LAG: special nodes of this group's trade so far
         const bool more_starts = __ballot(own_start) != 0, more_fixed = __ballot(own_fixed) != 0;
         ADR_STAMP(1);   // node folding
 
@@ -368,17 +424,83 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             }
         };
 
-        for (int pass = 0; pass < 3; ++pass) {
-            if (pass == 1) {            // fixed coupons that did not merge into a float payment node
-                if (!more_fixed) continue;
+        const int n_pass = LAG ? n_chunks + 1 : 3;
+        for (int pass = 0; pass < n_pass; ++pass) {
+            const bool chunk_pass = LAG && pass < n_chunks;
+            if (!LAG) {
+                if (pass == 1) {            // fixed coupons that did not merge into a float payment node
+                    if (!more_fixed) continue;
+                    qt = xtp; qa = sf * xpay; qon = own_fixed;
+                } else if (pass == 2) {     // start nodes that found no spare lane
+                    if (!more_starts) break;
+                    qt = ts; qa = sl * N; qon = own_start;
+                }
+            } else if (!chunk_pass) {
+                if (!more_fixed) break;
                 qt = xtp; qa = sf * xpay; qon = own_fixed;
-            } else if (pass == 2) {     // start nodes that found no spare lane
-                if (!more_starts) break;
-                qt = ts; qa = sl * N; qon = own_start;
             }
             // ---- build: lookup + exp in the lanes that own a query
             int cls_a = -2, cls_b = -2;
             double ba = 0.0, bb = 0.0, omega = 0.0;
+            bool greeks_lag = false, special = false;
+            if (chunk_pass) {
+                // coupon q of the row, role 0: accrual start, 1: accrual end, 2: payment time (ratio node),
+                // 3: payment time (payment node); the quad's lanes read the same words (one L1 line per array)
+                const int q = 8 * pass + (l >> 2), role = l & 3;
+                const int64_t at = (unit * G + g) * kRowSlots + q;
+                const bool have = live && q < n_flt;
+                double ctp = 0.0, cts = 0.0, cte = 0.0, cal = 0.0, cw = 1.0, cxtp = 0.0, cxpay = 0.0;
+                if (have) {
+                    ctp = tr.row_tp[at]; cts = tr.row_ts[at]; cte = tr.row_te[at]; cal = tr.row_alpha[at];
+                    if (tr.row_w) cw = tr.row_w[at];
+                    if (q < n_fix) { cxtp = tr.row_xtp[at]; cxpay = tr.row_xpay[at]; }
+                }
+                const bool cin = have && ctp >= 0.0, accr = cal > 0.0;
+                const double t_q = role == 0 ? cts : (role == 1 ? cte : ctp);
+                const bool look = cin && (role == 3 || accr);
+                int ka = 0, kb = 0;
+                double ell = 0.0;
+                if (look) {
+                    const Lookup lq = curve_lookup(c, t_q);
+                    ba = lq.ba; bb = lq.bb; ka = lq.ka; kb = lq.kb;
+                    cls_a = c.knot_class[ka];
+                    cls_b = bb != 0.0 ? c.knot_class[kb] : -2;
+                    ell = fma(ba, c.log_df[ka], bb * c.log_df[kb]);
+                }
+                // the quad shares its three log discount factors, classes and the accrual-end weights
+                const double ls = quad_bcast_d<0x00>(ell), le = quad_bcast_d<0x55>(ell), lp = quad_bcast_d<0xAA>(ell);
+                const int pair = (cls_a << 16) | (cls_b & 0xffff);
+                const int pair_s = quad_bcast_i<0x00>(pair), pair_e = quad_bcast_i<0x55>(pair), pair_p = quad_bcast_i<0xAA>(pair);
+                const double e_ba = quad_bcast_d<0x55>(ba), e_bb = quad_bcast_d<0x55>(bb);
+                const int null_pair = (-2 << 16) | (-2 & 0xffff);
+                const double w_not = sl * N * cw;
+                const double om_r = (cin && accr) ? w_not * exp(ls - le + lp) : 0.0;
+                // accrual end and payment time a few days apart share their knots: the end weights join the payment
+                // record (one walk of those rows instead of two)
+                const bool fold_e = pair_e == pair_p;
+                if (role == 1) { ba = -ba; bb = -bb; }
+                if (role == 2 && fold_e) { ba -= e_ba; bb -= e_bb; }
+                if (role == 3) {
+                    double a_q = cin ? w_not * (spread * cal - (accr ? 1.0 : 0.0)) : 0.0;
+                    if (have && q < n_fix && cxtp == ctp && cxtp > 0.0) a_q = fma(sf, cxpay, a_q);   // the fixed coupon of the date
+                    omega = a_q * exp(ell);
+                    pv += omega;
+                    greeks_lag = omega != 0.0 && pair != null_pair;
+                } else {
+                    omega = om_r;
+                    if (role == 2) pv += omega;
+                    const bool any_part = pair_s != null_pair || pair_e != null_pair || pair_p != null_pair;
+                    greeks_lag = om_r != 0.0 && (role == 2 ? any_part : (pair != null_pair && !(role == 1 && fold_e)));
+                    // special: a short-end knot is involved and the parts do not all sit on one knot interval - the
+                    // rank-one term then reaches pairs of pillars the packed ladder has no entry for
+                    const bool has_mini = min(min(pair_s >> 16, static_cast<int>(static_cast<int16_t>(pair_s))),
+                                              min(min(pair_e >> 16, static_cast<int>(static_cast<int16_t>(pair_e))),
+                                                  min(pair_p >> 16, static_cast<int>(static_cast<int16_t>(pair_p))))) <= -3;
+                    const bool one_interval = (pair_s == null_pair || pair_s == pair_p) && (pair_e == null_pair || pair_e == pair_p);
+                    special = role == 2 && om_r != 0.0 && has_mini && !one_interval;
+                }
+                if (!greeks_lag) { omega = 0.0; ba = bb = 0.0; cls_a = cls_b = -2; }
+            } else
             if (qon) {
                 const Lookup q = curve_lookup(c, qt);
                 ba = q.ba; bb = q.bb;
@@ -389,7 +511,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             }
             ADR_STAMP(2);   // lookup + exp
             if (!DELTA) continue;
-            const bool greeks = qon && !(cls_a == -2 && cls_b == -2);
+            const bool greeks = chunk_pass ? greeks_lag : (qon && !(cls_a == -2 && cls_b == -2));
             if (!greeks) { omega = 0.0; cls_a = -2; cls_b = -2; }
             // ---- consume: the groups walk their nodes in lockstep.  Every lane leaves its node as a 32-byte
             // record {omega, ba, bb, the two knot classes} in LDS; node n of a group is then two broadcast
@@ -399,7 +521,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             {
                 double2* wp = reinterpret_cast<double2*>(rec + lane * 4);
                 wp[0] = make_double2(omega, ba);
-                wp[1] = make_double2(bb, __hiloint2double(cls_b, cls_a));   // both words are read back: a dead
+                const int cls_b_word = LAG ? ((cls_b & 0xffff) | (special ? 0x10000 : 0)) : cls_b;
+                wp[1] = make_double2(bb, __hiloint2double(cls_b_word, cls_a));   // both words are read back: a dead
                 // half would be reused as a scratch register while the prefetch of the record is still in flight
             }
             wave_lds_sync();
@@ -417,7 +540,12 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                 const int n_next = has_next ? __builtin_ctzll(any_row) : n;   // nothing left: read n again
                 any_row &= any_row - 1;
                 const double om = nx0.x, wa = nx0.y, wb = nx1.x;
-                const int ca = __double2loint(nx1.y), cb = __double2hiint(nx1.y);
+                const int cb_word = __double2hiint(nx1.y);
+                const int ca = __double2loint(nx1.y), cb = LAG ? static_cast<int>(static_cast<int16_t>(cb_word & 0xffff)) : cb_word;
+                // LAG chunk passes: records 0 and 1 of a quad only add to the ratio node's v; 2 completes it, 3 is the
+                // payment node (the lane index is the same for both groups, so this is wave-uniform)
+                const bool is_final = !chunk_pass || (n & 3) >= 2;
+                const bool is_special = LAG && (cb_word & 0x10000) != 0;
                 nx0 = rec_g[2 * n_next]; nx1 = rec_g[2 * n_next + 1];
                 n = n_next;
                 __builtin_amdgcn_sched_barrier(0);
@@ -453,8 +581,57 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                         }
                     }
                 }
+                auto mini_convexity = [&]() {
+                    if (any_mini) {
+#pragma unroll
+                        for (int side = 0; side < 2; ++side) {
+                            const bool mine = side == 0 ? mini_a : mini_b;
+                            if (!__ballot(mine)) continue;
+                            const MiniKnot& m = c.mini[mine ? (-3 - (side == 0 ? ca : cb)) : 0];
+                            const double coef = mine ? om * (side == 0 ? wa : wb) : 0.0;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                const int e = m.e[j];
+                                if (j > 0 && !__ballot(mine && e >= 0)) continue;   // single-pillar knots: one entry
+                                const bool owner = mine && e >= 0 && (e % L) == l;
+                                const double add = owner ? coef * m.lc[j] : 0.0;
+                                const int at = e / L;
+#pragma unroll
+                                for (int i = 0; i < EPG; ++i) acc[i] += (i == at) ? add : 0.0;
+                            }
+                        }
+                    }
+                };
 #pragma unroll
                 for (int k = 0; k < PPL; ++k) dacc[k] = fma(om, v[k], dacc[k]);
+                if (LAG) {
+#pragma unroll
+                    for (int k = 0; k < PPL; ++k) { vacc[k] += v[k]; v[k] = vacc[k]; }    // v of the node so far
+                    if (is_final) {
+#pragma unroll
+                        for (int k = 0; k < PPL; ++k) vacc[k] = 0.0;
+                        if (__ballot(is_special)) {      // keep {v, omega} for the pairs without a packed entry
+                            if (is_special) {
+                                double* dst = lag_scratch + n_special * kLagStashDoubles;
+#pragma unroll
+                                for (int k = 0; k < PPL; ++k) dst[l + L * k] = v[k];
+                                if (l == 0) dst[kPillarPad] = om;
+                                ++n_special;
+                            }
+                        }
+                    }
+                }
+                if (GAMMA && LAG && !is_final) {
+                    // a record that only adds to the node's v: its convexity part, nothing else
+                    if (__ballot(carry_row != zero_row && carry_row != ra)) {
+                        const bool flush = carry_row != ra;
+                        lc_row_pass(flush ? carry_row : zero_row, flush ? carry_w : 0.0);
+                        if (flush) { carry_row = zero_row; carry_w = 0.0; }
+                    }
+                    lc_row_pass(ra, om * wa + (carry_row == ra ? carry_w : 0.0));
+                    carry_row = rb; carry_w = om * wb;
+                    mini_convexity();
+                } else
                 if (GAMMA) {
                     // rank-1 part: omega * v v^T through the group's LDS slot
                     __builtin_amdgcn_wave_barrier();
@@ -506,25 +683,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
                     }
                     // convexity of short-end knots: one to three numbers (the symmetric 2x2 block on pillars
                     // p0, p1), added by the lanes that own the packed entries (p0,p0), (p0,p1), (p1,p1)
-                    if (any_mini) {
-#pragma unroll
-                        for (int side = 0; side < 2; ++side) {
-                            const bool mine = side == 0 ? mini_a : mini_b;
-                            if (!__ballot(mine)) continue;
-                            const MiniKnot& m = c.mini[mine ? (-3 - (side == 0 ? ca : cb)) : 0];
-                            const double coef = mine ? om * (side == 0 ? wa : wb) : 0.0;
-#pragma unroll
-                            for (int j = 0; j < 3; ++j) {
-                                const int e = m.e[j];
-                                if (j > 0 && !__ballot(mine && e >= 0)) continue;   // single-pillar knots: one entry
-                                const bool owner = mine && e >= 0 && (e % L) == l;
-                                const double add = owner ? coef * m.lc[j] : 0.0;
-                                const int at = e / L;
-#pragma unroll
-                                for (int i = 0; i < EPG; ++i) acc[i] += (i == at) ? add : 0.0;
-                            }
-                        }
-                    }
+                    mini_convexity();
                 }
                 if (!has_next) break;
             }
@@ -571,6 +730,8 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 #pragma unroll
             for (int gg = 0; gg < G; ++gg) {
                 const int tt = group_trade[gg];   // < 0: idle slot of the last unit, stored to the sink
+                const int n_sp_gg = LAG ? __builtin_amdgcn_readfirstlane(__shfl(n_special, gg * L, 64)) : 0;
+                if (LAG && n_sp_gg > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the scratch stores have landed
                 __builtin_amdgcn_wave_barrier();
                 if (g == gg) {
 #pragma unroll
@@ -602,6 +763,27 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 #pragma unroll
                         for (int s = 0; s < EPL; ++s) tot_gamma[s] += ts_[s];
                     }
+                    if (LAG && n_sp_gg > 0) {
+                        // special ratio nodes of this trade: omega v_r v_c for this lane's elements that have no packed
+                        // entry (their staging index is the zero entry), from the wave's scratch
+                        const double* sv = out.lag_scratch + (static_cast<size_t>(blockIdx.x) * kWaves + wave) * (G * L * kLagStashDoubles) +
+                                           gg * (L * kLagStashDoubles);
+                        for (int sp = 0; sp < n_sp_gg; ++sp, sv += kLagStashDoubles) {
+                            const double om_sp = __builtin_nontemporal_load(sv + kPillarPad) * 1e-8;
+#pragma unroll
+                            for (int b = 0; b < kBands; ++b) {
+                                const int band = kBands * part + b;
+                                const int r = band_rc[band] & 0xff, q = band_rc[band] >> 8;
+                                const bool miss0 = (mbs[b] & 0xffff) == kZeroEntry, miss1 = (mbs[b] >> 16) == kZeroEntry;
+                                if (((beyond >> band) & 1) || !(miss0 || miss1)) continue;
+                                const double vr = __builtin_nontemporal_load(sv + r);
+                                const nt_pair vc = __builtin_nontemporal_load(reinterpret_cast<const nt_pair*>(sv + q));
+                                const double a0 = miss0 ? om_sp * vr * vc.x : 0.0, a1 = miss1 ? om_sp * vr * vc.y : 0.0;
+                                gv[2 * b] += a0; gv[2 * b + 1] += a1;
+                                if (tt >= 0) { tot_patch[2 * band] += a0; tot_patch[2 * band + 1] += a1; }
+                            }
+                        }
+                    }
                     if (STORE) {
 #pragma unroll
                         for (int b = 0; b < kBands; ++b) {
@@ -620,7 +802,7 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
 
 #ifdef ADR_STAMPS
     if (out.stamps && lane == 0) {
-        unsigned long long* dst = out.stamps + (static_cast<size_t>(blockIdx.x) * kWavesPerBlock + wave) * 8;
+        unsigned long long* dst = out.stamps + (static_cast<size_t>(blockIdx.x) * kWaves + wave) * 8;
         for (int i = 0; i < 8; ++i) dst[i] = stamp_sum[i];
     }
 #endif
@@ -660,11 +842,26 @@ __global__ __launch_bounds__(kBlockThreads) void price_fast_kernel(CurveDev cv, 
             mine[1 + kPillarPad + r * kPillarPad + q] = GAMMA ? blk_gamma[GAMMA ? e : 0] : 0.0;
         }
         __syncthreads();
+        if (LAG) {      // the patched elements: every wave adds to its own record `mine`, each lane its own 16 elements
+            {
+                {
+#pragma unroll
+                    for (int band = 0; band < 8; ++band) {
+                        const int r = band_rc[band] & 0xff, q = band_rc[band] >> 8;
+                        if (r < P) {
+                            mine[1 + kPillarPad + r * kPillarPad + q] += tot_patch[2 * band];
+                            mine[1 + kPillarPad + r * kPillarPad + q + 1] += tot_patch[2 * band + 1];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
         double* dst = out.block_partials + static_cast<size_t>(blockIdx.x) * kAggStride;
-        for (int i = threadIdx.x; i < kAggStride; i += kBlockThreads) {
+        for (int i = threadIdx.x; i < kAggStride; i += kThreads) {
             double s = 0.0;
 #pragma unroll
-            for (int w = 0; w < kWavesPerBlock; ++w) s += red[w * kAggStride + i];
+            for (int w = 0; w < kWaves; ++w) s += red[w * kAggStride + i];
             dst[i] = s;
         }
     }
@@ -699,37 +896,37 @@ constexpr int kGroups = 2;   // trades per wavefront: the row table has 64 / 2 =
 // group lane, with cpg = epg - 2 (the last two slots hold the fringe pairs) or cpg = epg (universal).
 using KernelFn = void (*)(CurveDev, TradesDev, OutputsDev);
 
-template <int EPG, bool STORE, bool LONG>
+template <int EPG, bool STORE, bool LONG, bool LAG>
 KernelFn gamma_kernel(int cpg) {
-    if (cpg == EPG - 2) return &price_fast_kernel<true, true, STORE, LONG, EPG, EPG - 2, kGroups>;
-    return &price_fast_kernel<true, true, STORE, LONG, EPG, EPG, kGroups>;
+    if (cpg == EPG - 2) return &price_fast_kernel<true, true, STORE, LONG, LAG, EPG, EPG - 2, kGroups>;
+    return &price_fast_kernel<true, true, STORE, LONG, LAG, EPG, EPG, kGroups>;
 }
 
-template <bool STORE, bool LONG>
+template <bool STORE, bool LONG, bool LAG>
 KernelFn gamma_kernel_for(const CurveDev& cv) {
     switch (cv.epg) {
-        case 7: return gamma_kernel<7, STORE, LONG>(cv.cpg);
-        case 8: return gamma_kernel<8, STORE, LONG>(cv.cpg);
-        case 12: return gamma_kernel<12, STORE, LONG>(cv.cpg);
-        default: return gamma_kernel<18, STORE, LONG>(cv.cpg);
+        case 7: return gamma_kernel<7, STORE, LONG, LAG>(cv.cpg);
+        case 8: return gamma_kernel<8, STORE, LONG, LAG>(cv.cpg);
+        case 12: return gamma_kernel<12, STORE, LONG, LAG>(cv.cpg);
+        default: return gamma_kernel<18, STORE, LONG, LAG>(cv.cpg);
     }
 }
 
 template <bool LONG>
 KernelFn pick_kernel(const CurveDev& cv, bool want_delta, bool want_gamma, bool store_gamma) {
     if (!want_gamma)
-        return want_delta ? &price_fast_kernel<true, false, false, LONG, 1, 1, kGroups>
-                          : &price_fast_kernel<false, false, false, LONG, 1, 1, kGroups>;
-    return store_gamma ? gamma_kernel_for<true, LONG>(cv) : gamma_kernel_for<false, LONG>(cv);
+        return want_delta ? &price_fast_kernel<true, false, false, LONG, false, 1, 1, kGroups>
+                          : &price_fast_kernel<false, false, false, LONG, false, 1, 1, kGroups>;
+    return store_gamma ? gamma_kernel_for<true, LONG, false>(cv) : gamma_kernel_for<false, LONG, false>(cv);
 }
 
-template <bool STORE, bool LONG>
+template <bool STORE, bool LONG, bool LAG>
 void collect_gamma_kernels(std::vector<const void*>& fns) {
     for (int universal : {0, 1}) {
-        fns.push_back(reinterpret_cast<const void*>(gamma_kernel<7, STORE, LONG>(universal ? 7 : 5)));
-        fns.push_back(reinterpret_cast<const void*>(gamma_kernel<8, STORE, LONG>(universal ? 8 : 6)));
-        fns.push_back(reinterpret_cast<const void*>(gamma_kernel<12, STORE, LONG>(universal ? 12 : 10)));
-        fns.push_back(reinterpret_cast<const void*>(gamma_kernel<18, STORE, LONG>(universal ? 18 : 16)));
+        fns.push_back(reinterpret_cast<const void*>(gamma_kernel<7, STORE, LONG, LAG>(universal ? 7 : 5)));
+        fns.push_back(reinterpret_cast<const void*>(gamma_kernel<8, STORE, LONG, LAG>(universal ? 8 : 6)));
+        fns.push_back(reinterpret_cast<const void*>(gamma_kernel<12, STORE, LONG, LAG>(universal ? 12 : 10)));
+        fns.push_back(reinterpret_cast<const void*>(gamma_kernel<18, STORE, LONG, LAG>(universal ? 18 : 16)));
     }
 }
 
@@ -737,7 +934,13 @@ void collect_gamma_kernels(std::vector<const void*>& fns) {
 
 int fast_kernel_groups() { return kGroups; }
 
-size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
+size_t fast_kernel_lag_scratch_bytes(int n_blocks) {
+    return sizeof(double) * static_cast<size_t>(n_blocks) * (kLagThreads / 64) * kGroups * kGroupLanes * kLagStashDoubles;
+}
+int fast_kernel_threads(bool lagged) { return lagged ? kLagThreads : kBlockThreads; }
+
+size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma, bool lagged) {
+    const size_t kWavesPerBlock = static_cast<size_t>(fast_kernel_threads(lagged)) / 64;
     const size_t slot = slot_doubles(gamma, cv.epg, kGroups);
     const size_t slack = kGroupLanes * cv.cpg > cv.Ec + 1 ? kGroupLanes * cv.cpg - (cv.Ec + 1) : 0;
     size_t doubles = static_cast<size_t>(cv.K) + 2 * cv.Kc + static_cast<size_t>(cv.Kcore + 1) * cv.pc_pad +
@@ -753,10 +956,16 @@ size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
 
 hipError_t launch_price_fast(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                              bool want_gamma, int n_blocks, hipStream_t stream) {
-    const size_t lds = fast_kernel_lds_bytes(cv, want_gamma);
-    const KernelFn fn = tr.rows_chained ? pick_kernel<true>(cv, want_delta, want_gamma, out.gamma != nullptr)
-                                        : pick_kernel<false>(cv, want_delta, want_gamma, out.gamma != nullptr);
-    hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out);
+    const size_t lds = fast_kernel_lds_bytes(cv, want_gamma, tr.rows_lagged != 0);
+    KernelFn fn;
+    if (tr.rows_lagged) {
+        if (!want_gamma) return hipErrorInvalidValue;        // the payment-lag rows exist for gamma requests only
+        fn = out.gamma != nullptr ? gamma_kernel_for<true, false, true>(cv) : gamma_kernel_for<false, false, true>(cv);
+    } else {
+        fn = tr.rows_chained ? pick_kernel<true>(cv, want_delta, want_gamma, out.gamma != nullptr)
+                             : pick_kernel<false>(cv, want_delta, want_gamma, out.gamma != nullptr);
+    }
+    hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(fast_kernel_threads(tr.rows_lagged != 0)), lds, stream, cv, tr, out);
     return hipGetLastError();
 }
 
@@ -777,14 +986,16 @@ hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes) {
     e = set_lite_kernel_lds_limit(fast_bytes);
     if (e != hipSuccess) return e;
     std::vector<const void*> fns;
-    collect_gamma_kernels<true, false>(fns);
-    collect_gamma_kernels<false, false>(fns);
-    collect_gamma_kernels<true, true>(fns);
-    collect_gamma_kernels<false, true>(fns);
-    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<true, false, false, false, 1, 1, kGroups>));
-    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<false, false, false, false, 1, 1, kGroups>));
-    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<true, false, false, true, 1, 1, kGroups>));
-    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<false, false, false, true, 1, 1, kGroups>));
+    collect_gamma_kernels<true, false, false>(fns);
+    collect_gamma_kernels<false, false, false>(fns);
+    collect_gamma_kernels<true, true, false>(fns);
+    collect_gamma_kernels<false, true, false>(fns);
+    collect_gamma_kernels<true, false, true>(fns);
+    collect_gamma_kernels<false, false, true>(fns);
+    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<true, false, false, false, false, 1, 1, kGroups>));
+    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<false, false, false, false, false, 1, 1, kGroups>));
+    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<true, false, false, true, false, 1, 1, kGroups>));
+    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<false, false, false, true, false, 1, 1, kGroups>));
     for (const void* f : fns) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(fast_bytes));
         if (e != hipSuccess) return e;
