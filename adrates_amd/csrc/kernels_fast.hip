@@ -47,6 +47,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "curve_lookup.hpp"
@@ -75,6 +76,7 @@ __device__ __forceinline__ double from_next_lane(double x) {
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), 0x130, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ int from_prev_lane_i(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }   // wave_shr:1
 __device__ __forceinline__ double from_prev_lane(double x) {
     const int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), 0x138, 0xf, 0xf, false);   // wave_shr:1
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), 0x138, 0xf, 0xf, false);
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
             // ---- build: lookup + exp in the lanes that own a query
             int cls_a = -2, cls_b = -2;
             double ba = 0.0, bb = 0.0, omega = 0.0;
-            bool greeks_lag = false, special = false;
+            bool greeks_lag = false, special = false, taken_by_date = false;
             if (chunk_pass) {
                 // coupon q of the row, role 0: accrual start, 1: accrual end, 2: payment time (ratio node),
                 // 3: payment time (payment node); the quad's lanes read the same words (one L1 line per array)
@@ -500,6 +502,11 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                     special = role == 2 && om_r != 0.0 && has_mini && !one_interval;
                 }
                 if (!greeks_lag) { omega = 0.0; ba = bb = 0.0; cls_a = cls_b = -2; }
+                // records the date record of a quad takes along (see the walk): the quad's payment node, and the accrual
+                // start of the NEXT quad when it sits on the same two knots as this quad's payment time
+                const bool pr_live = quad_bcast_i<0xAA>(greeks_lag ? 1 : 0) != 0;
+                const int prev_pair = from_prev_lane_i(from_prev_lane_i(pair)), prev_live = from_prev_lane_i(from_prev_lane_i(greeks_lag ? 1 : 0));
+                taken_by_date = greeks_lag && ((role == 3 && pr_live) || (role == 0 && l >= 4 && prev_live != 0 && prev_pair == pair));
             } else
             if (qon) {
                 const Lookup q = curve_lookup(c, qt);
@@ -521,12 +528,12 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
             {
                 double2* wp = reinterpret_cast<double2*>(rec + lane * 4);
                 wp[0] = make_double2(omega, ba);
-                const int cls_b_word = LAG ? ((cls_b & 0xffff) | (special ? 0x10000 : 0)) : cls_b;
+                const int cls_b_word = LAG ? ((cls_b & 0xffff) | (special ? 0x10000 : 0) | (taken_by_date ? 0x20000 : 0)) : cls_b;
                 wp[1] = make_double2(bb, __hiloint2double(cls_b_word, cls_a));   // both words are read back: a dead
                 // half would be reused as a scratch register while the prefetch of the record is still in flight
             }
             wave_lds_sync();
-            unsigned long long any_row = __ballot(greeks);
+            unsigned long long any_row = __ballot(greeks && !taken_by_date);
 #pragma unroll
             for (int off = L; off < 64; off <<= 1) any_row |= any_row >> off;
             any_row &= kGroupMask;
@@ -542,10 +549,15 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                 const double om = nx0.x, wa = nx0.y, wb = nx1.x;
                 const int cb_word = __double2hiint(nx1.y);
                 const int ca = __double2loint(nx1.y), cb = LAG ? static_cast<int>(static_cast<int16_t>(cb_word & 0xffff)) : cb_word;
-                // LAG chunk passes: records 0 and 1 of a quad only add to the ratio node's v; 2 completes it, 3 is the
-                // payment node (the lane index is the same for both groups, so this is wave-uniform)
-                const bool is_final = !chunk_pass || (n & 3) >= 2;
+                // LAG chunk passes (the lane index is the same for both groups, so the role is wave-uniform): records 0
+                // and 1 of a quad (accrual start / end) only add to the ratio node's v; record 2 is the DATE record - it
+                // completes the ratio node and takes the quad's payment node (record 3) and the NEXT coupon's accrual
+                // start (record 0 of the next quad) along when those sit on the same two knots (flag 0x20000 in their
+                // class word): one walk of the date's rows, two rank-one updates
+                const int n_cur = n;
+                const int role = chunk_pass ? (n_cur & 3) : 3;
                 const bool is_special = LAG && (cb_word & 0x10000) != 0;
+                const bool taken = LAG && (cb_word & 0x20000) != 0;     // served by a date record: nothing to do on its own
                 nx0 = rec_g[2 * n_next]; nx1 = rec_g[2 * n_next + 1];
                 n = n_next;
                 __builtin_amdgcn_sched_barrier(0);
@@ -553,23 +565,23 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                 const bool mini_a = ca <= -3, mini_b = cb <= -3;
                 const bool any_mini = __ballot(mini_a || mini_b) != 0;
 
-                // v for this lane's pillars: core rows (the zero row for anything else) ...
-                double v[PPL];
+                // LJ at this lane's pillars for the record's two knots: core rows (the zero row for anything else),
+                // the short-end knots' one or two entries from their records
+                double ua[PPL], ub[PPL];
                 {
                     // (24-bit multiplies: full rate, v_mul_lo_u32 is quarter rate)
                     const double* lja = c.ljc + __mul24(ra, c.pc_pad);
                     const double* ljb = c.ljc + __mul24(rb, c.pc_pad);
 #pragma unroll
-                    for (int k = 0; k < PPL; ++k) v[k] = fma(wb, ljb[col[k]], wa * lja[col[k]]);
+                    for (int k = 0; k < PPL; ++k) { ua[k] = lja[col[k]]; ub[k] = ljb[col[k]]; }
                 }
-                // ... plus the short-end knots' one or two entries
                 if (any_mini) {
                     if (mini_a) {
                         const MiniKnot& m = c.mini[-3 - ca];
 #pragma unroll
                         for (int k = 0; k < PPL; ++k) {
                             const int p = l + L * k;
-                            v[k] = fma(wa, p == m.p[0] ? m.lj[0] : (p == m.p[1] ? m.lj[1] : 0.0), v[k]);
+                            ua[k] = p == m.p[0] ? m.lj[0] : (p == m.p[1] ? m.lj[1] : 0.0);
                         }
                     }
                     if (mini_b) {
@@ -577,18 +589,20 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
 #pragma unroll
                         for (int k = 0; k < PPL; ++k) {
                             const int p = l + L * k;
-                            v[k] = fma(wb, p == m.p[0] ? m.lj[0] : (p == m.p[1] ? m.lj[1] : 0.0), v[k]);
+                            ub[k] = p == m.p[0] ? m.lj[0] : (p == m.p[1] ? m.lj[1] : 0.0);
                         }
                     }
                 }
-                auto mini_convexity = [&]() {
+                // convexity of short-end knots: one to three numbers (the symmetric 2x2 block on pillars p0, p1), added
+                // by the lanes that own the packed entries (p0,p0), (p0,p1), (p1,p1)
+                auto mini_convexity = [&](double coef_a, double coef_b) {
                     if (any_mini) {
 #pragma unroll
                         for (int side = 0; side < 2; ++side) {
                             const bool mine = side == 0 ? mini_a : mini_b;
                             if (!__ballot(mine)) continue;
                             const MiniKnot& m = c.mini[mine ? (-3 - (side == 0 ? ca : cb)) : 0];
-                            const double coef = mine ? om * (side == 0 ? wa : wb) : 0.0;
+                            const double coef = mine ? (side == 0 ? coef_a : coef_b) : 0.0;
 #pragma unroll
                             for (int j = 0; j < 3; ++j) {
                                 const int e = m.e[j];
@@ -602,57 +616,32 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                         }
                     }
                 };
-#pragma unroll
-                for (int k = 0; k < PPL; ++k) dacc[k] = fma(om, v[k], dacc[k]);
-                if (LAG) {
-#pragma unroll
-                    for (int k = 0; k < PPL; ++k) { vacc[k] += v[k]; v[k] = vacc[k]; }    // v of the node so far
-                    if (is_final) {
-#pragma unroll
-                        for (int k = 0; k < PPL; ++k) vacc[k] = 0.0;
-                        if (__ballot(is_special)) {      // keep {v, omega} for the pairs without a packed entry
-                            if (is_special) {
-                                double* dst = lag_scratch + n_special * kLagStashDoubles;
-#pragma unroll
-                                for (int k = 0; k < PPL; ++k) dst[l + L * k] = v[k];
-                                if (l == 0) dst[kPillarPad] = om;
-                                ++n_special;
-                            }
-                        }
-                    }
-                }
-                if (GAMMA && LAG && !is_final) {
-                    // a record that only adds to the node's v: its convexity part, nothing else
+                // Convexity rows.  Consecutive nodes of a swap usually share a knot (the right neighbour of one payment
+                // time is the left neighbour of the next), so the right-hand row is not read with its node: its weight
+                // is carried to the next node and joins that node's left-hand weight when the rows agree; a carried row
+                // that does not match is added on its own first.  Returns the left row's coefficient.
+                auto convexity_coef = [&](double coef_a, double coef_b) {
                     if (__ballot(carry_row != zero_row && carry_row != ra)) {
                         const bool flush = carry_row != ra;
                         lc_row_pass(flush ? carry_row : zero_row, flush ? carry_w : 0.0);
                         if (flush) { carry_row = zero_row; carry_w = 0.0; }
                     }
-                    lc_row_pass(ra, om * wa + (carry_row == ra ? carry_w : 0.0));
-                    carry_row = rb; carry_w = om * wb;
-                    mini_convexity();
-                } else
-                if (GAMMA) {
-                    // rank-1 part: omega * v v^T through the group's LDS slot
+                    const double coa = coef_a + (carry_row == ra ? carry_w : 0.0);
+                    carry_row = rb; carry_w = coef_b;
+                    return coa;
+                };
+                // rank-one update om_r * vv vv^T through the group's LDS slot, with the left row's convexity term
+                // (coefficient coa) folded into the same batches of LDS reads when WITH_ROW
+                auto rank_one = [&](auto with_row, double om_r, const double (&vv_)[PPL], double coa) {
+                    constexpr bool WITH_ROW = decltype(with_row)::value;
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int k = 0; k < PPL; ++k) vbuf[l + L * k] = v[k];
+                    for (int k = 0; k < PPL; ++k) vbuf[l + L * k] = vv_[k];
                     wave_lds_sync();
-                    // Convexity rows.  Consecutive nodes of a swap usually share a knot (the right neighbour of
-                    // one payment time is the left neighbour of the next), so the right-hand row is not read
-                    // here: its weight is carried to the next node and joins that node's left-hand weight when
-                    // the rows agree; a carried row that does not match is added on its own first.
-                    if (__ballot(carry_row != zero_row && carry_row != ra)) {
-                        const bool flush = carry_row != ra;
-                        lc_row_pass(flush ? carry_row : zero_row, flush ? carry_w : 0.0);
-                        if (flush) { carry_row = zero_row; carry_w = 0.0; }
-                    }
                     const double* rowa = c.lcc + __mul24(ra, c.ec_stride) + (HUB ? 0 : l);
-                    const double coa = om * wa + (carry_row == ra ? carry_w : 0.0), cob = om * wb;
-                    carry_row = rb; carry_w = cob;
-                    // All operands of a batch of entries are fetched before any of them is used: the
-                    // scheduling barrier keeps the compiler from pairing each LDS read with its FMA (which
-                    // would expose one LDS round trip per entry).
+                    // All operands of a batch of entries are fetched before any of them is used: the scheduling barrier
+                    // keeps the compiler from pairing each LDS read with its FMA (which would expose one LDS round trip
+                    // per entry).
                     constexpr int kBatch = EPG < ADR_FAST_BATCH ? EPG : ADR_FAST_BATCH;
                     double hub_v = 0.0;
 #pragma unroll
@@ -665,15 +654,15 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                             if (!(HUB && i0 + i < CPG)) uu[i] = vbuf[up[i0 + i]];
                             vv[i] = vbuf[vq[i0 + i]];
                             // convexity rows: entry l + L*i of a row sits at row[l + L*i] (hub layout: row[pos[i]])
-                            if (i0 + i < CPG) la[i] = HUB ? rowa[pos[i0 + i]] : rowa[L * (i0 + i)];
+                            if (WITH_ROW && i0 + i < CPG) la[i] = HUB ? rowa[pos[i0 + i]] : rowa[L * (i0 + i)];
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int i = 0; i < kBatch; ++i) {
                             if (i0 + i >= EPG) continue;
                             const double u_i = (HUB && i0 + i < CPG) ? hub_v : uu[i];
-                            double gsum = fma(om * u_i, vv[i], acc[i0 + i]);
-                            if (i0 + i < CPG) {
+                            double gsum = fma(om_r * u_i, vv[i], acc[i0 + i]);
+                            if (WITH_ROW && i0 + i < CPG) {
                                 const bool core = CPG < EPG || (i0 + i) < core_entries;   // compile-time true unless universal
                                 gsum = fma(core ? coa : 0.0, la[i], gsum);
                             }
@@ -681,9 +670,74 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    // convexity of short-end knots: one to three numbers (the symmetric 2x2 block on pillars
-                    // p0, p1), added by the lanes that own the packed entries (p0,p0), (p0,p1), (p1,p1)
-                    mini_convexity();
+                };
+                auto stash_special = [&](const double (&vv_)[PPL], double om_r) {   // {v, omega} for the pairs without a packed entry
+                    if (__ballot(is_special)) {
+                        if (is_special) {
+                            double* dst = lag_scratch + n_special * kLagStashDoubles;
+#pragma unroll
+                            for (int k = 0; k < PPL; ++k) dst[l + L * k] = vv_[k];
+                            if (l == 0) dst[kPillarPad] = om_r;
+                            ++n_special;
+                        }
+                    }
+                };
+
+                if (LAG && chunk_pass && role == 2) {
+                    // ---- date record: ratio node (its last part), payment node, next coupon's accrual start
+                    const double2 p0 = rec_g[2 * (n_cur + 1)], p1 = rec_g[2 * (n_cur + 1) + 1];
+                    const int s_at = n_cur + 2 < L ? n_cur + 2 : n_cur;              // last quad of the row: nothing follows
+                    const double2 s0 = rec_g[2 * s_at], s1 = rec_g[2 * s_at + 1];
+                    const bool use_p = (__double2hiint(p1.y) & 0x20000) != 0;
+                    const bool use_s = n_cur + 2 < L && (__double2hiint(s1.y) & 0x20000) != 0;
+                    const double om_p = use_p ? p0.x : 0.0, wpa = use_p ? p0.y : 0.0, wpb = use_p ? p1.x : 0.0;
+                    const double om_s = use_s ? s0.x : 0.0, wsa = use_s ? s0.y : 0.0, wsb = use_s ? s1.x : 0.0;
+                    double v1[PPL], vp[PPL];
+#pragma unroll
+                    for (int k = 0; k < PPL; ++k) {
+                        const double vr = fma(wb, ub[k], wa * ua[k]);
+                        vp[k] = fma(wpb, ub[k], wpa * ua[k]);
+                        const double vs = fma(wsb, ub[k], wsa * ua[k]);
+                        dacc[k] = fma(om, vr, fma(om_p, vp[k], fma(om_s, vs, dacc[k])));
+                        v1[k] = vacc[k] + vr;
+                        vacc[k] = vs;                                   // the next ratio node starts with its accrual start
+                    }
+                    stash_special(v1, om);
+                    if (GAMMA) {
+                        const double coef_a = fma(om, wa, fma(om_p, wpa, om_s * wsa)), coef_b = fma(om, wb, fma(om_p, wpb, om_s * wsb));
+                        const double coa = convexity_coef(coef_a, coef_b);
+                        rank_one(std::true_type{}, om, v1, coa);
+                        mini_convexity(coef_a, coef_b);
+                        if (__ballot(om_p != 0.0)) rank_one(std::false_type{}, om_p, vp, 0.0);
+                    }
+                } else if (LAG && chunk_pass && role < 2) {
+                    // ---- accrual start / end on knots of their own: adds to the node's v; first-order and convexity part
+                    const double om_e = taken ? 0.0 : om;               // (a start record the previous date record has served)
+#pragma unroll
+                    for (int k = 0; k < PPL; ++k) {
+                        const double vk = taken ? 0.0 : fma(wb, ub[k], wa * ua[k]);
+                        dacc[k] = fma(om_e, vk, dacc[k]);
+                        vacc[k] += vk;
+                    }
+                    if (GAMMA) {
+                        const double coa = convexity_coef(om_e * wa, om_e * wb);
+                        lc_row_pass(ra, coa);
+                        mini_convexity(om_e * wa, om_e * wb);
+                    }
+                } else {
+                    // ---- an ordinary node (LAG: a payment node on its own, or a fixed coupon)
+                    const double om_n = taken ? 0.0 : om;
+                    double v[PPL];
+#pragma unroll
+                    for (int k = 0; k < PPL; ++k) {
+                        v[k] = fma(wb, ub[k], wa * ua[k]);
+                        dacc[k] = fma(om_n, v[k], dacc[k]);
+                    }
+                    if (GAMMA) {
+                        const double coa = convexity_coef(om_n * wa, om_n * wb);
+                        rank_one(std::true_type{}, om_n, v, coa);
+                        mini_convexity(om_n * wa, om_n * wb);
+                    }
                 }
                 if (!has_next) break;
             }

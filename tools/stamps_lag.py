@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of the payment-lag variant of the fast kernel (library built with -DADR_STAMPS)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from adrates_amd import _native
+from adrates_amd.market.curves.curve_tables import build_engine_curve
+from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
+from adrates_amd.utils import BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes
+from adrates_amd.trades.market_data import README_VALUE_DT as vd, gbp_model
+n = 200_000
+curve = gbp_model().curves.GBP_OIS_SONIA
+host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+ctx = _native.Context(0)
+dc = _native.DeviceCurve(ctx, 4, host.times, host.dfs, host.jac, host.hess)
+rng = np.random.default_rng(2)
+months = rng.integers(1, 361, n)
+terms = OISTerms(vd, [f"{int(m)}M" for m in months], rng.uniform(0.01, 0.07, n), np.round(rng.uniform(1e6, 5e7, n), -5),
+                 rng.random(n) < 0.5, FrequencyTypes.ANNUAL, DayCountTypes.ACT_365F, CurveTypes.GBP_OIS_SONIA,
+                 CurrencyTypes.GBP, float_freq_type=FrequencyTypes.ANNUAL, float_dc_type=DayCountTypes.ACT_365F, payment_lag=2,
+                 bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
+dt = _native.DeviceTrades(ctx, compile_ois_terms(terms, vd))
+dev = torch.device("cuda", 0); P = 32
+pv = torch.empty(n, dtype=torch.float64, device=dev); de = torch.empty((n, P), dtype=torch.float64, device=dev)
+ga = torch.empty((n, P, P), dtype=torch.float64, device=dev); ag = torch.empty(1 + P + P * P, dtype=torch.float64, device=dev)
+lib = _native.load()
+lib.adr_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+_native.price_dev(ctx, dc, dt, 7, pv.data_ptr(), de.data_ptr(), ga.data_ptr(), ag.data_ptr()); ctx.sync()
+nw = 256 * 8
+buf = np.zeros((nw, 8), dtype=np.uint64)
+lib.adr_debug_stamps(ctx._h, buf.ctypes.data_as(C.c_void_p), nw)
+tot = buf.sum(0).astype(float)
+names = ["input wait", "folding", "lookup+exp (chunk build)", "node consumption", "outputs", "-"]
+print("cycles per wave:", int(buf.sum(1).mean()))
+for nm, v in zip(names, tot[:6]): print(f"   {nm:26s} {100 * v / tot.sum():5.1f} %")
