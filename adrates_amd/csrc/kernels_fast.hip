@@ -451,14 +451,17 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                 const int q = 8 * pass + (l >> 2), role = l & 3;
                 const int64_t at = (unit * G + g) * kRowSlots + q;
                 const bool have = live && q < n_flt;
-                double ctp = 0.0, cts = 0.0, cte = 0.0, cal = 0.0, cw = 1.0, cxtp = 0.0, cxpay = 0.0;
+                double ctp = 0.0, t_q = 0.0, cal = 0.0, cw = 1.0, cxtp = 0.0, cxpay = 0.0;
                 if (have) {
-                    ctp = tr.row_tp[at]; cts = tr.row_ts[at]; cte = tr.row_te[at]; cal = tr.row_alpha[at];
+                    // this lane's query time comes from the array of its role (one load instead of three)
+                    const double* times = role == 0 ? tr.row_ts : (role == 1 ? tr.row_te : tr.row_tp);
+                    t_q = times[at];
+                    ctp = role >= 2 ? t_q : tr.row_tp[at];
+                    cal = tr.row_alpha[at];
                     if (tr.row_w) cw = tr.row_w[at];
-                    if (q < n_fix) { cxtp = tr.row_xtp[at]; cxpay = tr.row_xpay[at]; }
+                    if (role == 3 && q < n_fix) { cxtp = tr.row_xtp[at]; cxpay = tr.row_xpay[at]; }
                 }
                 const bool cin = have && ctp >= 0.0, accr = cal > 0.0;
-                const double t_q = role == 0 ? cts : (role == 1 ? cte : ctp);
                 const bool look = cin && (role == 3 || accr);
                 int ka = 0, kb = 0;
                 double ell = 0.0;
@@ -745,6 +748,9 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
             ADR_STAMP(3);   // node consumption
         }
         if (GAMMA && __ballot(carry_row != zero_row)) lc_row_pass(carry_row, carry_w);
+        // LAG: the scratch stores of this unit's special nodes must have landed before the output phase reads them back;
+        // waited for HERE, where nothing else is in flight (later, the wait would also cover the next unit's input loads)
+        if (LAG && __ballot(n_special > 0)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (LONG) {
             fresh = !more;
             if (more) {                        // the trade continues in this wave's next unit: no results yet
@@ -785,7 +791,6 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
             for (int gg = 0; gg < G; ++gg) {
                 const int tt = group_trade[gg];   // < 0: idle slot of the last unit, stored to the sink
                 const int n_sp_gg = LAG ? __builtin_amdgcn_readfirstlane(__shfl(n_special, gg * L, 64)) : 0;
-                if (LAG && n_sp_gg > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the scratch stores have landed
                 __builtin_amdgcn_wave_barrier();
                 if (g == gg) {
 #pragma unroll
@@ -823,16 +828,22 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                         const double* sv = out.lag_scratch + (static_cast<size_t>(blockIdx.x) * kWaves + wave) * (G * L * kLagStashDoubles) +
                                            gg * (L * kLagStashDoubles);
                         for (int sp = 0; sp < n_sp_gg; ++sp, sv += kLagStashDoubles) {
+                            // all of a node's operands for this part's bands are requested together (one L2 round trip)
+                            double vr[kBands];
+                            nt_pair vc[kBands];
                             const double om_sp = __builtin_nontemporal_load(sv + kPillarPad) * 1e-8;
 #pragma unroll
                             for (int b = 0; b < kBands; ++b) {
+                                const int rc_ = band_rc[kBands * part + b];
+                                vr[b] = __builtin_nontemporal_load(sv + (rc_ & 31));                 // (rows beyond P: masked below)
+                                vc[b] = __builtin_nontemporal_load(reinterpret_cast<const nt_pair*>(sv + ((rc_ >> 8) & 30)));
+                            }
+#pragma unroll
+                            for (int b = 0; b < kBands; ++b) {
                                 const int band = kBands * part + b;
-                                const int r = band_rc[band] & 0xff, q = band_rc[band] >> 8;
-                                const bool miss0 = (mbs[b] & 0xffff) == kZeroEntry, miss1 = (mbs[b] >> 16) == kZeroEntry;
-                                if (((beyond >> band) & 1) || !(miss0 || miss1)) continue;
-                                const double vr = __builtin_nontemporal_load(sv + r);
-                                const nt_pair vc = __builtin_nontemporal_load(reinterpret_cast<const nt_pair*>(sv + q));
-                                const double a0 = miss0 ? om_sp * vr * vc.x : 0.0, a1 = miss1 ? om_sp * vr * vc.y : 0.0;
+                                const bool inside = ((beyond >> band) & 1) == 0;
+                                const bool miss0 = inside && (mbs[b] & 0xffff) == kZeroEntry, miss1 = inside && (mbs[b] >> 16) == kZeroEntry;
+                                const double a0 = miss0 ? om_sp * vr[b] * vc[b].x : 0.0, a1 = miss1 ? om_sp * vr[b] * vc[b].y : 0.0;
                                 gv[2 * b] += a0; gv[2 * b + 1] += a1;
                                 if (tt >= 0) { tot_patch[2 * band] += a0; tot_patch[2 * band + 1] += a1; }
                             }
