@@ -199,7 +199,9 @@ int adr_curve_tables_host(int K, int P, const double* times, const double* dfs, 
     if (log_df) std::copy(t.log_df.begin(), t.log_df.end(), log_df);
     if (lj)
         for (int c = 0; c < t.Kc; ++c)
-            for (int p = 0; p < P; ++p) lj[static_cast<size_t>(c) * P + p] = t.lj[static_cast<size_t>(c) * adr::kPillarPad + p];
+            for (int p = 0; p < P; ++p)
+                lj[static_cast<size_t>(c) * P + p] =
+                    t.lj[(static_cast<size_t>(p / adr::kPillarPad) * t.Kc + c) * adr::kPillarPad + p % adr::kPillarPad];
     if (lc && t.has_hess) std::copy(t.lc.begin(), t.lc.end(), lc);
     return t.Kc;
 }
@@ -236,12 +238,12 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
         return fail(ADR_ERR_UNSUPPORTED, "adr_curve_upload: only FLAT_FWD_RATES (1), LINEAR_FWD_RATES (2) and "
                                          "LINEAR_ZERO_RATES (4) are implemented");
     if (P > ADR_MAX_PILLARS)
-        return fail(ADR_ERR_UNSUPPORTED, "adr_curve_upload: more than ADR_MAX_PILLARS pillars");
+        return fail(ADR_ERR_UNSUPPORTED, "adr_curve_upload: more than ADR_MAX_PILLARS (64) pillars");
     adr::CurveTables t;
     const std::string err = adr::build_curve_tables(K, P, times, dfs, jac, hess, t);
     if (!err.empty()) return fail(ADR_ERR_INVALID, "adr_curve_upload: " + err);
 
-    const size_t lds = adr::general_kernel_lds_bytes(t.K, t.Kc);
+    const size_t lds = adr::general_kernel_lds_bytes(t.K, t.Kc, t.T > 1);
     if (lds > kLdsBudget)
         return fail(ADR_ERR_UNSUPPORTED, "adr_curve_upload: curve tables exceed the 160 KiB LDS of a CU");
 
@@ -288,6 +290,7 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     }
     if (e != hipSuccess) { adr_free_curve(c); return fail_hip(e, "adr_curve_upload: copying tables"); }
     c->dev.K = t.K; c->dev.Kc = t.Kc; c->dev.P = t.P; c->dev.method = interp_method;
+    c->dev.T = t.T; c->dev.tile_i = c->dev.tile_j = 0;
     c->dev.x = d_x; c->dev.log_df = d_log; c->dev.inv_x = d_invx; c->dev.lj = d_lj; c->dev.lc_lanes = d_lc; c->dev.lc_block_mask = d_lcmask;
     c->dev.first_of = d_first; c->dev.compact_of = d_comp; c->dev.lut = d_lut; c->dev.n_lut = static_cast<int>(t.lut.size() / 2);
     // the fast kernels store the [P][P] matrices as 16-byte pairs of the flat array: P must be even
@@ -358,7 +361,8 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
         interp_method != ADR_INTERP_LINEAR_FWD_RATES)
         return fail(ADR_ERR_UNSUPPORTED, "adr_curve_plan_create: only FLAT_FWD_RATES (1), LINEAR_FWD_RATES (2) and "
                                          "LINEAR_ZERO_RATES (4) are implemented");
-    if (P > ADR_MAX_PILLARS) return fail(ADR_ERR_UNSUPPORTED, "adr_curve_plan_create: more than ADR_MAX_PILLARS pillars");
+    if (P > adr::kPillarPad)
+        return fail(ADR_ERR_UNSUPPORTED, "adr_curve_plan_create: the device curve builder takes at most 32 pillars");
     if (!acc || !pillar || !prev_idx) return fail(ADR_ERR_INVALID, "adr_curve_plan_create: null scan arrays");
     for (int k = 0; k < K; ++k) {
         if (pillar[k] < 0 || pillar[k] >= P) return fail(ADR_ERR_INVALID, "adr_curve_plan_create: pillar index out of range");
@@ -428,7 +432,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     d.knot_class = d_class; d.core_pillars = d_core; d.lcc_pq = d_lccpq;
 
     adr::CurveDev& c = plan->shared;
-    c.K = t.K; c.Kc = t.Kc; c.P = t.P; c.method = interp_method;
+    c.K = t.K; c.Kc = t.Kc; c.P = t.P; c.method = interp_method; c.T = 1; c.tile_i = c.tile_j = 0;
     c.x = d_x; c.inv_x = d_invx; c.first_of = d_first; c.compact_of = d_comp; c.lc_block_mask = d_lcmask;
     c.lut = d_lut; c.n_lut = static_cast<int>(t.lut.size() / 2);
     c.packed_ok = d.packed_ok;
@@ -877,6 +881,37 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     o.pv = (req_mask & ADR_REQ_VALUE) ? pv_dev : nullptr;
     o.delta = (req_mask & ADR_REQ_DELTA) ? delta_dev : nullptr;
     o.gamma = want_gamma ? gamma_dev : nullptr;
+
+    if (curve->dev.T > 1) {
+        // More than 32 pillars: the general kernel prices every trade once per pair of pillar tiles (tile_i <= tile_j);
+        // each launch writes its tile of the ladders, its partials are reduced into its tile of the aggregate.
+        const int T = curve->dev.T;
+        const int threads = adr::kGeneralThreads;
+        const int64_t need = (n + threads / 64 - 1) / (threads / 64);
+        const int blocks = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * 4));
+        const int n_launch = want_gamma ? T * (T + 1) / 2 : T;
+        if (blocks * n_launch > ctx->max_blocks) return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
+        adr::TradesDev all = trades->dev;
+        all.list = nullptr; all.n_list = n;
+        const size_t pair_tile = static_cast<size_t>(curve->dev.Kc) * 64 * adr::kGammaPerLane;
+        int launch = 0;
+        for (int tj = 0; tj < T; ++tj)
+            for (int ti = 0; ti <= tj; ++ti) {
+                if (!want_gamma && ti != tj) continue;               // PV / delta live on the diagonal tiles
+                adr::CurveDev cv = curve->dev;
+                cv.tile_i = ti; cv.tile_j = tj;
+                if (cv.lc_lanes) cv.lc_lanes += static_cast<size_t>(adr::tile_pair(ti, tj)) * pair_tile;
+                if (cv.lc_block_mask) cv.lc_block_mask += static_cast<size_t>(adr::tile_pair(ti, tj)) * curve->dev.Kc;
+                o.block_partials = agg_dev ? ctx->partials + static_cast<size_t>(launch) * blocks * adr::kAggStride : nullptr;
+                ADR_HIP(adr::launch_price_general(cv, all, o, want_delta, want_gamma, blocks, stream));
+                if (agg_dev)
+                    ADR_HIP(adr::launch_reduce_partials(o.block_partials, blocks, P, want_gamma, agg_dev, stream, ti, tj));
+                ++launch;
+            }
+        if (agg_dev && !want_gamma)       // no off-diagonal launches ran: the gamma part of the aggregate is all zero
+            ADR_HIP(hipMemsetAsync(agg_dev + 1 + P, 0, sizeof(double) * static_cast<size_t>(P) * P, stream));
+        return ADR_OK;
+    }
 
     // Routing.  With GAMMA: trades without payment lag go to the fast kernel when the curve has the packed layout
     // (those with more than 32 coupons per leg as chains of rows, in a launch of their own), everything else to the

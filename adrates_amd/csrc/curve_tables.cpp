@@ -8,7 +8,7 @@ namespace adr {
 std::string build_curve_tables(int K, int P, const double* times, const double* dfs, const double* jac,
                                const double* hess, CurveTables& out) {
     if (K < 2) return "curve needs at least two knots";
-    if (P < 1 || P > kPillarPad) return "pillar count must be in 1.." + std::to_string(kPillarPad);
+    if (P < 1 || P > kMaxPillars) return "pillar count must be in 1.." + std::to_string(kMaxPillars);
     if (K > 32767) return "too many knots (int16 index tables)";
     if (!times || !dfs || !jac) return "times, dfs and jac must not be null";
     for (int k = 0; k < K; ++k) {
@@ -62,37 +62,45 @@ std::string build_curve_tables(int K, int P, const double* times, const double* 
     }
     const int Kc = out.Kc = static_cast<int>(out.knot_index.size());
 
+    const int T = out.T = pillar_tiles(P), n_pairs = T * (T + 1) / 2;
     out.log_df.resize(Kc);
     out.inv_x.resize(Kc);
-    out.lj.assign(static_cast<size_t>(Kc) * kPillarPad, 0.0);
+    out.lj.assign(static_cast<size_t>(T) * Kc * kPillarPad, 0.0);
     if (out.has_hess) {
         out.lc.assign(static_cast<size_t>(Kc) * P * P, 0.0);
-        out.lc_lanes.assign(static_cast<size_t>(Kc) * 64 * kGammaPerLane, 0.0);
-        out.lc_block_mask.assign(Kc, 0);
+        out.lc_lanes.assign(static_cast<size_t>(n_pairs) * Kc * 64 * kGammaPerLane, 0.0);
+        out.lc_block_mask.assign(static_cast<size_t>(n_pairs) * Kc, 0);
     }
 
+    std::vector<double> ljrow(static_cast<size_t>(P));
     for (int c = 0; c < Kc; ++c) {
         const int k = out.knot_index[c];
         const double d = dfs[k];
         out.log_df[c] = std::log(d);
         out.inv_x[c] = 1.0 / std::max(times[k], 1e-15);
-        double* ljrow = &out.lj[static_cast<size_t>(c) * kPillarPad];
-        for (int p = 0; p < P; ++p) ljrow[p] = jac[static_cast<size_t>(k) * P + p] / d;
+        for (int p = 0; p < P; ++p) {
+            ljrow[p] = jac[static_cast<size_t>(k) * P + p] / d;
+            out.lj[(static_cast<size_t>(p / kPillarPad) * Kc + c) * kPillarPad + p % kPillarPad] = ljrow[p];
+        }
         if (!out.has_hess) continue;
         const double* hk = hess + static_cast<size_t>(k) * P * P;
         double* lck = &out.lc[static_cast<size_t>(c) * P * P];
         for (int p = 0; p < P; ++p)
             for (int q = 0; q < P; ++q) lck[p * P + q] = hk[p * P + q] / d - ljrow[p] * ljrow[q];
-        double* lanes = &out.lc_lanes[static_cast<size_t>(c) * 64 * kGammaPerLane];
-        uint64_t mask = 0;
-        for (int lane = 0; lane < 64; ++lane)
-            for (int e = 0; e < kGammaPerLane; ++e) {
-                const int r = gamma_row(lane, e), q = gamma_col(lane, e);
-                const double x = (r < P && q < P) ? lck[r * P + q] : 0.0;
-                lanes[lane * kGammaPerLane + e] = x;
-                if (x != 0.0) mask |= 1ull << lane;
+        for (int tj = 0; tj < T; ++tj)
+            for (int ti = 0; ti <= tj; ++ti) {
+                const size_t pair = static_cast<size_t>(tile_pair(ti, tj));
+                double* lanes = &out.lc_lanes[(pair * Kc + c) * 64 * kGammaPerLane];
+                uint64_t mask = 0;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < kGammaPerLane; ++e) {
+                        const int r = kPillarPad * ti + gamma_row(lane, e), q = kPillarPad * tj + gamma_col(lane, e);
+                        const double x = (r < P && q < P) ? lck[r * P + q] : 0.0;
+                        lanes[lane * kGammaPerLane + e] = x;
+                        if (x != 0.0) mask |= 1ull << lane;
+                    }
+                out.lc_block_mask[pair * Kc + c] = mask;
             }
-        out.lc_block_mask[c] = mask;
     }
     out.packed_ok = build_packed_layout(out);
     return std::string();
@@ -211,6 +219,7 @@ static bool hub_layout(int Pc, const std::vector<int>& core_pillars, int cpg, Cu
 // intervals and are not covered; they go to the general kernel.
 bool build_packed_layout(CurveTables& t) {
     const int P = t.P, Kc = t.Kc;
+    if (P > kPillarPad) return false;          // the packed layout (fast kernels) is for one pillar tile
     std::vector<uint32_t> support(Kc, 0u);
     for (int c = 0; c < Kc; ++c) {
         uint32_t m = 0;

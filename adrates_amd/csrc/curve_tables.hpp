@@ -20,7 +20,10 @@
 
 namespace adr {
 
-constexpr int kPillarPad = 32;                                  // ladders are padded to this on chip
+constexpr int kPillarPad = 32;                                  // ladders are padded to this on chip (one pillar tile)
+constexpr int kMaxPillars = 64;                                 // more than 32 pillars: tiles of 32, general kernel only
+inline int pillar_tiles(int P) { return (P + kPillarPad - 1) / kPillarPad; }
+inline int tile_pair(int ti, int tj) { return tj * (tj + 1) / 2 + ti; }       // ti <= tj
 constexpr int kGammaPerLane = kPillarPad * kPillarPad / 64;     // 16 gamma entries per lane (4x4 block)
 constexpr int kMinCorePillars = 8;   // fewer core pillars than this: no packed layout (general kernel)
 constexpr int kGroupLanes = 32;                                 // lanes per trade in the fast kernel
@@ -54,10 +57,12 @@ struct CurveTables {
     std::vector<int32_t> knot_index;   // [Kc]  inverse of compact_of
     std::vector<double> log_df;        // [Kc]
     std::vector<double> inv_x;         // [Kc]  1 / max(x_k, 1e-15)   (linear-zero-rate weights)
-    std::vector<double> lj;            // [Kc][kPillarPad], zero padded
+    int T = 1;                         // pillar tiles of 32: ceil(P / 32)
+    std::vector<double> lj;            // [T][Kc][kPillarPad], zero padded: pillar 32 t + j of knot c at (t * Kc + c) * 32 + j
     std::vector<double> lc;            // [Kc][P][P] row-major (plain layout, for checking)
-    std::vector<double> lc_lanes;      // [Kc][64][16] lane-major layout read by the general gamma kernel
-    std::vector<uint64_t> lc_block_mask;  // [Kc] bit l: lane l's 4x4 block of LC_k has a non-zero entry
+    std::vector<double> lc_lanes;      // [pairs][Kc][64][16] lane-major 32x32 tiles read by the general gamma kernel; tile pair
+                                       //                     (ti <= tj) at index tile_pair(ti, tj), pair 0 = the only one for P <= 32
+    std::vector<uint64_t> lc_block_mask;  // [pairs][Kc] bit l: lane l's 4x4 block of that tile of LC_k has a non-zero entry
 
     // ---- packed layout of the fast kernels (see build_packed_layout) ----
     int Pc = 0;                        // pillars in the core set

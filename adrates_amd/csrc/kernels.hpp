@@ -103,6 +103,8 @@ struct LiteRowsDev {
 // Curve tables in HBM.
 struct CurveDev {
     int K, Kc, P, method;
+    int T;                       // pillar tiles of 32 (curve_tables.hpp); more than one: general kernel, one launch per tile pair
+    int tile_i, tile_j;          // the tile pair (tile_i <= tile_j) a general-kernel launch works on; 0, 0 for P <= 32
     const double* x;             // [K]
     const double* log_df;        // [Kc]
     const double* inv_x;         // [Kc]
@@ -111,9 +113,9 @@ struct CurveDev {
     const int16_t* first_of;     // [K]
     const int16_t* compact_of;   // [K]
     // general kernel: dense 32-wide tables
-    const double* lj;            // [Kc][32]
-    const double* lc_lanes;      // [Kc][64][16], null without gamma
-    const unsigned long long* lc_block_mask;  // [Kc] lanes whose 4x4 block of LC_k is not structurally zero
+    const double* lj;            // [T][Kc][32]
+    const double* lc_lanes;      // [pairs][Kc][64][16], null without gamma
+    const unsigned long long* lc_block_mask;  // [pairs][Kc] lanes whose 4x4 block of that tile of LC_k is not structurally zero
     // fast kernels: packed layout (curve_tables.hpp), valid when packed_ok
     int packed_ok, Pc, pc_pad, Ec, Eu, epg, cpg, hub, Kcore, n_mini;
     int fringe_start;            // first packed entry of the fringe pairs (entries fringe_start .. Eu - 1)
@@ -168,7 +170,7 @@ hipError_t launch_curve_build(const CurveBuildPlanDev& plan, int n_scen, const d
                               double* jac, double* hess, double* d2pv_scratch, const CurvePackOut& out,
                               hipStream_t stream);
 
-size_t general_kernel_lds_bytes(int K, int Kc);
+size_t general_kernel_lds_bytes(int K, int Kc, bool two_tiles = false);
 int general_kernel_threads(const CurveDev& cv, bool gamma);          // block size of the variant launch_price_general picks
 size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma, bool lagged = false);
 int fast_kernel_threads(bool lagged);
@@ -184,7 +186,9 @@ size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta);
 hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const OutputsDev& out, bool want_delta,
                              int n_blocks, hipStream_t stream);
 // has_gamma == false: the gamma part of the partials was not written (no gamma requested); agg's gamma part is zeroed
+// (tile_i, tile_j): the pillar tile pair the partials belong to (0, 0 for P <= 32); off-diagonal tiles are also written
+// transposed; pv comes from tile (0, 0), delta from the diagonal tiles
 hipError_t launch_reduce_partials(const double* partials, int n_blocks, int P, bool has_gamma, double* agg,
-                                  hipStream_t stream);
+                                  hipStream_t stream, int tile_i = 0, int tile_j = 0);
 
 }  // namespace adr

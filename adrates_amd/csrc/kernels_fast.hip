@@ -935,24 +935,34 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
 // Fixed-order sum of the block partials -> agg[1 + P + P*P]: one wavefront per output, lanes stride over
 // the blocks, then a fixed butterfly - the aggregate does not depend on scheduling.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* partials, int n_blocks, int P,
-                                                               int has_gamma, double* agg) {
+                                                               int has_gamma, double* agg, int ti, int tj) {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int n_out = 1 + P + P * P;
-    if (i >= n_out) return;
-    if (!has_gamma && i >= 1 + P) {       // nothing was accumulated there: the launches ran without GAMMA
-        if (lane == 0) agg[i] = 0.0;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // slot of the tile-local record
+    if (i >= kAggStride) return;
+    const bool diag = ti == tj;
+    int at = -1, mirror = -1;                                                // where the slot goes in agg[1 + P + P*P]
+    if (i == 0) {
+        if (ti == 0 && tj == 0) at = 0;
+    } else if (i < 1 + kPillarPad) {
+        const int p = kPillarPad * ti + i - 1;
+        if (diag && p < P) at = 1 + p;
+    } else {
+        const int r = kPillarPad * ti + (i - 1 - kPillarPad) / kPillarPad, q = kPillarPad * tj + (i - 1 - kPillarPad) % kPillarPad;
+        if (r < P && q < P) {
+            at = 1 + P + r * P + q;
+            if (!diag) mirror = 1 + P + q * P + r;
+        }
+    }
+    if (at < 0) return;
+    if (!has_gamma && i >= 1 + kPillarPad) {      // nothing was accumulated there: the launches ran without GAMMA
+        if (lane == 0) { agg[at] = 0.0; if (mirror >= 0) agg[mirror] = 0.0; }
         return;
     }
-    int src;
-    if (i == 0) src = 0;
-    else if (i < 1 + P) src = i;
-    else { const int r = (i - 1 - P) / P, q = (i - 1 - P) % P; src = 1 + kPillarPad + r * kPillarPad + q; }
     double s = 0.0;
-    for (int b = lane; b < n_blocks; b += 64) s += partials[static_cast<size_t>(b) * kAggStride + src];
+    for (int b = lane; b < n_blocks; b += 64) s += partials[static_cast<size_t>(b) * kAggStride + i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) agg[i] = s;
+    if (lane == 0) { agg[at] = s; if (mirror >= 0) agg[mirror] = s; }
 }
 
 constexpr int kGroups = 2;   // trades per wavefront: the row table has 64 / 2 = 32 slots per row
@@ -1035,10 +1045,9 @@ hipError_t launch_price_fast(const CurveDev& cv, const TradesDev& tr, const Outp
 }
 
 hipError_t launch_reduce_partials(const double* partials, int n_blocks, int P, bool has_gamma, double* agg,
-                                  hipStream_t stream) {
-    const int n_out = 1 + P + P * P;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_out + 3) / 4), dim3(256), 0, stream, partials, n_blocks, P,
-                       has_gamma ? 1 : 0, agg);
+                                  hipStream_t stream, int tile_i, int tile_j) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((kAggStride + 3) / 4), dim3(256), 0, stream, partials, n_blocks, P,
+                       has_gamma ? 1 : 0, agg, tile_i, tile_j);
     return hipGetLastError();
 }
 

@@ -60,7 +60,10 @@ struct CurveLds {
     const double* x;        // [K]
     const double* log_df;   // [Kc]
     const double* inv_x;    // [Kc]
-    const double* lj;       // [Kc][32]
+    const double* lj;       // [Kc][32] of the row tile, then (off-diagonal tile pairs) [Kc][32] of the column tile
+    int lj_off;             // this lane's table: lanes 0-31 build v on the row tile, lanes 32-63 on the column tile
+    int col0;               // where the column tile's v sits in the wave's hand-off buffer (0 on diagonal tile pairs)
+    bool diag;              // the launch's tile pair is on the diagonal (always, for P <= 32): blocks below it are mirrors
     const int16_t* lut;         // [n_lut][2] knot-search table (curve_tables.hpp)
     int n_lut;
     const int16_t* first_of;    // [K]
@@ -206,14 +209,14 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
         for (int i = 0; i < NK; ++i) cc[i] = (CF && GAMMA) ? readlane_d(cf[i], n) : om * bb[i];
         double v = 0.0;
 #pragma unroll
-        for (int i = 0; i < NK; ++i) v = fma(bb[i], c.lj[kk[i] * kPillarPad + p], v);
+        for (int i = 0; i < NK; ++i) v = fma(bb[i], c.lj[c.lj_off + kk[i] * kPillarPad + p], v);
         if (DELTA) acc.delta = fma(om, v, acc.delta);
         if (GAMMA) {
             // hand v[0..31] to every lane through the wave's LDS slot (same-wave LDS ops are ordered)
             // (the DS instructions of one wavefront execute in issue order: a compiler barrier is all the
             // hand-off needs, no wait for the write to retire)
             __builtin_amdgcn_wave_barrier();
-            if (lane < 32) vbuf[lane] = v;
+            vbuf[lane] = v;                       // lanes 32-63: the column tile's v (a copy on diagonal tile pairs)
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
@@ -245,10 +248,10 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
             }
             // gamma is symmetric: only the lanes holding a block on or above the diagonal accumulate (and read
             // LC tiles); the mirror blocks are written from their registers at output time
-            if (bi > bj) continue;
+            if (c.diag && bi > bj) continue;
             double vr[4], vc[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { vr[i] = om * vbuf[4 * bi + i]; vc[i] = vbuf[4 * bj + i]; }
+            for (int i = 0; i < 4; ++i) { vr[i] = om * vbuf[4 * bi + i]; vc[i] = vbuf[c.col0 + 4 * bj + i]; }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -307,11 +310,13 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
     double* s_x = reinterpret_cast<double*>(smem_raw);
     double* s_log = s_x + cv.K;
     double* s_invx = s_log + cv.Kc;
+    const bool diag = cv.tile_i == cv.tile_j;
+    const int n_lj = cv.Kc * kPillarPad;                 // one pillar tile of LJ
     double* s_lj = s_invx + cv.Kc;
-    double* s_vbuf = s_lj + static_cast<size_t>(cv.Kc) * kPillarPad;
+    double* s_vbuf = s_lj + static_cast<size_t>(n_lj) * (diag ? 1 : 2);
     // per-knot masks of the structurally non-zero LC blocks: read before every tile, so LDS-resident (a global
     // read here would put a second L2 round trip in front of each tile)
-    unsigned long long* s_lcmask = reinterpret_cast<unsigned long long*>(s_vbuf + kWavesPerBlock * kPillarPad);
+    unsigned long long* s_lcmask = reinterpret_cast<unsigned long long*>(s_vbuf + kWavesPerBlock * 64);
     // LDS path: packed convexity rows, the short-end records and the per-wave staging of the flat sums
     const int ec_stride = cv.Ec + 1;
     const int n_lcc = (LDSLC && GAMMA) ? (cv.Kcore + 1) * ec_stride : 0;
@@ -341,7 +346,13 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
         for (int i = threadIdx.x; i < cv.n_mini * 8; i += kBlockThreads) dst[i] = src[i];
     }
     for (int i = threadIdx.x; i < 2 * cv.n_lut; i += kBlockThreads) s_lut[i] = cv.lut[i];
-    for (int i = threadIdx.x; i < cv.Kc * kPillarPad; i += kBlockThreads) s_lj[i] = cv.lj[i];
+    {
+        const double* row_tile = cv.lj + static_cast<size_t>(cv.tile_i) * n_lj;
+        const double* col_tile = cv.lj + static_cast<size_t>(cv.tile_j) * n_lj;
+        for (int i = threadIdx.x; i < n_lj; i += kBlockThreads) s_lj[i] = row_tile[i];
+        if (!diag)
+            for (int i = threadIdx.x; i < n_lj; i += kBlockThreads) s_lj[n_lj + i] = col_tile[i];
+    }
     __syncthreads();
 
     CurveLds c;
@@ -352,8 +363,14 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar loads of the header
     const int knot0 = c.compact_of[0];                                    // the value-time knot (t = 0)
     constexpr bool linear_df = LINDF;                                     // LINEAR_FWD_RATES: see `Lookup`
-    double* vbuf = s_vbuf + wave * kPillarPad;
+    double* vbuf = s_vbuf + wave * 64;
     const int P = cv.P;
+    c.lj_off = (lane >= 32 && !diag) ? n_lj : 0;
+    c.col0 = diag ? 0 : 32;
+    c.diag = diag;
+    const int row0 = kPillarPad * cv.tile_i, col0g = kPillarPad * cv.tile_j;    // first pillar of the row / column tile
+    const bool first_tile = cv.tile_i == 0 && cv.tile_j == 0;
+    const bool one_tile = cv.T == 1;
     const double* __restrict__ lc_lanes = cv.lc_lanes;
     const unsigned long long* lc_block_mask = s_lcmask;
     ConvLds conv;
@@ -582,14 +599,16 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
         }
 
         // ---------------------------------------------------------------- results of this trade
+        // (more than 32 pillars: this launch holds the tile pair (tile_i, tile_j) of the ladders - the PV comes from the
+        // launch of tile (0, 0), the delta tiles from the diagonal launches, off-diagonal gamma tiles are written twice)
         const double pv = wave_sum(acc.pv);
-        if (lane == 0) {
+        if (lane == 0 && first_tile) {
             if (out.pv) out.pv[t] = pv;
             total.pv += pv;
         }
-        if (DELTA) {
+        if (DELTA && diag) {
             const double d = acc.delta * 1e-4;
-            if (lane < P && out.delta) out.delta[t * P + lane] = d;
+            if (lane < kPillarPad && row0 + lane < P && out.delta) out.delta[t * P + row0 + lane] = d;
             total.delta += d;
         }
         if constexpr (GAMMA && LDSLC) {
@@ -608,44 +627,45 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
         }
         if (GAMMA) {
             const int bi = lane >> 3, bj = lane & 7;
+            const bool mine_block = !diag || bi <= bj;                       // diagonal tiles: blocks below the diagonal are mirrors
             double* g = out.gamma ? out.gamma + t * static_cast<int64_t>(P) * P : nullptr;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int r = 4 * bi + i;
+                const int r = row0 + 4 * bi + i;
                 double gv[4];
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) {
                     gv[jx] = acc.gamma[i * 4 + jx] * 1e-8;
                     total.gamma[i * 4 + jx] += gv[jx];
                 }
-                if (g && r < P && bi <= bj) {
-                    if (P == kPillarPad) {
+                if (g && r < P && mine_block) {
+                    if (one_tile && P == kPillarPad) {
                         double2* dst = reinterpret_cast<double2*>(g + r * kPillarPad + 4 * bj);
                         dst[0] = make_double2(gv[0], gv[1]);
                         dst[1] = make_double2(gv[2], gv[3]);
                     } else {
 #pragma unroll
                         for (int jx = 0; jx < 4; ++jx)
-                            if (4 * bj + jx < P) g[r * P + 4 * bj + jx] = gv[jx];
+                            if (col0g + 4 * bj + jx < P) g[r * P + col0g + 4 * bj + jx] = gv[jx];
                     }
                 }
             }
-            if (g && bi < bj) {          // the mirror block (bj, bi): rows 4*bj + jx hold column jx of this block
+            if (g && (!diag || bi < bj)) {   // the mirror block: rows (col0g + 4 bj + jx) hold column jx of this block
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) {
-                    const int r = 4 * bj + jx;
+                    const int r = col0g + 4 * bj + jx;
                     if (r >= P) continue;
                     double gt[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) gt[i] = acc.gamma[i * 4 + jx] * 1e-8;
-                    if (P == kPillarPad) {
+                    if (one_tile && P == kPillarPad) {
                         double2* dst = reinterpret_cast<double2*>(g + r * kPillarPad + 4 * bi);
                         dst[0] = make_double2(gt[0], gt[1]);
                         dst[1] = make_double2(gt[2], gt[3]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            if (4 * bi + i < P) g[r * P + 4 * bi + i] = gt[i];
+                            if (row0 + 4 * bi + i < P) g[r * P + row0 + 4 * bi + i] = gt[i];
                     }
                 }
             }
@@ -665,8 +685,8 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
             for (int e = 0; e < kGammaPerLane; ++e) {
                 const int r = 4 * bi + (e >> 2), q = 4 * bj + (e & 3);
                 const double x = GAMMA ? total.gamma[GAMMA ? e : 0] : 0.0;
-                if (bi <= bj) mine[1 + kPillarPad + r * kPillarPad + q] = x;
-                if (bi < bj) mine[1 + kPillarPad + q * kPillarPad + r] = x;     // lower blocks: mirrors
+                if (!diag || bi <= bj) mine[1 + kPillarPad + r * kPillarPad + q] = x;
+                if (diag && bi < bj) mine[1 + kPillarPad + q * kPillarPad + r] = x;     // lower blocks of a diagonal tile: mirrors
             }
         }
         __syncthreads();
@@ -682,10 +702,10 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
 
 }  // namespace
 
-size_t general_kernel_lds_bytes(int K, int Kc) {
+size_t general_kernel_lds_bytes(int K, int Kc, bool two_tiles) {
     constexpr int kWavesPerBlock = kThreadsL2 / 64;
-    size_t tables = sizeof(double) * (static_cast<size_t>(K) + 3 * Kc + static_cast<size_t>(Kc) * kPillarPad +
-                                      kWavesPerBlock * kPillarPad) + sizeof(int16_t) * (2 * static_cast<size_t>(K) + 2 * kLutMax);
+    size_t tables = sizeof(double) * (static_cast<size_t>(K) + 3 * Kc + static_cast<size_t>(Kc) * kPillarPad * (two_tiles ? 2 : 1) +
+                                      kWavesPerBlock * 64) + sizeof(int16_t) * (2 * static_cast<size_t>(K) + 2 * kLutMax);
     size_t reduce = sizeof(double) * kWavesPerBlock * kAggStride;
     size_t need = tables > reduce ? tables : reduce;
     return (need + 15) & ~static_cast<size_t>(15);
@@ -695,8 +715,9 @@ size_t general_kernel_lds_bytes(int K, int Kc) {
 size_t general_lds_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
     if (!cv.lcc_pos || !cv.knot_class || (gamma && !cv.lcc)) return 0;
     constexpr int kWavesPerBlock = kThreadsLds / 64;
+    if (cv.T > 1) return 0;
     size_t bytes = sizeof(double) * (static_cast<size_t>(cv.K) + 2 * cv.Kc + static_cast<size_t>(cv.Kc) * kPillarPad +
-                                     kWavesPerBlock * kPillarPad);
+                                     kWavesPerBlock * 64);
     if (gamma)
         bytes += sizeof(double) * (static_cast<size_t>(cv.Kcore + 1) * (cv.Ec + 1) + kWavesPerBlock * kConvStage) +
                  sizeof(MiniKnot) * cv.n_mini;
@@ -726,7 +747,7 @@ hipError_t launch_price_general(const CurveDev& cv, const TradesDev& tr, const O
         else hipLaunchKernelGGL((price_general_kernel<true, true, false, true>), grid, block, lds, stream, cv, tr, out);
         return hipGetLastError();
     }
-    const size_t lds = general_kernel_lds_bytes(cv.K, cv.Kc);
+    const size_t lds = general_kernel_lds_bytes(cv.K, cv.Kc, cv.tile_i != cv.tile_j);
     dim3 grid(n_blocks), block(kThreadsL2);
     if (want_gamma) {
         if (lin) hipLaunchKernelGGL((price_general_kernel<true, true, true, false>), grid, block, lds, stream, cv, tr, out);

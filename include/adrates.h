@@ -58,8 +58,12 @@ typedef enum adr_status {
 #define ADR_REQ_DELTA 2u
 #define ADR_REQ_GAMMA 4u
 
-/* Largest pillar count the kernels are built for (the ladders are padded to it on chip). */
-#define ADR_MAX_PILLARS 32
+/* Largest pillar count (the reference has none, cavour/market/position/engine.py:2388-2389).  Ladders live on chip
+ * in tiles of 32 pillars: curves of up to 32 pillars take the fast kernels; beyond that the general kernel prices each
+ * trade once per pair of tiles (3 launches for 33-64 pillars).  Odd pillar counts are served by the general kernel as
+ * well (the fast kernel stores the [P][P] matrices as 16-byte pairs).  The device curve builder
+ * (adr_curve_plan_create) takes at most 32 pillars. */
+#define ADR_MAX_PILLARS 64
 
 int adr_version(void);
 const char* adr_last_error(void);

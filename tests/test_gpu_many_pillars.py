@@ -1,0 +1,114 @@
+"""Curves with more than 32 pillars, and with an odd pillar count (the reference has no pillar limit,
+cavour/market/position/engine.py:2388-2389).  Ladders live on chip in tiles of 32 pillars: a 40-pillar curve is priced
+by the general kernel once per pair of tiles (include/adrates.h, ADR_MAX_PILLARS); a 17-pillar curve takes the
+general kernel for gamma (the fast kernel stores matrices as 16-byte pairs) and the lite kernel for delta."""
+import numpy as np
+import pytest
+
+from adrates_amd import _native
+from adrates_amd.trades import synthetic
+from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
+from adrates_amd.utils import (BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes, InterpTypes,
+                               RequestTypes)
+from oracle import port
+
+from . import _fixtures as F
+from ._parity import assert_batch_parity
+from .test_gpu_parity_batch import _device_curve
+
+pytestmark = pytest.mark.gpu
+
+EXTRA = ["11Y", "13Y", "14Y", "16Y", "17Y", "18Y", "19Y", "35Y"]
+
+
+def _years(tenor):
+    n, unit = int(tenor[:-1]), tenor[-1]
+    return n / {"D": 365.0, "W": 52.0, "M": 12.0, "Y": 1.0}[unit]
+
+
+def forty_pillar_quotes():
+    """The 32 README quotes plus eight more annual pillars, quoted off the neighbours (linear in maturity)."""
+    base_t = np.array([_years(t) for t in F.TENORS])
+    tenors = sorted(list(F.TENORS) + EXTRA, key=_years)
+    px = [float(np.interp(_years(t), base_t, F.GBP_PX)) if t in EXTRA else F.GBP_PX[F.TENORS.index(t)] for t in tenors]
+    return px, tenors
+
+
+def _mixed_batch(vd, n, seed):
+    rng = np.random.default_rng(seed)
+    terms = OISTerms(effective_dt=vd, tenor=[f"{int(m)}M" for m in rng.integers(1, 481, n)],
+                     coupon=rng.uniform(0.01, 0.07, n), notional=np.round(rng.uniform(1e6, 5e7, n), -5),
+                     pay_fixed=rng.random(n) < 0.5, fixed_freq_type=FrequencyTypes.ANNUAL, fixed_dc_type=DayCountTypes.ACT_365F,
+                     floating_index=CurveTypes.GBP_OIS_SONIA, currency=CurrencyTypes.GBP,
+                     float_freq_type=[[FrequencyTypes.ANNUAL, FrequencyTypes.SEMI_ANNUAL][i] for i in rng.integers(0, 2, n)],
+                     float_dc_type=DayCountTypes.ACT_365F, float_spread=np.where(rng.random(n) < 0.3, 0.0015, 0.0),
+                     payment_lag=rng.choice([0, 0, 2], size=n), bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
+    return compile_ois_terms(terms, vd)
+
+
+@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES, InterpTypes.LINEAR_FWD_RATES])
+def test_forty_pillar_curve_vs_c_oracle(gpu_ctx, interp):
+    vd = F.README_VALUE_DT
+    px, tenors = forty_pillar_quotes()
+    curve = F.gbp_model(vd, interp, px=px, tenors=tenors).curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    assert dc.n_pillars == 40
+    batch = _mixed_batch(vd, 3001, seed=12)
+    dt = _native.DeviceTrades(gpu_ctx, batch)
+    ref = port.price(interp.value, host.times, host.dfs, host.jac, host.hess, batch)
+    got = _native.price(gpu_ctx, dc, dt, aggregate=True)
+    assert got["delta"].shape == (3001, 40) and got["gamma"].shape == (3001, 40, 40)
+    worst = assert_batch_parity(got, ref, batch.notional)
+    asym = np.max(np.abs(got["gamma"] - np.swapaxes(got["gamma"], 1, 2)), axis=(1, 2))
+    assert np.all(asym <= 1e-12 * np.max(np.abs(got["gamma"]), axis=(1, 2)) + 1e-14)     # mirrored tiles / blocks, rounding inside diagonal blocks
+    assert np.any(got["gamma"][:, :32, 32:] != 0.0)                       # the off-diagonal tile pair carries weight
+    assert np.allclose(got["agg_pv"], ref["pv"].sum(), rtol=1e-10, atol=1e-3)
+    assert np.allclose(got["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
+    assert np.allclose(got["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+    only_d = _native.price(gpu_ctx, dc, dt, want_gamma=False, aggregate=True)
+    assert_batch_parity(only_d, dict(pv=ref["pv"], delta=ref["delta"]), batch.notional)
+    assert np.allclose(only_d["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6) and np.all(only_d["agg_gamma"] == 0.0)
+    only_v = _native.price(gpu_ctx, dc, dt, want_delta=False, want_gamma=False)
+    assert_batch_parity(only_v, dict(pv=ref["pv"]), batch.notional)
+    dt.close()
+    print(f"40 pillars, {interp.name}: worst error {worst:.2e}")
+
+
+def test_forty_pillar_curve_through_the_public_api(gpu_ctx):
+    vd = F.README_VALUE_DT
+    px, tenors = forty_pillar_quotes()
+    model = F.gbp_model(vd, px=px, tenors=tenors)
+    swap = F.make_swap(vd, "33Y", 0.041, 2e7)
+    res = swap.position(model).compute([RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA])
+    assert len(res.risk.risk_ladder) == 40 and res.gamma.risk_ladder.shape == (40, 40)
+    assert res.risk.ladder.data["35Y"] != 0.0 and res.risk.ladder.data["40Y"] == 0.0
+    bumped = swap.position(model.scenario("GBP_OIS_SONIA", 0.01)).compute([RequestTypes.VALUE]).value.amount
+    down = swap.position(model.scenario("GBP_OIS_SONIA", -0.01)).compute([RequestTypes.VALUE]).value.amount
+    assert abs(res.risk.value.amount - (bumped - down) / 2.0) / abs(res.risk.value.amount) < 1e-4     # the reference's tolerance at 1 bp
+    # every calibration swap of the 40-pillar curve reprices through the engine grid
+    for tenor, p in zip(tenors, px):
+        v = F.make_swap(vd, tenor, p / 100, 1e6).position(model).compute([RequestTypes.VALUE]).value.amount
+        assert abs(v) <= 1e-5, (tenor, v)
+    with pytest.raises(Exception, match="64|pillar"):
+        big_t = [f"{k}M" for k in range(1, 13)] + [f"{k}Y" for k in range(2, 60)]      # 70 pillars
+        big = F.gbp_model(vd, px=[4.0 + 0.001 * i for i in range(len(big_t))], tenors=big_t)
+        F.make_swap(vd, "5Y", 0.04).position(big).compute([RequestTypes.VALUE])
+
+
+def test_seventeen_pillar_curve_all_requests(gpu_ctx):
+    """Odd pillar count inside the library: gamma on the general kernel, delta on the lite kernel, same numbers."""
+    vd = F.README_VALUE_DT
+    px, tenors = list(F.GBP_PX[8:9] + F.GBP_PX[14:30]), list(F.TENORS[8:9] + F.TENORS[14:30])      # 6M, 1Y ... 30Y
+    curve = F.gbp_model(px=px, tenors=tenors).curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    assert dc.n_pillars == 17
+    batch = synthetic.synthesize(vd, 4001, seed=3)
+    dt = _native.DeviceTrades(gpu_ctx, batch)
+    ref = port.price(4, host.times, host.dfs, host.jac, host.hess, batch)
+    got = _native.price(gpu_ctx, dc, dt, aggregate=True)
+    assert got["gamma"].shape == (4001, 17, 17)
+    assert_batch_parity(got, ref, batch.notional)
+    assert np.allclose(got["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+    only_d = _native.price(gpu_ctx, dc, dt, want_gamma=False)
+    assert_batch_parity(only_d, dict(pv=ref["pv"], delta=ref["delta"]), batch.notional)
+    dt.close()
