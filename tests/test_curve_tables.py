@@ -82,7 +82,7 @@ def test_native_table_argument_checks(native_lib):
     with pytest.raises(LibError):
         _native.curve_tables_host(good["times"], np.array([1.0, -0.1, 0.9]), good["jac"])    # DF <= 0
     with pytest.raises(LibError):
-        _native.curve_tables_host(good["times"], good["dfs"], np.zeros((3, 40)))             # too many pillars
+        _native.curve_tables_host(good["times"], good["dfs"], np.zeros((3, 70)))             # too many pillars (64 at most)
     with pytest.raises(LibError, match="value time"):
         _native.curve_tables_host(np.array([0.5, 1.0, 2.0]), good["dfs"], good["jac"])       # grid not anchored at t = 0
     with pytest.raises(LibError, match="value time"):
@@ -108,3 +108,23 @@ def test_curves_without_a_core_are_left_to_the_general_kernel(native_lib):
         h = build_engine_curve([0.04 + 0.001 * i for i in range(n)], [float(i + 1) for i in range(n)],
                                [[1.0] * (i + 1) for i in range(n)])
         assert _native.curve_layout_host(h.times, h.dfs, h.jac, h.hess)["packed_ok"] == want
+
+
+def test_more_than_32_pillars_are_tiled(native_lib):
+    """Curves of 33-64 pillars: the host tables come in pillar tiles of 32 (curve_tables.hpp); through the plain-layout
+    accessor they are the same log-space tables, LJ = J / d and LC = C / d - LJ LJ^T, for every pillar."""
+    rng = np.random.default_rng(4)
+    K, P = 9, 40
+    times = np.concatenate(([0.0], np.sort(rng.uniform(0.1, 30.0, K - 1))))
+    dfs = np.concatenate(([1.0], np.exp(-0.03 * times[1:])))
+    jac = np.vstack((np.zeros((1, P)), rng.normal(0, 1, (K - 1, P))))
+    hess = rng.normal(0, 1, (K, P, P))
+    hess = hess + np.swapaxes(hess, 1, 2)
+    hess[0] = 0.0
+    t = _native.curve_tables_host(times, dfs, jac, hess)
+    idx = t["knot_index"]
+    lj = jac[idx] / dfs[idx, None]
+    assert np.array_equal(t["lj"], lj)
+    assert np.allclose(t["lc"], hess[idx] / dfs[idx, None, None] - lj[:, :, None] * lj[:, None, :], rtol=0, atol=1e-15)
+    info = _native.curve_layout_host(times, dfs, jac, hess)
+    assert info["packed_ok"] == 0            # the packed layout of the fast kernels is for one tile
