@@ -75,3 +75,37 @@ def test_autodiff_oracle_agrees_with_high_precision_differences(case):
     assert np.any(want != 0.0) and len([1 for p, q in pairs if p != q and g[p, q] != 0.0]) >= 3
     for p in dead:
         assert got[(min(p, live[0]), max(p, live[0]))] == 0.0 and np.all(g[p] == 0.0)
+
+
+def test_cross_currency_autodiff_oracle_agrees_with_high_precision_differences():
+    """oracle/xccy_oracle.py - the XCCY curve's scan and `Engine._compute_xccy` differentiated with torch.func - against
+    the same PV restated in 60-digit arithmetic as a function of the three quote vectors and differenced
+    (oracle/mp_oracle.py::MpXccy): PV, entries of the three delta ladders, of the three gamma matrices and of the
+    foreign-rate x basis cross term, on a seasoned semi-annual swap with payment lags."""
+    from adrates_amd.market.curves.curve_tables import build_engine_curve
+    from adrates_amd.utils import CurveTypes
+    from oracle import xccy_oracle as XO
+    from tests.test_gpu_xccy import VALUE_DT, _model, _swap
+    from tests.test_xccy_curve import _basis_swaps
+    m = _model()
+    gbp, usd, x = m.curves.GBP_OIS_SONIA, m.curves.USD_OIS_SOFR, m.curves.USD_GBP_BASIS
+    swap = _swap("6Y", 0.0041, lag=2, effective=VALUE_DT.add_months(-8), freq=FrequencyTypes.SEMI_ANNUAL, notional=5_000_000)
+    cache = lambda c: (lambda h: dict(times=h.times, dfs=h.dfs, jac=h.jac, hess=h.hess))(build_engine_curve(c.swap_rates, c.swap_times, c.year_fracs))
+    ad = XO.xccy_analytics(swap, VALUE_DT, cache(gbp), gbp._interp_type.value, cache(usd), usd._interp_type.value, x, times_from_dates)
+    third = MP.MpXccy(swap, VALUE_DT, gbp, usd, x, _basis_swaps(), times_from_dates)
+    n = abs(swap._domestic_leg._notional)
+    # the XCCY knot DFs of the 60-digit scan are the curve's
+    assert np.allclose([float(d) for d in third.xccy_dfs(third.spreads)], np.asarray(x._dfs), rtol=1e-13, atol=0)
+    assert abs(third.value() - ad["value"]) <= TOL * max(abs(ad["value"]), 1e-4 * n)
+    for which, key, pillars in (("dom", "delta_dom", (1, 4, 6)), ("for", "delta_for", (0, 3, 5, 6)), ("basis", "delta_basis", (2, 5, 6))):
+        got = third.delta(which, pillars)
+        scale = max(np.max(np.abs(ad[key])), 1e-8 * n)
+        for p in pillars:
+            assert abs(got[p] - ad[key][p]) <= TOL * scale, (key, p, got[p], ad[key][p])
+    for (a, p, b, q), key in ((("for", 5, "for", 5), "gamma_for"), (("for", 3, "for", 5), "gamma_for"),
+                               (("basis", 5, "basis", 5), "gamma_basis"), (("basis", 2, "basis", 6), "gamma_basis"),
+                               (("dom", 4, "dom", 6), "gamma_dom"), (("for", 5, "basis", 5), "cross_for_basis"),
+                               (("for", 3, "basis", 6), "cross_for_basis")):
+        want = ad[key][p, q]
+        scale = max(np.max(np.abs(ad[key])), 1e-12 * n)
+        assert abs(third.second(a, p, b, q) - want) <= 1e-11 * scale, (key, p, q, third.second(a, p, b, q), want)

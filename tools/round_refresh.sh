@@ -9,7 +9,10 @@ tail -1 gpurun_out/gpu_tests_$TAG.log
 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err || exit 1
 python bench.py --kind ongrid --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_ongrid.json 2>/dev/null || exit 1
 python bench.py --interp FLAT_FWD_RATES --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_flatfwd.json 2>/dev/null || exit 1
+python bench.py --interp LINEAR_FWD_RATES --trades 200000 --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_linfwd_200k.json 2>/dev/null || exit 1
 python bench.py --trades 100000 --requests value,delta --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_config2_delta_100k.json 2>/dev/null || exit 1
+python bench.py --trades 1000000 --requests value,delta --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_delta_1m.json 2>/dev/null || exit 1
+python bench.py --trades 1000000 --requests value --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_value_1m.json 2>/dev/null || exit 1
 python tools/ablate.py > gpurun_out/ablate_$TAG.log 2>&1 || exit 1
 python tools/bench_long_legs.py > gpurun_out/bench_${TAG}_long_legs.json 2>/dev/null || exit 1
 python tools/bench_curve_build.py > gpurun_out/bench_${TAG}_curve_build.json 2>/dev/null || exit 1
