@@ -32,6 +32,7 @@ DESIGN.md section 9.
 """
 from __future__ import annotations
 
+import dataclasses
 from dataclasses import dataclass
 
 import numpy as np
@@ -39,8 +40,10 @@ import numpy as np
 from ... import _native
 from ...requests.results import AnalyticsResult, CrossGamma, Delta, Gamma, Risk, Valuation
 from ...trades.compiler import TradeBatch
+from ...utils.day_count import DayCountTypes
 from ...utils.error import LibError
 from ...utils.global_types import CurveTypes, InterpTypes, RequestTypes, SwapTypes
+from ...utils.global_vars import gDaysInYear
 from ...utils.helpers import times_from_dates, to_tenor
 
 
@@ -121,53 +124,141 @@ class XccyTerms:
     foreign_payment_lag: object = 0
 
 
-def raw_from_terms(terms: XccyTerms, value_dt, xdc) -> RawXccy:
-    """`RawXccy` of swaps given by their terms, without per-swap objects: one template swap per distinct combination
-    of schedule-defining terms (dates, frequencies, day counts, lags), per-swap arrays gathered with NumPy - the
-    cross-currency counterpart of `trades.compiler.compile_ois_terms`."""
-    from ...trades.compiler import _column
+_FIXED_DENOMINATOR = {DayCountTypes.ACT_365F: 365, DayCountTypes.ACT_360: 360, DayCountTypes.SIMPLE: gDaysInYear}
+
+
+def _concat_raw(parts) -> RawXccy:
+    out = {}
+    for f in dataclasses.fields(RawXccy):
+        cols = [getattr(p, f.name) for p in parts]
+        if f.name in ("dom_off", "for_off"):
+            ends = np.cumsum([c[-1] for c in cols])
+            cols = [cols[0]] + [c[1:] + e for c, e in zip(cols[1:], ends[:-1])]
+        out[f.name] = np.concatenate(cols)
+    return RawXccy(**out)
+
+
+def _take_raw(raw: RawXccy, pick) -> RawXccy:
+    """Swaps ``pick`` of ``raw``, in that order."""
+    out = {f.name: getattr(raw, f.name)[pick] for f in dataclasses.fields(RawXccy)
+           if f.name[4:] not in ("off", "tp", "tpx", "ts", "te", "al")}
+    for side, cols in (("dom", ("dom_tp", "dom_ts", "dom_te", "dom_al")), ("for", ("for_tpx", "for_ts", "for_te", "for_al"))):
+        src = getattr(raw, side + "_off")
+        lens = (src[1:] - src[:-1])[pick]
+        off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+        idx = np.repeat(src[:-1][pick] - off[:-1], lens) + np.arange(off[-1])
+        out[side + "_off"] = off
+        for c in cols:
+            out[c] = getattr(raw, c)[idx]
+    return RawXccy(**out)
+
+
+def _slice_columns(cols, pick):
+    return {k: ((v[0][pick], v[1]) if isinstance(v, tuple) else v[pick]) for k, v in cols.items()}
+
+
+def _raw_by_templates(cols, singles, value_dt, xdc) -> RawXccy:
+    """One template swap object per distinct combination of schedule-defining terms, per-swap arrays gathered with
+    NumPy (the route of `trades.compiler.compile_ois_terms`)."""
     from ...trades.rates.xccy_basis_swap import XccyBasisSwap
     from ...utils.date import Date
-    dom_n = np.asarray(terms.domestic_notional, dtype=np.float64).reshape(-1)
-    n = dom_n.shape[0]
-    col = lambda v, kind: _column(v, n, kind)
-    eff = col(terms.effective_dt, "date")
-    dlag, flag = col(terms.domestic_payment_lag, "int"), col(terms.foreign_payment_lag, "int")
-    coded = {k: col(v, "code") for k, v in (("tenor", terms.tenor), ("dfreq", terms.domestic_freq_type),
-                                             ("ffreq", terms.foreign_freq_type), ("ddc", terms.domestic_dc_type),
-                                             ("fdc", terms.foreign_dc_type))}
-    keys, inverse = np.unique(np.stack([eff, dlag, flag] + [coded[k][0] for k in coded], axis=1), axis=0, return_inverse=True)
+    names = ("tenor", "dfreq", "ffreq", "ddc", "fdc")
+    keys, inverse = np.unique(np.stack([cols["eff"], cols["dlag"], cols["flag"]] + [cols[k][0] for k in names], axis=1),
+                              axis=0, return_inverse=True)
     inverse = inverse.reshape(-1)
-    one = lambda v: v[0] if isinstance(v, (list, tuple, np.ndarray)) else v
-    names = list(coded)
     templates = []
     for row in keys:
-        kw = {k: coded[k][1][int(row[3 + j])] for j, k in enumerate(names)}
+        kw = {k: cols[k][1][int(row[3 + j])] for j, k in enumerate(names)}
         swap = XccyBasisSwap(effective_dt=Date._from_serial(int(row[0])), term_dt_or_tenor=kw["tenor"],
                              domestic_notional=1.0, foreign_notional=1.0, domestic_spread=0.0, foreign_spread=0.0,
                              domestic_freq_type=kw["dfreq"], foreign_freq_type=kw["ffreq"], domestic_dc_type=kw["ddc"],
-                             foreign_dc_type=kw["fdc"], domestic_floating_index=one(terms.domestic_floating_index),
-                             foreign_floating_index=one(terms.foreign_floating_index),
-                             domestic_currency=one(terms.domestic_currency), foreign_currency=one(terms.foreign_currency),
-                             domestic_payment_lag=int(row[1]), foreign_payment_lag=int(row[2]))
+                             foreign_dc_type=kw["fdc"], domestic_floating_index=singles["dindex"],
+                             foreign_floating_index=singles["findex"], domestic_currency=singles["dccy"],
+                             foreign_currency=singles["fccy"], domestic_payment_lag=int(row[1]),
+                             foreign_payment_lag=int(row[2]))
         templates.append(raw_from_swaps([swap], value_dt, xdc))
+    raw = _take_raw(_concat_raw(templates), inverse)
+    raw.dom_n, raw.for_n = cols["dom_n"].copy(), cols["for_n"].copy()
+    raw.dom_spread, raw.for_spread = cols["dspread"].copy(), cols["fspread"].copy()
+    return raw
 
-    def gather(off_name, fields):
-        counts = np.array([int(getattr(t, off_name)[1]) for t in templates], dtype=np.int64)
-        lens = counts[inverse]
-        off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
-        starts = np.concatenate(([0], np.cumsum(counts)))[:-1]
-        idx = np.repeat(starts[inverse] - off[:-1], lens) + np.arange(off[-1])
-        return off, [np.concatenate([getattr(t, f) for t in templates])[idx] for f in fields]
 
-    d_off, (dtp, dts, dte, dal) = gather("dom_off", ("dom_tp", "dom_ts", "dom_te", "dom_al"))
-    f_off, (ftp, fts, fte, fal) = gather("for_off", ("for_tpx", "for_ts", "for_te", "for_al"))
-    d_ex = np.concatenate([t.dom_exch_t for t in templates])[inverse]
-    f_ex = np.concatenate([t.for_exch_t for t in templates])[inverse]
+def _raw_by_arrays(cols, value_serial, xdc) -> RawXccy:
+    """The same without any per-swap or per-schedule Python: `utils.schedule_np` on the whole book.  Returns the
+    `RawXccy` and the mask of swaps whose two schedules are plain (see `schedule_np.backward_schedules`)."""
+    from ...utils import schedule_np as S
+    from ...utils.calendar import BusDayAdjustTypes
+    from ...utils.frequency import annual_frequency
+    bd = BusDayAdjustTypes.FOLLOWING                        # XccyBasisSwap's defaults: WEEKEND calendar, FOLLOWING, BACKWARD
+    eff = cols["eff"]
+    count, unit = S.parse_tenors(cols["tenor"][1])
+    code = cols["tenor"][0]
+    term = S.add_tenor(eff, count[code], unit[code])
+    maturity = S.adjust(term, bd)
+    if (eff > maturity).any():
+        raise LibError("Start date after maturity date")
+    den = lambda key: np.array([_FIXED_DENOMINATOR.get(d, 0) for d in cols[key][1]])[cols[key][0]]   # (0: not in this slice)
+    mpp = lambda key: np.array([int(12 / annual_frequency(f)) for f in cols[key][1]], dtype=np.int64)[cols[key][0]]
+    xden = _FIXED_DENOMINATOR[xdc]
+
+    def leg(freq_key, dc_key, lag, pay_den):
+        off, dts, plain = S.backward_schedules(eff, term, mpp(freq_key), bd)
+        n_dates = off[1:] - off[:-1]
+        is_start = np.ones(off[-1], dtype=bool); is_start[off[1:] - 1] = False
+        is_end = np.ones(off[-1], dtype=bool); is_end[off[:-1]] = False
+        start, end = dts[is_start], dts[is_end]
+        lens = n_dates - 1
+        pay = S.add_business_days(end, np.repeat(lag, lens))
+        d = np.repeat(den(dc_key), lens)
+        t = lambda x, dd: (x - value_serial) / dd
+        return (np.concatenate(([0], np.cumsum(lens))).astype(np.int64), t(pay, d if pay_den is None else pay_den), t(start, d),
+                t(end, d), (end - start) / d, plain)
+
+    d_off, dtp, dts_, dte, dal, d_plain = leg("dfreq", "ddc", cols["dlag"], None)
+    f_off, ftp, fts, fte, fal, f_plain = leg("ffreq", "fdc", cols["flag"], xden)
+    two = np.stack([eff, maturity], axis=1) - value_serial
+    n = eff.shape[0]
     yes = np.ones(n, dtype=bool)
-    return RawXccy(d_off, dtp, dts, dte, dal, f_off, ftp, fts, fte, fal, d_ex, f_ex, yes, yes,
-                   dom_n.copy(), col(terms.foreign_notional, "float"), col(terms.domestic_spread, "float"),
-                   col(terms.foreign_spread, "float"), np.ones(n), -np.ones(n))     # domestic received, foreign paid
+    raw = RawXccy(d_off, dtp, dts_, dte, dal, f_off, ftp, fts, fte, fal, two / den("ddc")[:, None], two / xden, yes, yes.copy(),
+                  cols["dom_n"].copy(), cols["for_n"].copy(), cols["dspread"].copy(), cols["fspread"].copy(),
+                  np.ones(n), -np.ones(n))                 # domestic received, foreign paid (xccy_basis_swap.py:150-168)
+    return raw, d_plain & f_plain
+
+
+def raw_from_terms(terms: XccyTerms, value_dt, xdc) -> RawXccy:
+    """`RawXccy` of swaps given by their terms, without per-swap objects - the cross-currency counterpart of
+    `trades.compiler.compile_ois_terms`.  Schedules, payment lags and year fractions
+    are computed on arrays for the whole book (`utils.schedule_np`); swaps on a day count without a fixed
+    denominator, or whose schedule needs the reference's de-duplication, go through one template object per
+    distinct schedule instead."""
+    from ...trades.compiler import _column
+    dom_n = np.asarray(terms.domestic_notional, dtype=np.float64).reshape(-1)
+    n = dom_n.shape[0]
+    col = lambda v, kind: _column(v, n, kind)
+    one = lambda v: v[0] if isinstance(v, (list, tuple, np.ndarray)) else v
+    cols = {"eff": col(terms.effective_dt, "date"), "dlag": col(terms.domestic_payment_lag, "int"),
+            "flag": col(terms.foreign_payment_lag, "int"), "tenor": col(terms.tenor, "code"),
+            "dfreq": col(terms.domestic_freq_type, "code"), "ffreq": col(terms.foreign_freq_type, "code"),
+            "ddc": col(terms.domestic_dc_type, "code"), "fdc": col(terms.foreign_dc_type, "code"),
+            "dom_n": dom_n, "for_n": col(terms.foreign_notional, "float"),
+            "dspread": col(terms.domestic_spread, "float"), "fspread": col(terms.foreign_spread, "float")}
+    singles = {"dindex": one(terms.domestic_floating_index), "findex": one(terms.foreign_floating_index),
+               "dccy": one(terms.domestic_currency), "fccy": one(terms.foreign_currency)}
+    fixed = lambda key: np.array([d in _FIXED_DENOMINATOR for d in cols[key][1]], dtype=bool)[cols[key][0]]
+    by_arrays = fixed("ddc") & fixed("fdc") if xdc in _FIXED_DENOMINATOR else np.zeros(n, dtype=bool)
+    if not by_arrays.any():
+        return _raw_by_templates(cols, singles, value_dt, xdc)
+    pick = np.nonzero(by_arrays)[0]
+    raw, plain = _raw_by_arrays(_slice_columns(cols, pick) if pick.size < n else cols, int(value_dt.excel_dt()), xdc)
+    if pick.size == n and plain.all():
+        return raw
+    by_arrays[pick[~plain]] = False
+    rest = np.nonzero(~by_arrays)[0]
+    slow = _raw_by_templates(_slice_columns(cols, rest), singles, value_dt, xdc)
+    fast = _take_raw(raw, np.nonzero(plain)[0])
+    order = np.empty(n, dtype=np.int64)
+    order[np.concatenate((np.nonzero(by_arrays)[0], rest))] = np.arange(n)
+    return _take_raw(_concat_raw([fast, slow]), order)
 
 
 def _exchange_flows(t2, notional, on, sign, scale):

@@ -119,7 +119,8 @@ class OISTerms:
 
 def _column(value, n, kind):
     """Broadcast a scalar or validate a sequence; enums/dates become small integers for `numpy.unique`."""
-    seq = isinstance(value, (list, tuple, np.ndarray))
+    coded = kind == "code" and isinstance(value, tuple) and len(value) == 2 and isinstance(value[0], np.ndarray)
+    seq = isinstance(value, (list, tuple, np.ndarray)) and not coded
     if seq and len(value) != n:
         raise LibError("OISTerms: every per-trade sequence must have one entry per trade")
     if kind == "float":
@@ -132,7 +133,12 @@ def _column(value, n, kind):
         if seq:
             return np.array([v if isinstance(v, (int, np.integer)) else int(v.excel_dt()) for v in value], dtype=np.int64)
         return np.full(n, value if isinstance(value, (int, np.integer)) else int(value.excel_dt()), dtype=np.int64)
-    # enums and strings: codes into a table of distinct objects
+    # enums and strings: codes into a table of distinct objects (or given that way: ``(codes array, table)``)
+    if isinstance(value, tuple) and len(value) == 2 and isinstance(value[0], np.ndarray) and isinstance(value[1], (list, tuple)):
+        codes = np.asarray(value[0], dtype=np.int64)
+        if codes.shape != (n,) or (codes.size and (codes.min() < 0 or codes.max() >= len(value[1]))):
+            raise LibError("OISTerms: a coded column needs one valid code per trade")
+        return codes, list(value[1])
     items = list(value) if seq else [value]
     table, codes = [], np.empty(len(items), dtype=np.int64)
     index = {}

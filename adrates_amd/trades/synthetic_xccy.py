@@ -87,14 +87,15 @@ def draw_terms(value_dt, n, seed=20240430):
     semi = rng.random(n) < 0.5
     for_n = np.round(rng.uniform(1e6, 5e7, n), -5)
     eff_of = {int(b): int(value_dt.add_months(-int(b)).excel_dt()) for b in (0, 4, 9)}
-    tenor_of = {int(m): f"{int(m)}M" for m in np.unique(months + back)}
+    total = months + back
+    tenor_months = np.unique(total)
     terms = XccyTerms(effective_dt=np.array([eff_of[int(b)] for b in back], dtype=np.int64),
-                      tenor=[tenor_of[int(m)] for m in months + back],
+                      tenor=(np.searchsorted(tenor_months, total), [f"{int(m)}M" for m in tenor_months]),
                       domestic_notional=SPOT * for_n, foreign_notional=for_n,
                       domestic_spread=np.round(rng.uniform(0.0, 0.0005, n), 6),
                       foreign_spread=np.round(rng.uniform(0.0010, 0.0060, n), 6),
                       domestic_freq_type=FrequencyTypes.ANNUAL,
-                      foreign_freq_type=[FrequencyTypes.SEMI_ANNUAL if x else FrequencyTypes.ANNUAL for x in semi],
+                      foreign_freq_type=(semi.astype(np.int64), [FrequencyTypes.ANNUAL, FrequencyTypes.SEMI_ANNUAL]),
                       domestic_dc_type=DayCountTypes.ACT_365F, foreign_dc_type=DayCountTypes.ACT_360,
                       domestic_floating_index=CurveTypes.GBP_OIS_SONIA, foreign_floating_index=CurveTypes.USD_OIS_SOFR,
                       domestic_currency=CurrencyTypes.GBP, foreign_currency=CurrencyTypes.USD)
@@ -106,7 +107,9 @@ def slice_terms(terms, lo, hi):
     """Swaps lo..hi-1 of an `XccyTerms` (per-swap sequences are cut, scalars kept)."""
     import dataclasses
     n = len(np.asarray(terms.domestic_notional).reshape(-1))
-    cut = lambda v: v[lo:hi] if isinstance(v, (list, tuple, np.ndarray)) and len(v) == n else v
+    coded = lambda v: isinstance(v, tuple) and len(v) == 2 and isinstance(v[0], np.ndarray)     # (codes, table) columns
+    cut = lambda v: ((v[0][lo:hi], v[1]) if coded(v) else
+                     v[lo:hi] if isinstance(v, (list, tuple, np.ndarray)) and len(v) == n else v)
     return dataclasses.replace(terms, **{f.name: cut(getattr(terms, f.name)) for f in dataclasses.fields(terms)})
 
 

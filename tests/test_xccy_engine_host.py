@@ -268,7 +268,7 @@ def check_matured_and_maturing(m):
 
 
 def test_terms_compiler_equals_the_object_path_and_the_book_is_distinct(host_engine):
-    """`xccy_engine.raw_from_terms` (one template per distinct schedule, NumPy gathers) gives, bit for bit, the arrays
+    """`xccy_engine.raw_from_terms` (schedules on arrays, `utils.schedule_np`) gives, bit for bit, the arrays
     `raw_from_swaps` builds from the corresponding `XccyBasisSwap` objects; a synthetic book (trades/synthetic_xccy.py)
     is reproducible, every swap in it is its own, and rank shares of one book tile it."""
     import dataclasses
@@ -281,10 +281,11 @@ def test_terms_compiler_equals_the_object_path_and_the_book_is_distinct(host_eng
     xdc = m.curves.USD_GBP_BASIS._dc_type
     terms, work = SX.draw_terms(README_VALUE_DT, 300, seed=3)
     fast = xccy_engine.raw_from_terms(terms, README_VALUE_DT, xdc)
-    swaps = [XccyBasisSwap(effective_dt=Date._from_serial(int(terms.effective_dt[i])), term_dt_or_tenor=terms.tenor[i],
+    at = lambda col, i: col[1][int(col[0][i])]                       # (codes, table) columns
+    swaps = [XccyBasisSwap(effective_dt=Date._from_serial(int(terms.effective_dt[i])), term_dt_or_tenor=at(terms.tenor, i),
                            domestic_notional=float(terms.domestic_notional[i]), foreign_notional=float(terms.foreign_notional[i]),
                            domestic_spread=float(terms.domestic_spread[i]), foreign_spread=float(terms.foreign_spread[i]),
-                           domestic_freq_type=terms.domestic_freq_type, foreign_freq_type=terms.foreign_freq_type[i],
+                           domestic_freq_type=terms.domestic_freq_type, foreign_freq_type=at(terms.foreign_freq_type, i),
                            domestic_dc_type=terms.domestic_dc_type, foreign_dc_type=terms.foreign_dc_type,
                            domestic_floating_index=terms.domestic_floating_index,
                            foreign_floating_index=terms.foreign_floating_index, domestic_currency=terms.domestic_currency,
