@@ -296,7 +296,7 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     // the fast kernels store the [P][P] matrices as 16-byte pairs of the flat array: P must be even
     // LINEAR_FWD_RATES is linear in the knot DFs, not in their logs: only the general kernel carries the extra
     // Hessian term (kernels_general.hip, `Lookup`)
-    c->dev.packed_ok = (t.packed_ok && t.P % 2 == 0 && interp_method != ADR_INTERP_LINEAR_FWD_RATES) ? 1 : 0;
+    c->dev.packed_ok = (t.packed_ok && t.P % 2 == 0) ? 1 : 0;
     c->dev.Pc = t.Pc; c->dev.pc_pad = t.pc_pad; c->dev.Ec = t.Ec; c->dev.Eu = t.Eu; c->dev.epg = t.epg; c->dev.cpg = t.cpg; c->dev.hub = t.hub ? 1 : 0;
     c->dev.Kcore = t.Kcore; c->dev.n_mini = t.n_mini; c->dev.fringe_start = t.fringe_start;
     c->dev.ljc = d_ljc; c->dev.lcc = d_lcc; c->dev.mini = d_mini; c->dev.knot_class = d_class;
@@ -427,7 +427,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
 
     adr::CurveBuildPlanDev& d = plan->dev;
     d.K = K; d.P = P; d.Kc = t.Kc; d.acc = d_acc; d.pillar = d_pil; d.prev_idx = d_prev; d.knot_index = d_kidx;
-    d.packed_ok = (t.packed_ok && t.P % 2 == 0 && interp_method != ADR_INTERP_LINEAR_FWD_RATES) ? 1 : 0;   // as in adr_curve_upload
+    d.packed_ok = (t.packed_ok && t.P % 2 == 0) ? 1 : 0;   // as in adr_curve_upload
     d.Pc = t.Pc; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Kcore = t.Kcore; d.n_mini = t.n_mini;
     d.knot_class = d_class; d.core_pillars = d_core; d.lcc_pq = d_lccpq;
 
@@ -921,7 +921,9 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     const bool use_fast = curve->dev.packed_ok != 0;
     const bool use_lite = !want_gamma && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES && trades->lite.n_units > 0;
     adr::TradesDev fast = trades->dev, chained = trades->chained, general = trades->dev, lagged = trades->lagged;
-    const bool use_lag = want_gamma && use_fast && lagged.n_rows > 0 && ctx->lag_scratch != nullptr;
+    // (the payment-lag variant's ratio nodes are single exponentials: not under LINEAR_FWD_RATES, which go to the general kernel)
+    const bool use_lag = want_gamma && use_fast && lagged.n_rows > 0 && ctx->lag_scratch != nullptr &&
+                         curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
     if (!use_lag) lagged.n_rows = 0;
     if (use_lite) {
         fast.n_rows = 0;                                   // the lite table holds exactly the 32-slot row table's trades

@@ -10,12 +10,13 @@ namespace adr {
 
 struct Lookup {
     int ka, kb;        // compact knots
-    double ba, bb;     // D = exp(ba*L[ka] + bb*L[kb]); bb == 0: single knot
+    double ba, bb;     // D = exp(ba*L[ka] + bb*L[kb]) (LINEAR_FWD_RATES: D = ba*d[ka] + bb*d[kb]); bb == 0: single knot
 };
 
 // InterpolatorAd.simple_interpolate for one time (interpolator_ad.py:210-243) in weight form.
 // ``C`` exposes the search arrays (any address space): x[K], lut[n_lut][2], first_of[K], compact_of[K], inv_x[Kc],
-// and K, n_lut, method (1 FLAT_FWD_RATES, 4 LINEAR_ZERO_RATES; LINEAR_FWD_RATES lives in kernels_general.hip).
+// and K, n_lut, method (1 FLAT_FWD_RATES, 4 LINEAR_ZERO_RATES; 2 LINEAR_FWD_RATES gets the plain linear weights of
+// FLAT_FWD_RATES here and the caller applies them to the discount factors instead of their logarithms).
 // INV_DX: ``C`` also has inv_dx[K] (1 / (x[i] - x[i-1]), 0 where jnp.interp's dx guard applies) and the weight is a
 // multiplication instead of a division (a double-precision divide is about twenty vector instructions; the weight
 // differs from the divided one by an ulp at most, the discount factor by ~1e-16 relative).

@@ -53,6 +53,13 @@
 #include "curve_lookup.hpp"
 #include "kernels.hpp"
 
+// This file is compiled twice: as is, and from kernels_fast_lindf.hip with ADR_FAST_LINDF = 1 - the same kernels with the
+// LINEAR_FWD_RATES node arithmetic (see `lindf` in the kernel) compiled in, kept out of the log-linear instantiations
+// so that their register budget (3 waves per SIMD) is untouched.
+#ifndef ADR_FAST_LINDF
+#define ADR_FAST_LINDF 0
+#endif
+
 namespace adr {
 
 namespace {
@@ -64,7 +71,7 @@ constexpr int kBlockThreads = kFastThreads;
 #define ADR_OUT_PARTS 2
 #endif
 constexpr int kOutParts = ADR_OUT_PARTS;      // the 8 output bands of a trade are gathered in this many batches
-constexpr int kWavesPerBlock = kBlockThreads / 64;
+[[maybe_unused]] constexpr int kWavesPerBlock = kBlockThreads / 64;
 constexpr int kLagThreads = 512;              // block size of the payment-lag variant
 
 __device__ __forceinline__ double shfl_d(double x, int src) { return __shfl(x, src, 64); }
@@ -226,6 +233,12 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
     double* rec = slot;                           // node records, 4 doubles per lane
     double* vbuf = slot + kRecDoubles + g * kPillarPad;       // this group's v, 32 doubles
     const int P = cv.P;
+    // LINEAR_FWD_RATES interpolates the discount factor itself, D(t) = (1 - w) d_a + w d_b: a node is TWO single-knot
+    // exponentials.  Its record carries the two amounts {1, omega_a, omega_b, classes}; the first-order sum reads it as any
+    // other record (v = omega_a u_a + omega_b u_b), and in the second-order sum the amount of a knot multiplies that
+    // knot's u u^T + LC - the same coefficient the convexity row of the knot gets, so the rank-one update runs on the
+    // knot's Jacobian row with the (carried) convexity coefficient instead of on v
+    constexpr bool lindf = ADR_FAST_LINDF != 0;
     const int bi = lane >> 3, bj = lane & 7;
     const int zero_row = cv.Kcore;
     const int core_entries = GAMMA ? (cv.Ec + L - 1) / L : 0;   // slots i < this hold core pairs
@@ -516,8 +529,15 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                 ba = q.ba; bb = q.bb;
                 cls_a = c.knot_class[q.ka];
                 cls_b = bb != 0.0 ? c.knot_class[q.kb] : -2;
-                omega = qa * exp(fma(ba, c.log_df[q.ka], bb * c.log_df[q.kb]));
-                pv += omega;
+                if (!LAG && lindf) {
+                    ba = qa * ba * exp(c.log_df[q.ka]);
+                    bb = bb != 0.0 ? qa * bb * exp(c.log_df[q.kb]) : 0.0;
+                    pv += ba + bb;
+                    omega = 1.0;
+                } else {
+                    omega = qa * exp(fma(ba, c.log_df[q.ka], bb * c.log_df[q.kb]));
+                    pv += omega;
+                }
             }
             ADR_STAMP(2);   // lookup + exp
             if (!DELTA) continue;
@@ -623,10 +643,13 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                 // time is the left neighbour of the next), so the right-hand row is not read with its node: its weight
                 // is carried to the next node and joins that node's left-hand weight when the rows agree; a carried row
                 // that does not match is added on its own first.  Returns the left row's coefficient.
+                int flush_row = zero_row;        // LINEAR_FWD_RATES: a carried knot that did not match (see below)
+                double flush_w = 0.0;
                 auto convexity_coef = [&](double coef_a, double coef_b) {
                     if (__ballot(carry_row != zero_row && carry_row != ra)) {
                         const bool flush = carry_row != ra;
-                        lc_row_pass(flush ? carry_row : zero_row, flush ? carry_w : 0.0);
+                        if (!LAG && lindf) { flush_row = flush ? carry_row : zero_row; flush_w = flush ? carry_w : 0.0; }
+                        else lc_row_pass(flush ? carry_row : zero_row, flush ? carry_w : 0.0);
                         if (flush) { carry_row = zero_row; carry_w = 0.0; }
                     }
                     const double coa = coef_a + (carry_row == ra ? carry_w : 0.0);
@@ -635,13 +658,13 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                 };
                 // rank-one update om_r * vv vv^T through the group's LDS slot, with the left row's convexity term
                 // (coefficient coa) folded into the same batches of LDS reads when WITH_ROW
-                auto rank_one = [&](auto with_row, double om_r, const double (&vv_)[PPL], double coa) {
+                auto rank_one_row = [&](auto with_row, double om_r, const double (&vv_)[PPL], double coa, int row) {
                     constexpr bool WITH_ROW = decltype(with_row)::value;
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int k = 0; k < PPL; ++k) vbuf[l + L * k] = vv_[k];
                     wave_lds_sync();
-                    const double* rowa = c.lcc + __mul24(ra, c.ec_stride) + (HUB ? 0 : l);
+                    const double* rowa = c.lcc + __mul24(row, c.ec_stride) + (HUB ? 0 : l);
                     // All operands of a batch of entries are fetched before any of them is used: the scheduling barrier
                     // keeps the compiler from pairing each LDS read with its FMA (which would expose one LDS round trip
                     // per entry).
@@ -673,6 +696,17 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                };
+                auto rank_one = [&](auto with_row, double om_r, const double (&vv_)[PPL], double coa) {
+                    rank_one_row(with_row, om_r, vv_, coa, ra);
+                };
+                // LINEAR_FWD_RATES: amount w on core row `row` - w (u u^T + LC) with u the row's Jacobian entries
+                auto lindf_knot = [&](int row, double w) {
+                    double u[PPL];
+                    const double* lj = c.ljc + __mul24(row, c.pc_pad);
+#pragma unroll
+                    for (int k = 0; k < PPL; ++k) u[k] = lj[col[k]];
+                    rank_one_row(std::true_type{}, w, u, w, row);
                 };
                 auto stash_special = [&](const double (&vv_)[PPL], double om_r) {   // {v, omega} for the pairs without a packed entry
                     if (__ballot(is_special)) {
@@ -738,11 +772,28 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                     }
                     if (GAMMA) {
                         const double coa = convexity_coef(om_n * wa, om_n * wb);
-                        rank_one(std::true_type{}, om_n, v, coa);
+                        if (!LAG && lindf) {
+                            if (__ballot(flush_row != zero_row)) lindf_knot(flush_row, flush_w);
+                            rank_one(std::true_type{}, coa, ua, coa);            // knot a (core row, or a short-end knot's entries)
+                            if (__ballot(mini_b)) {                              // a short-end knot b is not carried
+                                rank_one(std::false_type{}, mini_b ? wb : 0.0, ub, 0.0);
+                                if (mini_b) carry_w = 0.0;
+                            }
+                        } else {
+                            rank_one(std::true_type{}, om_n, v, coa);
+                        }
                         mini_convexity(om_n * wa, om_n * wb);
                     }
                 }
-                if (!has_next) break;
+                if (!has_next) {
+                    // LINEAR_FWD_RATES: the knot still carried gets its u u^T + LC here (the flush behind the passes adds
+                    // convexity rows only)
+                    if (!LAG && GAMMA && lindf && __ballot(carry_row != zero_row)) {
+                        lindf_knot(carry_row, carry_w);
+                        carry_row = zero_row; carry_w = 0.0;
+                    }
+                    break;
+                }
             }
 
             ADR_STAMP(3);   // node consumption
@@ -932,6 +983,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
     }
 }
 
+#if !ADR_FAST_LINDF
 // Fixed-order sum of the block partials -> agg[1 + P + P*P]: one wavefront per output, lanes stride over
 // the blocks, then a fixed butterfly - the aggregate does not depend on scheduling.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* partials, int n_blocks, int P,
@@ -964,6 +1016,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* part
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) { agg[at] = s; if (mirror >= 0) agg[mirror] = s; }
 }
+
+#endif  // !ADR_FAST_LINDF
 
 constexpr int kGroups = 2;   // trades per wavefront: the row table has 64 / 2 = 32 slots per row
 
@@ -1007,6 +1061,38 @@ void collect_gamma_kernels(std::vector<const void*>& fns) {
 
 }  // namespace
 
+#if ADR_FAST_LINDF
+// The LINEAR_FWD_RATES build of the kernels above (no payment-lag variant: its ratio nodes are single exponentials).
+hipError_t launch_price_fast_lindf(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
+                                   bool want_gamma, int n_blocks, size_t lds, hipStream_t stream) {
+    if (tr.rows_lagged) return hipErrorInvalidValue;
+    KernelFn fn = tr.rows_chained ? pick_kernel<true>(cv, want_delta, want_gamma, out.gamma != nullptr)
+                                  : pick_kernel<false>(cv, want_delta, want_gamma, out.gamma != nullptr);
+    hipLaunchKernelGGL(fn, dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out);
+    return hipGetLastError();
+}
+
+hipError_t set_fast_lindf_lds_limit(size_t bytes) {
+    std::vector<const void*> fns;
+    collect_gamma_kernels<true, false, false>(fns);
+    collect_gamma_kernels<false, false, false>(fns);
+    collect_gamma_kernels<true, true, false>(fns);
+    collect_gamma_kernels<false, true, false>(fns);
+    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<true, false, false, false, false, 1, 1, kGroups>));
+    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<false, false, false, false, false, 1, 1, kGroups>));
+    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<true, false, false, true, false, 1, 1, kGroups>));
+    fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<false, false, false, true, false, 1, 1, kGroups>));
+    for (const void* f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+#else
+hipError_t launch_price_fast_lindf(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
+                                   bool want_gamma, int n_blocks, size_t lds, hipStream_t stream);
+hipError_t set_fast_lindf_lds_limit(size_t bytes);
+
 int fast_kernel_groups() { return kGroups; }
 
 size_t fast_kernel_lag_scratch_bytes(int n_blocks) {
@@ -1032,6 +1118,7 @@ size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma, bool lagged) {
 hipError_t launch_price_fast(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                              bool want_gamma, int n_blocks, hipStream_t stream) {
     const size_t lds = fast_kernel_lds_bytes(cv, want_gamma, tr.rows_lagged != 0);
+    if (cv.method == 2) return launch_price_fast_lindf(cv, tr, out, want_delta, want_gamma, n_blocks, lds, stream);
     KernelFn fn;
     if (tr.rows_lagged) {
         if (!want_gamma) return hipErrorInvalidValue;        // the payment-lag rows exist for gamma requests only
@@ -1059,6 +1146,8 @@ hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes) {
     if (e != hipSuccess) return e;
     e = set_lite_kernel_lds_limit(fast_bytes);
     if (e != hipSuccess) return e;
+    e = set_fast_lindf_lds_limit(fast_bytes);
+    if (e != hipSuccess) return e;
     std::vector<const void*> fns;
     collect_gamma_kernels<true, false, false>(fns);
     collect_gamma_kernels<false, false, false>(fns);
@@ -1076,5 +1165,6 @@ hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes) {
     }
     return hipSuccess;
 }
+#endif  // ADR_FAST_LINDF
 
 }  // namespace adr

@@ -37,7 +37,7 @@ def _check(ctx, dc, host, method, batch, label):
 @pytest.mark.parametrize("kind", ["offgrid", "ongrid"])
 def test_benchmark_portfolio_value_and_delta(gpu_ctx, interp, kind):
     """The benchmark portfolio: 1-30 annual coupons, i.e. one- and two-row trades; odd trade counts leave groups of
-    the last wavefront empty.  LINEAR_FWD_RATES is not the lite kernel's (general kernel): same checks."""
+    the last wavefront empty.  LINEAR_FWD_RATES is not the lite kernel's (the fast kernels built for it, kernels_fast_lindf.hip): same checks."""
     vd = F.README_VALUE_DT
     curve = F.gbp_model(vd, interp).curves.GBP_OIS_SONIA
     host, dc = _device_curve(gpu_ctx, curve)

@@ -30,6 +30,6 @@ nw = 256 * 8
 buf = np.zeros((nw, 8), dtype=np.uint64)
 lib.adr_debug_stamps(ctx._h, buf.ctypes.data_as(C.c_void_p), nw)
 tot = buf.sum(0).astype(float)
-names = ["input wait", "folding", "lookup+exp (chunk build)", "node consumption", "outputs", "-"]
+names = ["input wait", "folding", "lookup+exp (chunk build)", "node consumption (rest)", "outputs", "walk: record + Jacobian rows", "walk, date record: v, sums", "walk, date record: rank-one x2"]
 print("cycles per wave:", int(buf.sum(1).mean()))
-for nm, v in zip(names, tot[:6]): print(f"   {nm:26s} {100 * v / tot.sum():5.1f} %")
+for nm, v in zip(names, tot[:8]): print(f"   {nm:26s} {100 * v / tot.sum():5.1f} %")
