@@ -67,10 +67,10 @@ def test_terms_book_against_the_autodiff_restatement(gpu_ctx):
     out = XE.price_xccy_batch(Engine(m), terms, {RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA})
     gbp, usd, x = m.curves.GBP_OIS_SONIA, m.curves.USD_OIS_SOFR, m.curves.USD_GBP_BASIS
     for i in (0, 57, 133, 262, 399):
-        swap = XccyBasisSwap(effective_dt=Date._from_serial(int(terms.effective_dt[i])), term_dt_or_tenor=terms.tenor[i],
+        swap = XccyBasisSwap(effective_dt=Date._from_serial(int(terms.effective_dt[i])), term_dt_or_tenor=terms.tenor[1][int(terms.tenor[0][i])],
                              domestic_notional=float(terms.domestic_notional[i]), foreign_notional=float(terms.foreign_notional[i]),
                              domestic_spread=float(terms.domestic_spread[i]), foreign_spread=float(terms.foreign_spread[i]),
-                             domestic_freq_type=terms.domestic_freq_type, foreign_freq_type=terms.foreign_freq_type[i],
+                             domestic_freq_type=terms.domestic_freq_type, foreign_freq_type=terms.foreign_freq_type[1][int(terms.foreign_freq_type[0][i])],
                              domestic_dc_type=terms.domestic_dc_type, foreign_dc_type=terms.foreign_dc_type,
                              domestic_floating_index=terms.domestic_floating_index,
                              foreign_floating_index=terms.foreign_floating_index, domestic_currency=terms.domestic_currency,

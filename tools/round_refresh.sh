@@ -20,6 +20,13 @@ python tools/bench_long_legs.py 200000 lag > gpurun_out/bench_${TAG}_payment_lag
 python tools/bench_xccy.py 100000 3 > gpurun_out/bench_${TAG}_xccy.json 2>/dev/null || exit 1
 python tools/bench_xccy.py 100000 7 >> gpurun_out/bench_${TAG}_xccy.json 2>/dev/null || exit 1
 python bench.py --xccy-swaps 100000 --steps 10 --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_mixed_book.json 2>/dev/null || exit 1
+python bench.py --interp LINEAR_FWD_RATES --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_linfwd.json 2>/dev/null || exit 1
 bash tools/profile.sh $TAG || exit 1
-bash tools/pmc.sh && python tools/pmc_summary.py > gpurun_out/pmc_$TAG.txt
+bash tools/pmc.sh && python tools/pmc_summary.py > gpurun_out/pmc_$TAG.txt || exit 1
+bash tools/profile_paths.sh $TAG || exit 1
+bash tools/pmc_lag.sh && python tools/pmc_summary.py 200000 > gpurun_out/pmc_${TAG}_lag.txt || exit 1
+if [ -f variants_stamps.so ]; then
+  ADRATES_HIP_LIB=/root/repo/variants_stamps.so python tools/stamps.py > gpurun_out/stamps_$TAG.txt 2>/dev/null || exit 1
+  ADRATES_HIP_LIB=/root/repo/variants_stamps.so python tools/stamps_lag.py > gpurun_out/stamps_${TAG}_lag.txt 2>/dev/null || exit 1
+fi
 echo refresh-done
