@@ -298,7 +298,7 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     // Hessian term (kernels_general.hip, `Lookup`)
     c->dev.packed_ok = (t.packed_ok && t.P % 2 == 0) ? 1 : 0;
     c->dev.Pc = t.Pc; c->dev.pc_pad = t.pc_pad; c->dev.Ec = t.Ec; c->dev.Eu = t.Eu; c->dev.epg = t.epg; c->dev.cpg = t.cpg; c->dev.hub = t.hub ? 1 : 0;
-    c->dev.Kcore = t.Kcore; c->dev.n_mini = t.n_mini; c->dev.fringe_start = t.fringe_start;
+    c->dev.Kcore = t.Kcore; c->dev.n_mini = t.n_mini; c->dev.fringe_start = t.fringe_start; c->dev.n_fringe = t.n_fringe; c->dev.fringe_own = t.fringe_own ? 1 : 0;
     c->dev.ljc = d_ljc; c->dev.lcc = d_lcc; c->dev.mini = d_mini; c->dev.knot_class = d_class;
     c->dev.pillar_to_core = d_p2c; c->dev.out_map = d_omap; c->dev.store_map = d_smap; c->dev.ent_pq = d_pq; c->dev.core_pos = d_cpos; c->dev.lcc_pos = d_lpos;
     // the packed tables must fit the LDS of a CU next to the search arrays, else the general kernel serves all
@@ -436,7 +436,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     c.x = d_x; c.inv_x = d_invx; c.first_of = d_first; c.compact_of = d_comp; c.lc_block_mask = d_lcmask;
     c.lut = d_lut; c.n_lut = static_cast<int>(t.lut.size() / 2);
     c.packed_ok = d.packed_ok;
-    c.Pc = t.Pc; c.pc_pad = t.pc_pad; c.Ec = t.Ec; c.Eu = t.Eu; c.epg = t.epg; c.cpg = t.cpg; c.hub = t.hub ? 1 : 0; c.Kcore = t.Kcore; c.n_mini = t.n_mini; c.fringe_start = t.fringe_start;
+    c.Pc = t.Pc; c.pc_pad = t.pc_pad; c.Ec = t.Ec; c.Eu = t.Eu; c.epg = t.epg; c.cpg = t.cpg; c.hub = t.hub ? 1 : 0; c.Kcore = t.Kcore; c.n_mini = t.n_mini; c.fringe_start = t.fringe_start; c.n_fringe = t.n_fringe; c.fringe_own = t.fringe_own ? 1 : 0;
     c.knot_class = d_class; c.pillar_to_core = d_p2c; c.out_map = d_omap; c.store_map = d_smap; c.ent_pq = d_pq; c.core_pos = d_cpos; c.lcc_pos = d_lpos;
     size_t fast_lds = 0;
     if (c.packed_ok) {

@@ -1,4 +1,7 @@
 #include "curve_tables.hpp"
+#include <cstdio>
+#include <functional>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cmath>
@@ -299,7 +302,42 @@ bool build_packed_layout(CurveTables& t) {
     t.lcc_pq.assign(t.ent_pq.begin(), t.ent_pq.end());
     t.core_pos.clear();
     t.hub = false;
-    const bool hub_ok = t.cpg < t.epg && hub_layout(Pc, core_pillars, t.cpg, t);
+    // Exact variants (two fringe slots per lane): a fringe pair is given to the lane of one of its own pillars - group
+    // lane l holds pillar l's v in a register, so the rank-one term of these slots needs one LDS gather instead of two
+    // (the kernels' exact instantiations rely on it).  Greedy: pairs with one candidate first, then the less loaded of
+    // the two lanes; a curve it cannot place takes a universal variant, like one without a star decomposition.
+    std::vector<int> own_slot(n_fringe, -1);                  // slot * 32 + lane
+    bool own_ok = t.cpg < t.epg;
+    if (own_ok) {
+        // bipartite matching, pairs -> (lane, slot) with lane one of the pair's pillars: augmenting paths (Kuhn)
+        std::vector<int> holder(2 * kGroupLanes, -1);         // pair held by slot * 32 + lane
+        std::vector<char> visited;
+        std::function<bool(int)> place = [&](int i) -> bool {
+            const int cand[2] = {fringe[i].first, fringe[i].second};
+            for (int c = 0; c < (cand[0] == cand[1] ? 1 : 2); ++c) {
+                if (cand[c] >= kGroupLanes) continue;
+                for (int slot = 0; slot < 2; ++slot) {
+                    const int at = slot * kGroupLanes + cand[c];
+                    if (visited[at]) continue;
+                    visited[at] = 1;
+                    if (holder[at] < 0 || place(holder[at])) { holder[at] = i; return true; }
+                }
+            }
+            return false;
+        };
+        for (int i = 0; i < n_fringe && own_ok; ++i) {
+            visited.assign(2 * kGroupLanes, 0);
+            own_ok = place(i);
+        }
+        if (own_ok)
+            for (int at = 0; at < 2 * kGroupLanes; ++at) {
+                const int i = holder[at];
+                if (i < 0) continue;
+                own_slot[i] = at;
+                if (fringe[i].first != at % kGroupLanes) std::swap(fringe[i].first, fringe[i].second);   // own pillar first
+            }
+    }
+    const bool hub_ok = own_ok && hub_layout(Pc, core_pillars, t.cpg, t);
     if (t.cpg < t.epg && !hub_ok) {
         // no star decomposition for this curve: the exact variants would index an empty core_pos (see above).
         // Take the first universal variant the entries fit, or leave the curve to the general kernel.
@@ -319,12 +357,21 @@ bool build_packed_layout(CurveTables& t) {
         t.hub = true;
     }
     while (static_cast<int>(t.ent_pq.size() / 2) < fringe_start) { t.ent_pq.push_back(0); t.ent_pq.push_back(0); }
-    for (const auto& pq : fringe) {
-        entry_of[pq.first * kPillarPad + pq.second] = static_cast<int>(t.ent_pq.size() / 2);
-        t.ent_pq.push_back(static_cast<uint8_t>(pq.first));
-        t.ent_pq.push_back(static_cast<uint8_t>(pq.second));
+    std::vector<int> fringe_entry(n_fringe, -1);
+    t.fringe_own = hub_ok;
+    for (int i = 0; i < n_fringe; ++i) fringe_entry[i] = fringe_start + (t.fringe_own ? own_slot[i] : i);
+    t.fringe_pos.assign(kPillarPad * kPillarPad, -1);
+    const int n_entries = t.fringe_own ? fringe_start + 2 * kGroupLanes : fringe_start + n_fringe;
+    while (static_cast<int>(t.ent_pq.size() / 2) < n_entries) { t.ent_pq.push_back(0); t.ent_pq.push_back(0); }
+    for (int i = 0; i < n_fringe; ++i) {
+        const int e = fringe_entry[i], a = fringe[i].first, b = fringe[i].second;
+        entry_of[std::min(a, b) * kPillarPad + std::max(a, b)] = e;
+        t.ent_pq[2 * e] = static_cast<uint8_t>(a);
+        t.ent_pq[2 * e + 1] = static_cast<uint8_t>(b);
+        t.fringe_pos[a * kPillarPad + b] = t.fringe_pos[b * kPillarPad + a] = i;
     }
-    t.Eu = static_cast<int>(t.ent_pq.size() / 2);
+    t.n_fringe = n_fringe;
+    t.Eu = n_entries;
 
     t.out_map.assign(kPillarPad * kPillarPad, -1);
     for (int r = 0; r < P; ++r)
@@ -370,10 +417,8 @@ bool build_packed_layout(CurveTables& t) {
         const int a = t.lcc_pq[2 * pos], b = t.lcc_pq[2 * pos + 1];
         t.lcc_pos[a * kPillarPad + b] = t.lcc_pos[b * kPillarPad + a] = static_cast<int16_t>(pos);
     }
-    for (int e = fringe_start; e < t.Eu; ++e) {
-        const int a = t.ent_pq[2 * e], b = t.ent_pq[2 * e + 1];
-        t.lcc_pos[a * kPillarPad + b] = t.lcc_pos[b * kPillarPad + a] = static_cast<int16_t>(Ec + 1 + (e - fringe_start));
-    }
+    for (int i = 0; i < kPillarPad * kPillarPad; ++i)        // fringe pairs: behind the row, in the order they were found
+        if (t.fringe_pos[i] >= 0) t.lcc_pos[i] = static_cast<int16_t>(Ec + 1 + t.fringe_pos[i]);
 
     // one extra all-zero row (index Kcore) stands in for knots nothing depends on, so the kernel's hot loop
     // needs no branch for them

@@ -72,6 +72,9 @@ struct CurveTables {
     int epg = 0;                       // packed entries per group lane the kernel is instantiated for (Eu <= 32*epg)
     int cpg = 0;                       // of which slots that read convexity rows: epg - 2 (exact) or epg (universal)
     int fringe_start = 0;              // first packed entry of the fringe pairs
+    int n_fringe = 0;                  // number of fringe pairs
+    bool fringe_own = false;           // every fringe pair sits in the lane of its first pillar (entry % 32 == that pillar)
+    std::vector<int> fringe_pos;       // [32*32] ordinal of the fringe pair (p, q), -1 if none (scratch of the layout builder)
     int Kcore = 0;                     // rows of ljc / lcc
     int n_mini = 0;                    // knots with at most two pillars outside the core
     std::vector<int16_t> pillar_to_core;   // [32]   core column of pillar p; Pc (the zero column) outside the core
@@ -84,7 +87,7 @@ struct CurveTables {
     std::vector<char> core_real;           // [32*cpg]         hub layout: entry e is a real pair (not padding)
     std::vector<uint8_t> lcc_pq;           // [Ec][2]          pillars of the pair stored at position pos of a lcc row
     std::vector<int16_t> lcc_pos;          // [32*32]          flat index of pair (r, c), either order: position in a lcc row (core),
-                                           //                  Ec + 1 + (entry - fringe_start) (fringe), -1 for pairs no node creates
+                                           //                  Ec + 1 + ordinal of the fringe pair, -1 for pairs no node creates
     std::vector<int16_t> out_map;          // [32*32]          packed entry feeding gamma[r][c] (32-wide rows), -1 if none
     std::vector<int16_t> store_map;        // [32*32]          the same by flat index r*P + c; -2 beyond P*P
     std::vector<MiniKnot> mini;            // [n_mini]

@@ -119,6 +119,7 @@ struct CurveDev {
     // fast kernels: packed layout (curve_tables.hpp), valid when packed_ok
     int packed_ok, Pc, pc_pad, Ec, Eu, epg, cpg, hub, Kcore, n_mini;
     int fringe_start;            // first packed entry of the fringe pairs (entries fringe_start .. Eu - 1)
+    int n_fringe, fringe_own;    // number of fringe pairs; 1: each sits in the group lane of its first pillar (that lane's own v)
     const double* ljc;           // [Kcore][pc_pad]
     const double* lcc;           // [Kcore][Ec + 1] (last entry of every row is 0), null without gamma
     const MiniKnot* mini;        // [n_mini]
@@ -129,7 +130,7 @@ struct CurveDev {
     const uint8_t* ent_pq;       // [Eu][2]
     const int16_t* core_pos;     // [32*cpg] hub layout only: row position of core entry e
     const int16_t* lcc_pos;      // [32*32] flat index of pair (r, c) for the general kernel's LDS rows: its position in a
-                                 //         lcc row (core pairs), Ec + 1 + (entry - fringe_start) (fringe pairs), -1 otherwise
+                                 //         lcc row (core pairs), Ec + 1 + ordinal (fringe pairs), -1 otherwise
 };
 
 struct OutputsDev {

@@ -250,6 +250,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
     // Exact variants (CPG < EPG) use the hub layout: the CPG core pairs of a lane share their first pillar,
     // whose v is read once per node; their convexity values sit at per-lane positions of the compact row.
     constexpr bool HUB = GAMMA && CPG < EPG;
+    static_assert(!HUB || PPL == 1, "exact variants: group lane l holds pillar l");
     int up[EPG], vq[EPG];                         // the two pillars of packed entry l + L*i (0, 0 if none)
 #pragma unroll
     for (int i = 0; i < EPG; ++i) {
@@ -420,6 +421,8 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
         // convexity row whose weight is still to be added (see the consume loop), per group
         int carry_row = zero_row;
         double carry_w = 0.0;
+        // (Carrying the right knot's Jacobian entries to the next node as well - one LDS read less per node - was
+        // measured 7 % SLOWER: the select and its branch sit on the node's critical path.)
         auto lc_row_pass = [&](int row, double w) {
             double lr[CPG > 0 ? CPG : 1];
             if (HUB) {
@@ -616,6 +619,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                         }
                     }
                 }
+                ADR_STAMP(5);   // (walk) record decode, Jacobian rows
                 // convexity of short-end knots: one to three numbers (the symmetric 2x2 block on pillars p0, p1), added
                 // by the lanes that own the packed entries (p0,p0), (p0,p1), (p1,p1)
                 auto mini_convexity = [&](double coef_a, double coef_b) {
@@ -677,7 +681,8 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
 #pragma unroll
                         for (int i = 0; i < kBatch; ++i) {
                             if (i0 + i >= EPG) continue;
-                            if (!(HUB && i0 + i < CPG)) uu[i] = vbuf[up[i0 + i]];
+                            // exact variants: the fringe slots' first pillar is the lane's own (curve_tables.cpp) - no gather
+                            if (!HUB) uu[i] = vbuf[up[i0 + i]];
                             vv[i] = vbuf[vq[i0 + i]];
                             // convexity rows: entry l + L*i of a row sits at row[l + L*i] (hub layout: row[pos[i]])
                             if (WITH_ROW && i0 + i < CPG) la[i] = HUB ? rowa[pos[i0 + i]] : rowa[L * (i0 + i)];
@@ -686,7 +691,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
 #pragma unroll
                         for (int i = 0; i < kBatch; ++i) {
                             if (i0 + i >= EPG) continue;
-                            const double u_i = (HUB && i0 + i < CPG) ? hub_v : uu[i];
+                            const double u_i = HUB ? (i0 + i < CPG ? hub_v : vv_[0]) : uu[i];
                             double gsum = fma(om_r * u_i, vv[i], acc[i0 + i]);
                             if (WITH_ROW && i0 + i < CPG) {
                                 const bool core = CPG < EPG || (i0 + i) < core_entries;   // compile-time true unless universal
@@ -743,9 +748,11 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                     if (GAMMA) {
                         const double coef_a = fma(om, wa, fma(om_p, wpa, om_s * wsa)), coef_b = fma(om, wb, fma(om_p, wpb, om_s * wsb));
                         const double coa = convexity_coef(coef_a, coef_b);
+                        ADR_STAMP(6);   // (walk, date record) the three v, first-order sums, convexity coefficient
                         rank_one(std::true_type{}, om, v1, coa);
                         mini_convexity(coef_a, coef_b);
                         if (__ballot(om_p != 0.0)) rank_one(std::false_type{}, om_p, vp, 0.0);
+                        ADR_STAMP(7);   // (walk, date record) the two rank-one updates
                     }
                 } else if (LAG && chunk_pass && role < 2) {
                     // ---- accrual start / end on knots of their own: adds to the node's v; first-order and convexity part

@@ -730,7 +730,7 @@ size_t general_lds_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
 bool general_kernel_uses_lds_rows(const CurveDev& cv, bool gamma) {
     // worth it only for GAMMA (the rows are the convexity term); needs the packed tables and at most 192 core pairs
     const size_t lds = general_lds_kernel_lds_bytes(cv, gamma);
-    return gamma && lds > 0 && lds <= 160 * 1024 && cv.Ec + 1 + (cv.Eu - cv.fringe_start) <= kConvStage;
+    return gamma && lds > 0 && lds <= 160 * 1024 && cv.Ec + 1 + cv.n_fringe <= kConvStage;
 }
 
 int general_kernel_threads(const CurveDev& cv, bool gamma) {
