@@ -916,10 +916,10 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     // Routing.  With GAMMA: trades without payment lag go to the fast kernel when the curve has the packed layout
     // (those with more than 32 coupons per leg as chains of rows, in a launch of their own), everything else to the
     // general kernel.  Without GAMMA (PV / PV + delta): the lite kernel takes every trade without payment lag and
-    // with at most 45 coupons per leg on either log-linear scheme, whatever the curve's structure; the rest goes to
+    // with at most 45 coupons per leg, whatever the curve's structure or scheme; the rest goes to
     // the chained fast kernel (packed layout) or the general kernel.
     const bool use_fast = curve->dev.packed_ok != 0;
-    const bool use_lite = !want_gamma && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES && trades->lite.n_units > 0;
+    const bool use_lite = !want_gamma && trades->lite.n_units > 0;
     adr::TradesDev fast = trades->dev, chained = trades->chained, general = trades->dev, lagged = trades->lagged;
     // (the payment-lag variant's ratio nodes are single exponentials: not under LINEAR_FWD_RATES, which go to the general kernel)
     const bool use_lag = want_gamma && use_fast && lagged.n_rows > 0 && ctx->lag_scratch != nullptr &&

@@ -779,6 +779,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                     }
                     if (GAMMA) {
                         const double coa = convexity_coef(om_n * wa, om_n * wb);
+                        ADR_STAMP(6);   // (walk) v, first-order sums, convexity coefficient
                         if (!LAG && lindf) {
                             if (__ballot(flush_row != zero_row)) lindf_knot(flush_row, flush_w);
                             rank_one(std::true_type{}, coa, ua, coa);            // knot a (core row, or a short-end knot's entries)
@@ -789,6 +790,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                         } else {
                             rank_one(std::true_type{}, om_n, v, coa);
                         }
+                        ADR_STAMP(7);   // (walk) the rank-one update with the left knot's convexity row
                         mini_convexity(om_n * wa, om_n * wb);
                     }
                 }

@@ -22,7 +22,7 @@
 //     per entry one broadcast b128 read, one b128 read of the row pair, two FMAs - no per-node decoding, no short-end
 //     special cases (the dense 32-wide LJ of all reachable knots fits LDS once the gamma tables are not needed);
 //   * neighbour moves and the 16-lane PV sum are DPP row operations (VALU, no LDS traffic).
-// Any curve of the two log-linear schemes qualifies (no packed layout, any pillar count up to 32).
+// Any curve of the three schemes qualifies (no packed layout, any pillar count up to 32).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -93,7 +93,9 @@ struct CurveLds {
     int K, method;
 };
 
-template <bool DELTA>
+// LINDF: LINEAR_FWD_RATES - D = ba d_a + bb d_b, a node is two single-knot exponentials and its two entries carry the
+// two amounts (kernels_fast.hip, `lindf`)
+template <bool DELTA, bool LINDF>
 __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                                                                                        OutputsDev out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -269,9 +271,15 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                 int off_a = 0, off_b = 0;
                 if (qon) {
                     const Lookup q = curve_lookup<true>(c, qt);
-                    const double omega = qa * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
-                    pv += omega;
-                    ca = omega * q.ba; cb = omega * q.bb;
+                    if (LINDF) {
+                        ca = qa * q.ba * exp(c.log_df[q.ka]);
+                        cb = q.bb != 0.0 ? qa * q.bb * exp(c.log_df[q.kb]) : 0.0;
+                        pv += ca + cb;
+                    } else {
+                        const double omega = qa * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
+                        pv += omega;
+                        ca = omega * q.ba; cb = omega * q.bb;
+                    }
                     off_a = q.ka * (kPillarPad * 8); off_b = q.kb * (kPillarPad * 8);
                 }
                 ADR_STAMP(2);   // lookup + exp
@@ -376,14 +384,22 @@ size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta) {
 hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const OutputsDev& out, bool want_delta,
                              int n_blocks, hipStream_t stream) {
     const size_t lds = lite_kernel_lds_bytes(cv, want_delta);
-    if (want_delta) hipLaunchKernelGGL(price_lite_kernel<true>, dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out);
-    else hipLaunchKernelGGL(price_lite_kernel<false>, dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out);
+    const dim3 grid(n_blocks), block(kBlockThreads);
+    if (cv.method == 2) {
+        if (want_delta) hipLaunchKernelGGL((price_lite_kernel<true, true>), grid, block, lds, stream, cv, tr, out);
+        else hipLaunchKernelGGL((price_lite_kernel<false, true>), grid, block, lds, stream, cv, tr, out);
+    } else {
+        if (want_delta) hipLaunchKernelGGL((price_lite_kernel<true, false>), grid, block, lds, stream, cv, tr, out);
+        else hipLaunchKernelGGL((price_lite_kernel<false, false>), grid, block, lds, stream, cv, tr, out);
+    }
     return hipGetLastError();
 }
 
 hipError_t set_lite_kernel_lds_limit(size_t bytes) {
-    const void* fns[] = {reinterpret_cast<const void*>(&price_lite_kernel<true>),
-                         reinterpret_cast<const void*>(&price_lite_kernel<false>)};
+    const void* fns[] = {reinterpret_cast<const void*>(&price_lite_kernel<true, false>),
+                         reinterpret_cast<const void*>(&price_lite_kernel<false, false>),
+                         reinterpret_cast<const void*>(&price_lite_kernel<true, true>),
+                         reinterpret_cast<const void*>(&price_lite_kernel<false, true>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
         if (e != hipSuccess) return e;

@@ -90,9 +90,9 @@ def measured_traffic(n, want_gamma, kind, interp):
     import glob
     if not (n == 1_000_000 and want_gamma and kind == "offgrid" and interp == "LINEAR_ZERO_RATES"):
         return None, "none: no committed PMC pass for this workload"
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_traffic.json")))
     if not files:
-        return None, "none: profiles/r*_traffic.json missing"
+        return None, "none: profiles/r*_final_traffic.json missing"
     try:
         with open(files[-1]) as f:
             return float(json.load(f)["hbm_bytes_per_launch"]), (

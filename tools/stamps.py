@@ -22,6 +22,6 @@ for mask, lab in ((7, "value+delta+gamma"), (3, "value+delta"), (1, "value")):
     buf = np.zeros((nw, 8), dtype=np.uint64)
     lib.adr_debug_stamps(ctx._h, buf.ctypes.data_as(C.c_void_p), nw)
     tot = buf.sum(0).astype(float)
-    names = ["header", "cashflow loads+folding", "lookup+exp", "node consumption: v, sums, rank-one", "outputs", "node consumption: record + Jacobian rows"]
+    names = ["header", "cashflow loads+folding", "lookup+exp", "walk: entry / exit", "outputs", "walk: record, Jacobian rows, loop tail", "walk: v, first-order sums, convexity coefficient", "walk: rank-one update"]
     print(lab, "cycles per wave:", int(buf.sum(1).mean()))
-    for nm, v in zip(names, tot[:6]): print(f"   {nm:26s} {100 * v / tot.sum():5.1f} %")
+    for nm, v in zip(names, tot[:8]): print(f"   {nm:26s} {100 * v / tot.sum():5.1f} %")

@@ -30,6 +30,6 @@ nw = 256 * 8
 buf = np.zeros((nw, 8), dtype=np.uint64)
 lib.adr_debug_stamps(ctx._h, buf.ctypes.data_as(C.c_void_p), nw)
 tot = buf.sum(0).astype(float)
-names = ["input wait", "folding", "lookup+exp (chunk build)", "node consumption (rest)", "outputs", "walk: record + Jacobian rows", "walk, date record: v, sums", "walk, date record: rank-one x2"]
+names = ["input wait", "folding", "lookup+exp (chunk build)", "walk: entry / exit", "outputs", "walk: record, Jacobian rows, loop tail", "walk: v, first-order sums, convexity coefficient", "walk: rank-one updates"]
 print("cycles per wave:", int(buf.sum(1).mean()))
 for nm, v in zip(names, tot[:8]): print(f"   {nm:26s} {100 * v / tot.sum():5.1f} %")
