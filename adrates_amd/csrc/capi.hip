@@ -217,6 +217,12 @@ int adr_curve_layout_host(int K, int P, const double* times, const double* dfs, 
     info[0] = t.packed_ok ? 1 : 0; info[1] = t.Pc; info[2] = t.Ec; info[3] = t.Eu; info[4] = t.epg;
     info[5] = t.Kcore; info[6] = t.n_mini;
     info[7] = t.packed_ok ? static_cast<int64_t>(adr::fast_kernel_lds_bytes(d, t.has_hess)) : 0;
+    {   // the general kernel's variant with LDS-resident convexity rows (it serves what the fast kernels do not take)
+        const size_t g = (t.packed_ok && t.has_hess && t.T == 1)
+            ? adr::general_lds_kernel_lds_bytes_for(t.K, t.Kc, t.Kcore, t.Ec, t.n_mini, static_cast<int>(t.lut.size() / 2), true) : 0;
+        info[8] = static_cast<int64_t>(g);
+        info[9] = adr::general_lds_rows_fit(g, t.Ec, t.n_fringe) ? 1 : 0;
+    }
     return ADR_OK;
 }
 

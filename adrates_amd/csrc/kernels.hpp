@@ -174,6 +174,8 @@ hipError_t launch_curve_build(const CurveBuildPlanDev& plan, int n_scen, const d
 size_t general_kernel_lds_bytes(int K, int Kc, bool two_tiles = false);
 int general_kernel_threads(const CurveDev& cv, bool gamma);          // block size of the variant launch_price_general picks
 size_t fast_kernel_lds_bytes(const CurveDev& cv, bool gamma, bool lagged = false);
+size_t general_lds_kernel_lds_bytes_for(int K, int Kc, int Kcore, int Ec, int n_mini, int n_lut, bool gamma);
+bool general_lds_rows_fit(size_t lds_bytes, int Ec, int n_fringe);
 int fast_kernel_threads(bool lagged);
 int fast_kernel_groups();
 size_t fast_kernel_lag_scratch_bytes(int n_blocks);

@@ -711,26 +711,34 @@ size_t general_kernel_lds_bytes(int K, int Kc, bool two_tiles) {
     return (need + 15) & ~static_cast<size_t>(15);
 }
 
-// LDS of the variant with resident convexity rows, or 0 when the curve has no packed tables
-size_t general_lds_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
-    if (!cv.lcc_pos || !cv.knot_class || (gamma && !cv.lcc)) return 0;
+// LDS of the variant with resident convexity rows for a curve of these sizes
+size_t general_lds_kernel_lds_bytes_for(int K, int Kc, int Kcore, int Ec, int n_mini, int n_lut, bool gamma) {
     constexpr int kWavesPerBlock = kThreadsLds / 64;
-    if (cv.T > 1) return 0;
-    size_t bytes = sizeof(double) * (static_cast<size_t>(cv.K) + 2 * cv.Kc + static_cast<size_t>(cv.Kc) * kPillarPad +
-                                     kWavesPerBlock * 64);
+    size_t bytes = sizeof(double) * (static_cast<size_t>(K) + 2 * Kc + static_cast<size_t>(Kc) * kPillarPad + kWavesPerBlock * 64);
     if (gamma)
-        bytes += sizeof(double) * (static_cast<size_t>(cv.Kcore + 1) * (cv.Ec + 1) + kWavesPerBlock * kConvStage) +
-                 sizeof(MiniKnot) * cv.n_mini;
-    bytes += sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + cv.Kc + 2 * kLutMax);
+        bytes += sizeof(double) * (static_cast<size_t>(Kcore + 1) * (Ec + 1) + kWavesPerBlock * kConvStage) +
+                 sizeof(MiniKnot) * n_mini;
+    // (the bucket table is the last array of the carve-up: its actual size counts, not the kLutMax reserve - with the
+    // reserve the README-sized curves are 214 bytes over the 160 KB)
+    bytes += sizeof(int16_t) * (2 * static_cast<size_t>(K) + Kc + 2 * static_cast<size_t>(n_lut));
     const size_t reduce = sizeof(double) * kWavesPerBlock * kAggStride;
     if (bytes < reduce) bytes = reduce;
     return (bytes + 15) & ~static_cast<size_t>(15);
 }
 
+// ... of an uploaded curve, or 0 when it has no packed tables
+size_t general_lds_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
+    if (!cv.lcc_pos || !cv.knot_class || (gamma && !cv.lcc) || cv.T > 1) return 0;
+    return general_lds_kernel_lds_bytes_for(cv.K, cv.Kc, cv.Kcore, cv.Ec, cv.n_mini, cv.n_lut, gamma);
+}
+
+// worth it only for GAMMA (the rows are the convexity term); needs the packed tables and at most 192 flat entries
+bool general_lds_rows_fit(size_t lds_bytes, int Ec, int n_fringe) {
+    return lds_bytes > 0 && lds_bytes <= 160 * 1024 && Ec + 1 + n_fringe <= kConvStage;
+}
+
 bool general_kernel_uses_lds_rows(const CurveDev& cv, bool gamma) {
-    // worth it only for GAMMA (the rows are the convexity term); needs the packed tables and at most 192 core pairs
-    const size_t lds = general_lds_kernel_lds_bytes(cv, gamma);
-    return gamma && lds > 0 && lds <= 160 * 1024 && cv.Ec + 1 + cv.n_fringe <= kConvStage;
+    return gamma && general_lds_rows_fit(general_lds_kernel_lds_bytes(cv, gamma), cv.Ec, cv.n_fringe);
 }
 
 int general_kernel_threads(const CurveDev& cv, bool gamma) {

@@ -128,3 +128,17 @@ def test_more_than_32_pillars_are_tiled(native_lib):
     assert np.allclose(t["lc"], hess[idx] / dfs[idx, None, None] - lj[:, :, None] * lj[:, None, :], rtol=0, atol=1e-15)
     info = _native.curve_layout_host(times, dfs, jac, hess)
     assert info["packed_ok"] == 0            # the packed layout of the fast kernels is for one tile
+
+
+def test_readme_sized_curves_keep_their_lds_resident_variants(native_lib):
+    """Both LDS-resident table sets of the 32-pillar benchmark curve fit the 160 KB of a CU: the fast kernels' packed
+    layout and the general kernel's resident convexity rows (which once fell 214 bytes short because of a table
+    reserve, silently sending >32-coupon payment-lag legs to the L2-streaming variant)."""
+    curve = F.readme_model().curves.GBP_OIS_SONIA
+    host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    info = _native.curve_layout_host(host.times, host.dfs, host.jac, host.hess)
+    assert info["packed_ok"] == 1 and info["entries_per_lane"] == 7 and info["core_pairs"] == 153
+    assert 0 < info["lds_bytes"] <= 160 * 1024
+    assert 0 < info["general_lds_bytes"] <= 160 * 1024 and info["general_lds_rows"] == 1
+    # every fringe pair sits in the lane of one of its own pillars: two slots of 32 entries behind the core slots
+    assert info["packed_entries"] == 32 * 7
