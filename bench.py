@@ -65,7 +65,7 @@ def spawn_ranks(args, argv):
     if args.print_spawn_command:
         print(" ".join(cmd), flush=True)
         return 0
-    if have < args.gpus:
+    if have < args.gpus and os.environ.get("ADR_BENCH_REHEARSE_ONE_GPU") != "1":
         print(f"bench.py: --gpus {args.gpus} requested but only {have} HIP device(s) are visible", file=sys.stderr)
         return 2
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -120,6 +120,12 @@ def main(argv=None):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) "
                          "or call bench.py without a launcher")
+    # ADR_BENCH_REHEARSE_ONE_GPU=1: every rank uses device 0 and the collectives run over gloo (RCCL refuses two
+    # ranks on one device) - a one-GPU box can then walk the whole N > 1 path (rank spawn, sharding of the one
+    # portfolio, all-reduce of the ladders, max-over-ranks timing).  The line it prints is NOT a scaling result.
+    rehearse = os.environ.get("ADR_BENCH_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
@@ -127,7 +133,17 @@ def main(argv=None):
     # the collective calls the N > 1 runs make; needs MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE in the env)
     use_dist = world > 1 or os.environ.get("ADR_BENCH_FORCE_DIST") == "1"
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+            _all_reduce = dist.all_reduce
+
+            def all_reduce_via_host(tensor, op=dist.ReduceOp.SUM):
+                host = tensor.detach().cpu()
+                _all_reduce(host, op=op)
+                tensor.copy_(host)
+            dist.all_reduce = all_reduce_via_host
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from adrates_amd import _native
     from adrates_amd.market.curves.curve_tables import build_engine_curve
@@ -269,7 +285,7 @@ def main(argv=None):
             "value": value, "unit": "trades/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "warmup_steps_run": warm_steps,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" if not rehearse else "synthetic; REHEARSAL: all ranks on device 0, gloo collectives - not a scaling result",
             "config": {"workload": f"{args.trades} random-tenor OIS per GPU ({args.kind}), PV + {P}-pillar delta"
                                    + (f" + full {P}x{P} gamma" if want_gamma else "")
                                    + f", {args.interp}, README GBP SONIA curve (BASELINE configs[2])",

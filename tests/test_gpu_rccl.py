@@ -72,3 +72,30 @@ def test_bench_process_group_path_with_one_rank(tmp_path):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f64"
     assert d["value"] > 1e6 and d["roofline"]["bound"] == "hbm" and 0.0 < d["roofline"]["frac"] < 1.0
     assert abs(d["value"] - 20000 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher, the way the driver calls it, walked end to end on a one-GPU box:
+    bench.py spawns its own two ranks (before touching the GPU), each compiles its share of the ONE portfolio, prices
+    it, the aggregate ladders are all-reduced and rank 0 prints one line.  ADR_BENCH_REHEARSE_ONE_GPU=1 puts both
+    ranks on device 0 and swaps RCCL (which refuses two ranks on one device) for gloo; everything else is the code
+    of the real run.  The line is marked as a rehearsal - its value says nothing about scaling."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADR_BENCH_REHEARSE_ONE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--trades", "30000", "--steps", "3",
+                          "--warmup", "1", "--xccy-swaps", "2000", "--cpu-baseline-seconds", "0"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and "REHEARSAL" in d["data"]
+    cfg = d["config"]
+    assert cfg["trades_total"] == 60000 and 0 < cfg["rank0_trades"] < 60000 and cfg["xccy_swaps_total"] == 4000
+    assert d["value"] > 1e5
