@@ -501,8 +501,17 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                 // accrual end and payment time a few days apart share their knots: the end weights join the payment
                 // record (one walk of those rows instead of two)
                 const bool fold_e = pair_e == pair_p;
+                // a payment time without sensitivity (the value-time knot - where the weighted coupons of a leg projected
+                // on another curve are "paid"): the date record takes the accrual end's two knots, so
+                // that such a coupon is one record too (and its successor's accrual start can ride along)
+                const bool fold_e0 = pair_p == null_pair && pair_e != null_pair;
+                const int date_pair = fold_e0 ? pair_e : pair_p;             // the knots of the quad's date record
                 if (role == 1) { ba = -ba; bb = -bb; }
                 if (role == 2 && fold_e) { ba -= e_ba; bb -= e_bb; }
+                if (role == 2 && fold_e0) {
+                    ba = -e_ba; bb = -e_bb;
+                    cls_a = pair_e >> 16; cls_b = static_cast<int>(static_cast<int16_t>(pair_e & 0xffff));
+                }
                 if (role == 3) {
                     double a_q = cin ? w_not * (spread * cal - (accr ? 1.0 : 0.0)) : 0.0;
                     if (have && q < n_fix && cxtp == ctp && cxtp > 0.0) a_q = fma(sf, cxpay, a_q);   // the fixed coupon of the date
@@ -513,20 +522,20 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                     omega = om_r;
                     if (role == 2) pv += omega;
                     const bool any_part = pair_s != null_pair || pair_e != null_pair || pair_p != null_pair;
-                    greeks_lag = om_r != 0.0 && (role == 2 ? any_part : (pair != null_pair && !(role == 1 && fold_e)));
+                    greeks_lag = om_r != 0.0 && (role == 2 ? any_part : (pair != null_pair && !(role == 1 && (fold_e || fold_e0))));
                     // special: a short-end knot is involved and the parts do not all sit on one knot interval - the
                     // rank-one term then reaches pairs of pillars the packed ladder has no entry for
                     const bool has_mini = min(min(pair_s >> 16, static_cast<int>(static_cast<int16_t>(pair_s))),
                                               min(min(pair_e >> 16, static_cast<int>(static_cast<int16_t>(pair_e))),
                                                   min(pair_p >> 16, static_cast<int>(static_cast<int16_t>(pair_p))))) <= -3;
-                    const bool one_interval = (pair_s == null_pair || pair_s == pair_p) && (pair_e == null_pair || pair_e == pair_p);
+                    const bool one_interval = (pair_s == null_pair || pair_s == date_pair) && (pair_e == null_pair || pair_e == date_pair);
                     special = role == 2 && om_r != 0.0 && has_mini && !one_interval;
                 }
                 if (!greeks_lag) { omega = 0.0; ba = bb = 0.0; cls_a = cls_b = -2; }
                 // records the date record of a quad takes along (see the walk): the quad's payment node, and the accrual
                 // start of the NEXT quad when it sits on the same two knots as this quad's payment time
                 const bool pr_live = quad_bcast_i<0xAA>(greeks_lag ? 1 : 0) != 0;
-                const int prev_pair = from_prev_lane_i(from_prev_lane_i(pair)), prev_live = from_prev_lane_i(from_prev_lane_i(greeks_lag ? 1 : 0));
+                const int prev_pair = from_prev_lane_i(from_prev_lane_i(date_pair)), prev_live = from_prev_lane_i(from_prev_lane_i(greeks_lag ? 1 : 0));
                 taken_by_date = greeks_lag && ((role == 3 && pr_live) || (role == 0 && l >= 4 && prev_live != 0 && prev_pair == pair));
             } else
             if (qon) {
