@@ -98,7 +98,7 @@ struct adr_trades {
     const int32_t* list_general = nullptr;
     adr::TradesDev chained{};        // row table of the longer trades as chains of 32-coupon rows (fast kernel, LONG)
     int chained_blocks = 0;          // the grid the chains were laid out for
-    // delta / PV-only requests: the trades without payment lag and at most 45 coupons per leg as 16-slot rows of the
+    // delta / PV-only requests: the trades without payment lag and at most 32 coupons per leg as 16-slot rows of the
     // lite kernel (the trades of the 32-slot row table); list_nonlite = every other trade (for curves without a packed layout)
     // gamma requests on curves with the packed layout: trades with payment lag or per-coupon notionals and at most 32
     // coupons per leg as rows of the payment-lag variant of the fast kernel; list_rest = the general list without them
@@ -108,6 +108,12 @@ struct adr_trades {
     adr::LiteRowsDev lite{};
     int64_t n_lite = 0, n_nonlite = 0;
     const int32_t* list_nonlite = nullptr;
+    // ... and the trades with payment lag or per-coupon notionals and at most 60 coupons per leg as rows of the lite
+    // kernel's payment-lag variant; list_general_b / list_nonlite_b = list_general / list_nonlite without them
+    adr::LiteRowsDev lite_lag{};
+    int64_t n_lite_lag = 0, n_general_b = 0, n_nonlite_b = 0;
+    const int32_t* list_general_b = nullptr;
+    const int32_t* list_nonlite_b = nullptr;
     std::vector<void*> allocations;
 };
 
@@ -788,32 +794,48 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
             if (e == hipSuccess) ctx->lag_blocks = blocks;
         }
     }
-    {   // lite table (kernels.hpp, LiteRowsDev): segments of 3-, 2- and 1-row trades, longest coupon counts first
+    {   // lite tables (kernels.hpp, LiteRowsDev): segments of 3-, 2- and 1-row trades, longest coupon counts first -
+        // one for the trades of the 32-slot row table, one (with accrual ends and notional multipliers) for trades with
+        // payment lag or per-coupon notionals of at most 60 coupons per leg (4 rows)
         constexpr int S = adr::kLiteSlots, C = adr::kLiteCoupons, G = 64 / adr::kLiteSlots;
         auto lite_rows = [&](int64_t t) {
             const int64_t m = std::max(flt_off[t + 1] - flt_off[t], fix_off[t + 1] - fix_off[t]);
             return std::max<int64_t>(1, (m + C - 1) / C);
         };
-        std::vector<int32_t> seg_trades[adr::kLiteSegments], nonlite;
+        std::vector<int32_t> seg_plain[adr::kLiteSegments], seg_lag[adr::kLiteSegments], nonlite, nonlite_b, general_b;
+        std::vector<char> lite_lag(static_cast<size_t>(n), 0);
         for (int64_t t = 0; t < n; ++t) {
-            bool general = false;
-            for (int64_t j = flt_off[t]; j < flt_off[t + 1] && !general; ++j)
-                general = (flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j]) || (flt_weight && flt_weight[j] != 1.0);
+            bool lagged = false;
+            for (int64_t j = flt_off[t]; j < flt_off[t + 1] && !lagged; ++j)
+                lagged = (flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j]) || (flt_weight && flt_weight[j] != 1.0);
             const int64_t rows = lite_rows(t);
-            // the same trades as the 32-slot row table holds (at most 32 coupons per leg, i.e. up to 3 lite rows);
-            // longer ones keep their chained rows
-            if (general || rows_of(t) > 1 || rows > adr::kLiteSegments) nonlite.push_back(static_cast<int32_t>(t));
-            else seg_trades[adr::kLiteSegments - rows].push_back(static_cast<int32_t>(t));     // segment 0: 3 rows
+            // plain: the same trades as the 32-slot row table holds (at most 32 coupons per leg, i.e. up to 3 lite
+            // rows); longer ones keep their chained rows
+            if (!lagged && rows_of(t) == 1) { seg_plain[adr::kLiteSegments - rows].push_back(static_cast<int32_t>(t)); continue; }
+            nonlite.push_back(static_cast<int32_t>(t));
+            if (lagged && rows <= adr::kLiteSegments) {
+                seg_lag[adr::kLiteSegments - rows].push_back(static_cast<int32_t>(t));
+                lite_lag[static_cast<size_t>(t)] = 1;
+            } else {
+                nonlite_b.push_back(static_cast<int32_t>(t));
+            }
         }
+        for (int32_t t : list_general) if (!lite_lag[static_cast<size_t>(t)]) general_b.push_back(t);
         tr->n_nonlite = static_cast<int64_t>(nonlite.size());
         tr->list_nonlite = static_cast<const int32_t*>(put(nonlite.data(), nonlite.size() * sizeof(int32_t)));
-        adr::LiteRowsDev& lt = tr->lite;
+        tr->n_nonlite_b = static_cast<int64_t>(nonlite_b.size());
+        tr->list_nonlite_b = static_cast<const int32_t*>(put(nonlite_b.data(), nonlite_b.size() * sizeof(int32_t)));
+        tr->n_general_b = static_cast<int64_t>(general_b.size());
+        tr->list_general_b = static_cast<const int32_t*>(put(general_b.data(), general_b.size() * sizeof(int32_t)));
+        bool too_many_rows = false;
+        auto build_lite = [&](std::vector<int32_t> (&seg_trades)[adr::kLiteSegments], adr::LiteRowsDev& lt, int64_t& n_out,
+                              bool with_te) {
         int64_t units = 0, rows = 0;
         for (int k = 0; k < adr::kLiteSegments; ++k) {
             std::stable_sort(seg_trades[k].begin(), seg_trades[k].end(), [&](int32_t a, int32_t b) {
                 return hdr[static_cast<size_t>(a)].n_flt > hdr[static_cast<size_t>(b)].n_flt;
             });
-            tr->n_lite += static_cast<int64_t>(seg_trades[k].size());
+            n_out += static_cast<int64_t>(seg_trades[k].size());
             lt.seg_rows[k] = adr::kLiteSegments - k;
             lt.seg_unit0[k] = units;
             lt.seg_row0[k] = rows;
@@ -822,12 +844,10 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
             rows += seg_units * G * lt.seg_rows[k];
         }
         lt.n_units = units;
-        if (rows * S > static_cast<int64_t>(UINT32_MAX)) {      // the kernel indexes the row arrays with 32 bits
-            adr_free_trades(tr);
-            return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^28 rows in the delta-only table; shard the portfolio");
-        }
+        if (rows * S > static_cast<int64_t>(UINT32_MAX)) { too_many_rows = true; return; }   // the kernel indexes with 32 bits
         const size_t n_slots = static_cast<size_t>(units) * G, n_rows = static_cast<size_t>(rows);
         std::vector<double> r_tpts(n_rows * S * 2, 0.0), r_alxtp(n_rows * S * 2, 0.0), r_xpay(n_rows * S, 0.0);
+        std::vector<double> r_tew(with_te ? n_rows * S * 2 : 0, 0.0);
         std::vector<adr::LiteTrade> r_slot(n_slots, adr::LiteTrade{0.0, 0.0, 0, -1, 0});
         for (int k = 0; k < adr::kLiteSegments; ++k) {
             const int R = lt.seg_rows[k];
@@ -840,6 +860,10 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
                     const size_t at = (row0 + static_cast<size_t>(j / C)) * S + static_cast<size_t>(j % C);
                     r_tpts[2 * at] = flt_tp[flt_off[t] + j]; r_tpts[2 * at + 1] = flt_ts[flt_off[t] + j];
                     r_alxtp[2 * at] = flt_alpha[flt_off[t] + j];
+                    if (with_te) {
+                        r_tew[2 * at] = flt_te[flt_off[t] + j];
+                        r_tew[2 * at + 1] = flt_weight ? flt_weight[flt_off[t] + j] : 1.0;
+                    }
                 }
                 for (int64_t j = 0; j < mf; ++j) {
                     const size_t at = (row0 + static_cast<size_t>(j / C)) * S + static_cast<size_t>(j % C);
@@ -854,7 +878,15 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         lt.tp_ts = static_cast<const double*>(put(r_tpts.data(), r_tpts.size() * sizeof(double)));
         lt.al_xtp = static_cast<const double*>(put(r_alxtp.data(), r_alxtp.size() * sizeof(double)));
         lt.xpay = static_cast<const double*>(put(r_xpay.data(), r_xpay.size() * sizeof(double)));
+        lt.te_w = with_te ? static_cast<const double*>(put(r_tew.data(), r_tew.size() * sizeof(double))) : nullptr;
         lt.slot = static_cast<const adr::LiteTrade*>(put(r_slot.data(), r_slot.size() * sizeof(adr::LiteTrade)));
+        };
+        build_lite(seg_plain, tr->lite, tr->n_lite, false);
+        if (!too_many_rows && tr->n_nonlite > tr->n_nonlite_b) build_lite(seg_lag, tr->lite_lag, tr->n_lite_lag, true);
+        if (too_many_rows) {
+            adr_free_trades(tr);
+            return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^28 rows in the delta-only table; shard the portfolio");
+        }
     }
     if (e != hipSuccess) { adr_free_trades(tr); return fail_hip(e, "adr_trades_upload: copying trades"); }
     *out = tr;
@@ -922,7 +954,8 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     // Routing.  With GAMMA: trades without payment lag go to the fast kernel when the curve has the packed layout
     // (those with more than 32 coupons per leg as chains of rows, in a launch of their own), everything else to the
     // general kernel.  Without GAMMA (PV / PV + delta): the lite kernel takes every trade without payment lag and
-    // with at most 45 coupons per leg, whatever the curve's structure or scheme; the rest goes to
+    // with at most 32 coupons per leg (with payment lag or per-coupon notionals, on a log-linear scheme: at most 60),
+    // whatever the curve's structure or scheme; the rest goes to
     // the chained fast kernel (packed layout) or the general kernel.
     const bool use_fast = curve->dev.packed_ok != 0;
     const bool use_lite = !want_gamma && trades->lite.n_units > 0;
@@ -931,13 +964,21 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     const bool use_lag = want_gamma && use_fast && lagged.n_rows > 0 && ctx->lag_scratch != nullptr &&
                          curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
     if (!use_lag) lagged.n_rows = 0;
-    if (use_lite) {
-        fast.n_rows = 0;                                   // the lite table holds exactly the 32-slot row table's trades
+    // (the lite kernel's payment-lag rows: PV / PV + delta of trades with payment lag or per-coupon notionals, log-linear schemes)
+    const bool use_lite_lag = !want_gamma && trades->lite_lag.n_units > 0 && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
+    if (use_lite || use_lite_lag) {
+        if (use_lite) fast.n_rows = 0;                     // the lite table holds exactly the 32-slot row table's trades
         if (use_fast) {                                    // long trades keep their chained rows
-            general.list = trades->list_general; general.n_list = trades->n_general;
+            general.list = use_lite_lag ? trades->list_general_b : trades->list_general;
+            general.n_list = use_lite_lag ? trades->n_general_b : trades->n_general;
         } else {                                           // no packed layout: long trades join the general list
-            chained.n_rows = 0;
-            general.list = trades->list_nonlite; general.n_list = trades->n_nonlite;
+            fast.n_rows = 0; chained.n_rows = 0;
+            if (use_lite) {
+                general.list = use_lite_lag ? trades->list_nonlite_b : trades->list_nonlite;
+                general.n_list = use_lite_lag ? trades->n_nonlite_b : trades->n_nonlite;
+            } else {        // no plain lite rows means no trade is outside list_nonlite
+                general.list = trades->list_nonlite_b; general.n_list = trades->n_nonlite_b;
+            }
         }
     } else if (use_fast) {
         general.list = use_lag ? trades->list_rest : trades->list_general;
@@ -945,7 +986,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     } else {
         fast.n_rows = 0; chained.n_rows = 0;   // general walks all n trades through the identity list
     }
-    int blocks_fast = 0, blocks_chained = 0, blocks_general = 0, blocks_lite = 0, blocks_lag = 0;
+    int blocks_fast = 0, blocks_chained = 0, blocks_general = 0, blocks_lite = 0, blocks_lag = 0, blocks_litelag = 0;
     if (lagged.n_rows > 0) {
         const int waves = adr::fast_kernel_threads(true) / 64;
         const int64_t units = (lagged.n_rows + adr::fast_kernel_groups() - 1) / adr::fast_kernel_groups();
@@ -957,6 +998,12 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
         const int64_t need = (trades->lite.n_units + adr::kLiteThreads / 64 - 1) / (adr::kLiteThreads / 64);
         blocks_lite = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * per_cu));
+    }
+    if (use_lite_lag) {
+        const size_t lds = adr::lite_kernel_lds_bytes(curve->dev, want_delta);
+        const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
+        const int64_t need = (trades->lite_lag.n_units + adr::kLiteThreads / 64 - 1) / (adr::kLiteThreads / 64);
+        blocks_litelag = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * per_cu));
     }
     if (fast.n_rows > 0) {
         const size_t lds = adr::fast_kernel_lds_bytes(curve->dev, want_gamma);
@@ -971,7 +1018,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         const int64_t need = (general.n_list + threads / 64 - 1) / (threads / 64);
         blocks_general = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * (threads == adr::kGeneralThreads ? 4 : 2)));
     }
-    if (blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag > ctx->max_blocks)
+    if (blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag > ctx->max_blocks)
         return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
     auto partials_at = [&](int first_block) {
         return agg_dev ? ctx->partials + static_cast<size_t>(first_block) * adr::kAggStride : nullptr;
@@ -997,8 +1044,12 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         o.lag_scratch = ctx->lag_scratch;
         ADR_HIP(adr::launch_price_fast(curve->dev, lagged, o, want_delta, want_gamma, blocks_lag, stream));
     }
+    if (blocks_litelag > 0) {
+        o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag);
+        ADR_HIP(adr::launch_price_lite(curve->dev, trades->lite_lag, o, want_delta, blocks_litelag, stream));
+    }
     if (agg_dev)
-        ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag,
+        ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag,
                                             P, want_gamma, agg_dev, stream));
     return ADR_OK;
 }

@@ -25,7 +25,7 @@ constexpr int kLiteThreads = 512;
 constexpr int kLiteWavesPerSimd = 4;                                 // 2 blocks of 8 waves per CU (105 VGPRs)
 constexpr int kLiteSlots = 16;
 constexpr int kLiteCoupons = 15;
-constexpr int kLiteSegments = 3;                                     // trades of 3, 2 and 1 rows (up to 45 coupons per leg)
+constexpr int kLiteSegments = 4;                                     // trades of 4, 3, 2 and 1 rows (up to 60 coupons per leg)
 
 // Per-trade header, 32 bytes, read once per trade with scalar loads.
 struct TradeHeader {
@@ -75,7 +75,8 @@ struct TradesDev {
     const int32_t* row_trade;    // [n_rows] index of the trade in the batch (where its results go)
 };
 
-// Row table of the lite kernel: the trades without payment lag and with at most 45 coupons per leg, grouped into
+// Row table of the lite kernel: the trades of the 32-slot row table (no payment lag, at most 32 coupons per leg) - or,
+// with `te_w`, trades with payment lag / per-coupon notionals of at most 60 coupons per leg -, grouped into
 // segments of equal row count (3, 2, 1 rows per trade; inside a segment sorted by coupon count), every segment padded
 // to a multiple of 4 trades (one unit = the 4 trades of a wavefront) with empty slots (trade = -1).
 struct LiteTrade {                    // 32 bytes: one 16-byte and one 8-byte load per lane
@@ -97,6 +98,7 @@ struct LiteRowsDev {
     const double* tp_ts;              // [n_rows][kLiteSlots][2] float payment time, accrual start time
     const double* al_xtp;             // [n_rows][kLiteSlots][2] accrual fraction, fixed payment time
     const double* xpay;               // [n_rows][kLiteSlots]    fixed payment amount
+    const double* te_w;               // [n_rows][kLiteSlots][2] accrual end time, notional multiplier - payment-lag rows only (else null)
     const LiteTrade* slot;            // [4 * n_units] per-trade scalars
 };
 

@@ -14,7 +14,7 @@
 // (2 trades per wavefront at ~400 VALU instructions per trade), so the mapping is chosen to
 // spend as few wave-instructions per trade as possible:
 //   * a wavefront prices FOUR trades at a time, 16 lanes each, and a trade's coupons arrive as rows of 16 slots
-//     (15 coupons + a spare lane for the leg's start node; trades of 16-45 coupons are 2 or 3 consecutive rows), so
+//     (15 coupons + a spare lane for the leg's start node; trades of 16-60 coupons are 2 to 4 consecutive rows), so
 //     half-empty 32-slot rows are neither loaded nor computed on: ~0.95 KB of row data per trade on the benchmark
 //     portfolio instead of 1.3 KB, fetched as 16-byte-per-lane loads of pair-interleaved arrays;
 //   * lanes = coupons for folding, lookup and exp; then every lane leaves its node as two 16-byte entries
@@ -95,9 +95,14 @@ struct CurveLds {
 
 // LINDF: LINEAR_FWD_RATES - D = ba d_a + bb d_b, a node is two single-knot exponentials and its two entries carry the
 // two amounts (kernels_fast.hip, `lindf`)
-template <bool DELTA, bool LINDF>
+// LAG: the rows hold trades whose coupons accrue to a date other than their payment date and / or carry a per-coupon
+// notional multiplier (`te_w`): a coupon is the ratio node N w D(ts) D(tp) / D(te) - one exponential, three lookups -
+// plus the payment node -N w (1 - spread a) D(tp).  The first-order sum is linear in a node's knot weights, so the
+// lane simply leaves three pairs of entries (ts: +, te: -, tp: + with both amounts) in three sweeps; no telescoping.
+template <bool DELTA, bool LINDF, bool LAG>
 __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                                                                                        OutputsDev out) {
+    static_assert(!(LAG && LINDF), "payment-lag trades under LINEAR_FWD_RATES go to the general kernel");
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS carve-up: per-wave entry slots (16-byte aligned), doubles, int16 tables
     unsigned char* s_rec = smem_raw;
@@ -170,6 +175,7 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
         at0 += (u - unit0) * (G * L) * R;
     };
     double nx_tp = 0.0, nx_ts = 0.0, nx_al = 0.0, nx_xtp = 0.0, nx_xpay = 0.0, nx_N = 0.0, nx_spread = 0.0;
+    double nx_te = 0.0, nx_w = 1.0;
     int nx_meta = 0, nx_trade = -1;
     auto request_row = [&](uint32_t at0, int R, int r) {            // group g's row r: R rows per trade, 16 slots per row
         const uint32_t at = at0 + r * L + __umul24(g, R * L) + l;
@@ -177,6 +183,10 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
         const nt_pair b = __builtin_nontemporal_load(reinterpret_cast<const nt_pair*>(tr.al_xtp) + at);
         nx_tp = a.x; nx_ts = a.y; nx_al = b.x; nx_xtp = b.y;
         nx_xpay = __builtin_nontemporal_load(tr.xpay + at);
+        if (LAG) {
+            const nt_pair cw = __builtin_nontemporal_load(reinterpret_cast<const nt_pair*>(tr.te_w) + at);
+            nx_te = cw.x; nx_w = cw.y;
+        }
     };
     auto request_trade = [&](uint32_t u) {
         // (scalar loads of the unit's four slots + a pick by group were tried: the wave then waits for the scalar
@@ -206,6 +216,7 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
     while (unit < n_units) {
         // ---- this step's inputs
         const double tp = nx_tp, ts = nx_ts, al = nx_al, xtp = nx_xtp, xpay = nx_xpay;
+        const double te = nx_te, cw = nx_w;
 #ifdef ADR_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -240,11 +251,11 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
             const bool valid = in && tp >= 0.0;
             const bool accrues = al > 0.0;
             double a_pay = valid ? sl * N * (spread * al - (accrues ? 1.0 : 0.0)) : 0.0;
-            if (in && l + 1 < m_flt && nal > 0.0 && ntp >= 0.0 && nts == tp) a_pay += sl * N;
+            if (!LAG && in && l + 1 < m_flt && nal > 0.0 && ntp >= 0.0 && nts == tp) a_pay += sl * N;
             const bool fix_in = live && l < m_fix;
             const bool fix_merged = fix_in && in && xtp == tp;
             if (fix_merged && xtp > 0.0) a_pay = fma(sf, xpay, a_pay);
-            bool own_start = valid && accrues && !(l > 0 && ptp == ts);
+            bool own_start = !LAG && valid && accrues && !(l > 0 && ptp == ts);
             const bool own_fixed = fix_in && !fix_merged && xtp > 0.0 && sf * xpay != 0.0;
 
             double qt = tp, qa = a_pay;
@@ -259,7 +270,63 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
             const bool more_starts = __ballot(own_start) != 0, more_fixed = __ballot(own_fixed) != 0;
             ADR_STAMP(1);   // folding
 
-            for (int pass = 0; pass < 3; ++pass) {
+            // ---- reverse sweep to the knots: every lane leaves its node as two entries {coefficient, byte offset of the
+            // knot's LJ row}.  Knot 0 is the value-time knot, whose row is all zero, so idle lanes and single-knot
+            // nodes need no flags.  (On curves whose pillar dates are runs of duplicate knots a node's right-hand knot -
+            // the first of a run - is never the next node's left-hand knot - the last of that run -, so merging
+            // neighbours' entries buys nothing: tried, slower.)
+            auto sweep = [&](bool on, double ca, double cb, int off_a, int off_b) {
+                __builtin_amdgcn_wave_barrier();
+                {
+                    double2* wp = reinterpret_cast<double2*>(rec_mine);
+                    wp[0] = make_double2(ca, __hiloint2double(0, off_a));
+                    wp[1] = make_double2(cb, __hiloint2double(0, off_b));
+                }
+                wave_lds_sync();
+                unsigned long long any = __ballot(on);
+                any |= any >> 32; any |= any >> 16;
+                const unsigned rows_any = static_cast<unsigned>(any) & 0xffffu;
+                if (!rows_any) return;
+                const int n_e = 2 * (32 - __builtin_clz(rows_any));      // entries up to the highest live lane of any row
+                for (int e = 0; e < n_e; e += kBatch) {                   // lanes past n_e wrote zero entries
+                    double2 rc[kBatch], rw[kBatch];
+#pragma unroll
+                    for (int i = 0; i < kBatch; ++i) rc[i] = *reinterpret_cast<const double2*>(rec_group + (e + i) * 16);
+#pragma unroll
+                    for (int i = 0; i < kBatch; ++i) rw[i] = *reinterpret_cast<const double2*>(lj_lane + __double2loint(rc[i].y));
+#pragma unroll
+                    for (int i = 0; i < kBatch; ++i) {
+                        if (i & 1) { e0 = fma(rc[i].x, rw[i].x, e0); e1 = fma(rc[i].x, rw[i].y, e1); }
+                        else { d0 = fma(rc[i].x, rw[i].x, d0); d1 = fma(rc[i].x, rw[i].y, d1); }
+                    }
+                }
+            };
+            if (LAG) {
+                // ---- the row's coupons: ratio node + payment node (lane = coupon); three lookups, two exponentials
+                const bool ratio = valid && accrues;
+                Lookup qs{0, 0, 0.0, 0.0}, qe{0, 0, 0.0, 0.0}, qp{0, 0, 0.0, 0.0};
+                double ls = 0.0, le = 0.0, lp = 0.0;
+                if (valid) { qp = curve_lookup<true>(c, tp); lp = fma(qp.ba, c.log_df[qp.ka], qp.bb * c.log_df[qp.kb]); }
+                if (ratio) {
+                    qs = curve_lookup<true>(c, ts); ls = fma(qs.ba, c.log_df[qs.ka], qs.bb * c.log_df[qs.kb]);
+                    qe = curve_lookup<true>(c, te); le = fma(qe.ba, c.log_df[qe.ka], qe.bb * c.log_df[qe.kb]);
+                }
+                const double w_not = sl * N * cw;
+                const double om_r = ratio ? w_not * exp(ls - le + lp) : 0.0;
+                double a_q = valid ? w_not * (spread * al - (accrues ? 1.0 : 0.0)) : 0.0;
+                if (fix_merged && xtp > 0.0) a_q = fma(sf, xpay, a_q);
+                const double om_p = valid ? a_q * exp(lp) : 0.0;
+                pv += om_r + om_p;
+                ADR_STAMP(2);   // lookups + exp
+                if (DELTA) {
+                    const int row = kPillarPad * 8;
+                    sweep(ratio, om_r * qs.ba, om_r * qs.bb, qs.ka * row, qs.kb * row);
+                    sweep(ratio, -om_r * qe.ba, -om_r * qe.bb, qe.ka * row, qe.kb * row);
+                    sweep(valid, (om_r + om_p) * qp.ba, (om_r + om_p) * qp.bb, qp.ka * row, qp.kb * row);
+                }
+                ADR_STAMP(3);   // entries + ladder
+            }
+            for (int pass = LAG ? 1 : 0; pass < 3; ++pass) {
                 if (pass == 1) {            // fixed coupons that did not merge into a float payment node
                     if (!more_fixed) continue;
                     qt = xtp; qa = sf * xpay; qon = own_fixed;
@@ -284,35 +351,7 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                 }
                 ADR_STAMP(2);   // lookup + exp
                 if (!DELTA) continue;
-                // ---- reverse sweep to the knots: every lane leaves its node as two entries {coefficient, byte
-                // offset of the knot's LJ row}.  Knot 0 is the value-time knot, whose row is all zero, so idle lanes
-                // and single-knot nodes need no flags.  (On curves whose pillar dates are runs of duplicate knots a
-                // node's right-hand knot - the first of a run - is never the next node's left-hand knot - the last of
-                // that run -, so merging neighbours' entries buys nothing: tried, slower.)
-                __builtin_amdgcn_wave_barrier();
-                {
-                    double2* wp = reinterpret_cast<double2*>(rec_mine);
-                    wp[0] = make_double2(ca, __hiloint2double(0, off_a));
-                    wp[1] = make_double2(cb, __hiloint2double(0, off_b));
-                }
-                wave_lds_sync();
-                unsigned long long any = __ballot(qon);
-                any |= any >> 32; any |= any >> 16;
-                const unsigned rows_any = static_cast<unsigned>(any) & 0xffffu;
-                if (!rows_any) continue;
-                const int n_e = 2 * (32 - __builtin_clz(rows_any));      // entries up to the highest live lane of any row
-                for (int e = 0; e < n_e; e += kBatch) {                   // lanes past n_e wrote zero entries
-                    double2 rc[kBatch], rw[kBatch];
-#pragma unroll
-                    for (int i = 0; i < kBatch; ++i) rc[i] = *reinterpret_cast<const double2*>(rec_group + (e + i) * 16);
-#pragma unroll
-                    for (int i = 0; i < kBatch; ++i) rw[i] = *reinterpret_cast<const double2*>(lj_lane + __double2loint(rc[i].y));
-#pragma unroll
-                    for (int i = 0; i < kBatch; ++i) {
-                        if (i & 1) { e0 = fma(rc[i].x, rw[i].x, e0); e1 = fma(rc[i].x, rw[i].y, e1); }
-                        else { d0 = fma(rc[i].x, rw[i].x, d0); d1 = fma(rc[i].x, rw[i].y, d1); }
-                    }
-                }
+                sweep(qon, ca, cb, off_a, off_b);
                 ADR_STAMP(3);   // entries + ladder
             }
         }
@@ -385,21 +424,27 @@ hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const Ou
                              int n_blocks, hipStream_t stream) {
     const size_t lds = lite_kernel_lds_bytes(cv, want_delta);
     const dim3 grid(n_blocks), block(kBlockThreads);
-    if (cv.method == 2) {
-        if (want_delta) hipLaunchKernelGGL((price_lite_kernel<true, true>), grid, block, lds, stream, cv, tr, out);
-        else hipLaunchKernelGGL((price_lite_kernel<false, true>), grid, block, lds, stream, cv, tr, out);
+    if (tr.te_w) {                     // payment-lag rows
+        if (cv.method == 2) return hipErrorInvalidValue;
+        if (want_delta) hipLaunchKernelGGL((price_lite_kernel<true, false, true>), grid, block, lds, stream, cv, tr, out);
+        else hipLaunchKernelGGL((price_lite_kernel<false, false, true>), grid, block, lds, stream, cv, tr, out);
+    } else if (cv.method == 2) {
+        if (want_delta) hipLaunchKernelGGL((price_lite_kernel<true, true, false>), grid, block, lds, stream, cv, tr, out);
+        else hipLaunchKernelGGL((price_lite_kernel<false, true, false>), grid, block, lds, stream, cv, tr, out);
     } else {
-        if (want_delta) hipLaunchKernelGGL((price_lite_kernel<true, false>), grid, block, lds, stream, cv, tr, out);
-        else hipLaunchKernelGGL((price_lite_kernel<false, false>), grid, block, lds, stream, cv, tr, out);
+        if (want_delta) hipLaunchKernelGGL((price_lite_kernel<true, false, false>), grid, block, lds, stream, cv, tr, out);
+        else hipLaunchKernelGGL((price_lite_kernel<false, false, false>), grid, block, lds, stream, cv, tr, out);
     }
     return hipGetLastError();
 }
 
 hipError_t set_lite_kernel_lds_limit(size_t bytes) {
-    const void* fns[] = {reinterpret_cast<const void*>(&price_lite_kernel<true, false>),
-                         reinterpret_cast<const void*>(&price_lite_kernel<false, false>),
-                         reinterpret_cast<const void*>(&price_lite_kernel<true, true>),
-                         reinterpret_cast<const void*>(&price_lite_kernel<false, true>)};
+    const void* fns[] = {reinterpret_cast<const void*>(&price_lite_kernel<true, false, false>),
+                         reinterpret_cast<const void*>(&price_lite_kernel<false, false, false>),
+                         reinterpret_cast<const void*>(&price_lite_kernel<true, true, false>),
+                         reinterpret_cast<const void*>(&price_lite_kernel<false, true, false>),
+                         reinterpret_cast<const void*>(&price_lite_kernel<true, false, true>),
+                         reinterpret_cast<const void*>(&price_lite_kernel<false, false, true>)};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
         if (e != hipSuccess) return e;
