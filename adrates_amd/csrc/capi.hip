@@ -103,7 +103,9 @@ struct adr_trades {
     // gamma requests on curves with the packed layout: trades with payment lag or per-coupon notionals and at most 32
     // coupons per leg as rows of the payment-lag variant of the fast kernel; list_rest = the general list without them
     adr::TradesDev lagged{};
-    int64_t n_lagged = 0, n_rest = 0;
+    adr::TradesDev lagged_chained{};   // ... those of 33-128 coupons per leg as chains of rows (LONG + LAG), laid out for
+    int lagged_chained_blocks = 0;     // this grid
+    int64_t n_lagged = 0, n_lagged_long = 0, n_rest = 0;
     const int32_t* list_rest = nullptr;
     adr::LiteRowsDev lite{};
     int64_t n_lite = 0, n_nonlite = 0;
@@ -618,7 +620,7 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         (flt_weight && !all_finite(flt_weight, n_flt)) || !all_finite(notional, n) || !all_finite(spread, n))
         return fail(ADR_ERR_INVALID, "adr_trades_upload: times, amounts, accruals, notionals and spreads must be finite");
 
-    std::vector<int32_t> list_fast, list_long, list_general, list_lagged, list_rest;
+    std::vector<int32_t> list_fast, list_long, list_general, list_lagged, list_lagged_long, list_rest;
     std::vector<adr::TradeHeader> hdr(static_cast<size_t>(n));
     constexpr int64_t kMaxChain = 4;     // rows per trade in the chained table: legs of up to 128 coupons
     auto rows_of = [&](int64_t t) {
@@ -631,7 +633,7 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
             general = (flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j])      // payment lag: ratio terms
                       || (flt_weight && flt_weight[j] != 1.0);              // per-coupon notionals
         (general ? list_general : rows_of(t) > 1 ? list_long : list_fast).push_back(static_cast<int32_t>(t));
-        if (general) (rows_of(t) == 1 ? list_lagged : list_rest).push_back(static_cast<int32_t>(t));
+        if (general) (rows_of(t) == 1 ? list_lagged : rows_of(t) <= kMaxChain ? list_lagged_long : list_rest).push_back(static_cast<int32_t>(t));
     }
     for (int64_t t = 0; t < n; ++t) {
         const int64_t mf = fix_off[t + 1] - fix_off[t], ml = flt_off[t + 1] - flt_off[t];
@@ -732,33 +734,30 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         tr->dev.rows_chained = 0;
         build_rows(pieces, tr->dev);
     }
-    tr->chained = tr->dev;
-    tr->chained.n_rows = 0;
-    if (!list_long.empty()) {
-        // Chained table.  The kernel's wave w walks units w, w + W, w + 2W, ... (W = waves of the launch), so the
-        // rows of a pair of trades (one per group of a wave) go to consecutive "rounds" of one wave column;
-        // pairs are dealt to the columns longest first, always to the shortest column.
-        std::stable_sort(list_long.begin(), list_long.end(), [&](int32_t a, int32_t b) { return rows_of(a) > rows_of(b); });
+    // Chained tables.  The kernel's wave w walks units w, w + W, w + 2W, ... (W = waves of the launch), so the
+    // rows of a pair of trades (one per group of a wave) go to consecutive "rounds" of one wave column;
+    // pairs are dealt to the columns longest first, always to the shortest column.
+    auto build_chained = [&](std::vector<int32_t>& list, adr::TradesDev& dst, int blocks, int waves_per_block, bool lagged) {
+        std::stable_sort(list.begin(), list.end(), [&](int32_t a, int32_t b) { return rows_of(a) > rows_of(b); });
         const int G = adr::fast_kernel_groups();
-        const int blocks = std::max(1, ctx->n_cu);
-        const int64_t W = static_cast<int64_t>(blocks) * (adr::kFastThreads / 64);
+        const int64_t W = static_cast<int64_t>(blocks) * waves_per_block;
         std::vector<std::vector<std::vector<Piece>>> column(static_cast<size_t>(W));   // [wave][round][group]
         std::vector<int64_t> height(static_cast<size_t>(W), 0);
-        for (size_t i = 0; i < list_long.size(); i += static_cast<size_t>(G)) {
+        for (size_t i = 0; i < list.size(); i += static_cast<size_t>(G)) {
             const size_t w = static_cast<size_t>(std::min_element(height.begin(), height.end()) - height.begin());
-            const int64_t len = rows_of(list_long[i]);                       // the longest of the pair (sorted)
+            const int64_t len = rows_of(list[i]);                       // the longest of the pair (sorted)
             for (int64_t j = 0; j < len; ++j) {
                 std::vector<Piece> unit(static_cast<size_t>(G), Piece{-1, 0, j + 1 < len});
-                for (int g = 0; g < G && i + static_cast<size_t>(g) < list_long.size(); ++g) {
-                    const int64_t t = list_long[i + static_cast<size_t>(g)];
+                for (int g = 0; g < G && i + static_cast<size_t>(g) < list.size(); ++g) {
+                    const int64_t t = list[i + static_cast<size_t>(g)];
                     if (j < rows_of(t)) unit[static_cast<size_t>(g)].trade = t;
                     unit[static_cast<size_t>(g)].first = j * adr::kRowSlots;
                 }
                 // results are written after the chain's last row, by the row's trade index: an empty
                 // padding row of the shorter trade still has to carry that index
-                for (int g = 0; g < G && i + static_cast<size_t>(g) < list_long.size(); ++g)
+                for (int g = 0; g < G && i + static_cast<size_t>(g) < list.size(); ++g)
                     if (unit[static_cast<size_t>(g)].trade < 0 && j + 1 == len)
-                        unit[static_cast<size_t>(g)] = Piece{list_long[i + static_cast<size_t>(g)], j * adr::kRowSlots, false};
+                        unit[static_cast<size_t>(g)] = Piece{list[i + static_cast<size_t>(g)], j * adr::kRowSlots, false};
                 column[w].push_back(unit);
             }
             height[w] += len;
@@ -769,15 +768,37 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
             for (size_t r = 0; r < column[static_cast<size_t>(w)].size(); ++r)
                 for (int g = 0; g < G; ++g)
                     pieces[static_cast<size_t>((static_cast<int64_t>(r) * W + w) * G + g)] = column[static_cast<size_t>(w)][r][static_cast<size_t>(g)];
-        tr->chained.rows_chained = 1;
-        tr->chained_blocks = blocks;
-        build_rows(pieces, tr->chained);
+        dst.rows_chained = 1;
+        build_rows(pieces, dst, lagged);
+        dst.rows_chained = 1;
+    };
+    tr->chained = tr->dev;
+    tr->chained.n_rows = 0;
+    if (!list_long.empty()) {
+        tr->chained_blocks = std::max(1, ctx->n_cu);
+        build_chained(list_long, tr->chained, tr->chained_blocks, adr::kFastThreads / 64, false);
     }
     tr->lagged = tr->dev;
     tr->lagged.n_rows = 0;
+    tr->lagged_chained = tr->dev;
+    tr->lagged_chained.n_rows = 0;
+    tr->n_lagged_long = static_cast<int64_t>(list_lagged_long.size());
     tr->n_lagged = static_cast<int64_t>(list_lagged.size());
     tr->n_rest = static_cast<int64_t>(list_rest.size());
     tr->list_rest = static_cast<const int32_t*>(put(list_rest.data(), list_rest.size() * sizeof(int32_t)));
+    if (!list_lagged_long.empty()) {   // payment-lag legs of 33-128 coupons: chains of rows for the grid of the variant
+        tr->lagged_chained_blocks = std::max(1, ctx->n_cu);
+        build_chained(list_lagged_long, tr->lagged_chained, tr->lagged_chained_blocks, adr::fast_kernel_threads(true) / 64, true);
+    }
+    if (!list_lagged.empty() || !list_lagged_long.empty()) {
+        const int blocks = std::max(1, ctx->n_cu);
+        if (e == hipSuccess && ctx->lag_blocks < blocks) {
+            if (ctx->lag_scratch) hipFree(ctx->lag_scratch);
+            ctx->lag_scratch = nullptr; ctx->lag_blocks = 0;
+            e = hipMalloc(reinterpret_cast<void**>(&ctx->lag_scratch), adr::fast_kernel_lag_scratch_bytes(blocks));
+            if (e == hipSuccess) ctx->lag_blocks = blocks;
+        }
+    }
     if (!list_lagged.empty()) {   // payment-lag rows: one row per trade, sorted by coupon count like the plain table
         std::stable_sort(list_lagged.begin(), list_lagged.end(), [&](int32_t a, int32_t b) {
             return hdr[static_cast<size_t>(a)].n_flt > hdr[static_cast<size_t>(b)].n_flt;
@@ -786,13 +807,6 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         for (size_t r = 0; r < list_lagged.size(); ++r) pieces[r] = {list_lagged[r], 0, false};
         tr->lagged.rows_chained = 0;
         build_rows(pieces, tr->lagged, true);
-        const int blocks = std::max(1, ctx->n_cu) * 2;
-        if (e == hipSuccess && ctx->lag_blocks < blocks) {
-            if (ctx->lag_scratch) hipFree(ctx->lag_scratch);
-            ctx->lag_scratch = nullptr; ctx->lag_blocks = 0;
-            e = hipMalloc(reinterpret_cast<void**>(&ctx->lag_scratch), adr::fast_kernel_lag_scratch_bytes(blocks));
-            if (e == hipSuccess) ctx->lag_blocks = blocks;
-        }
     }
     {   // lite tables (kernels.hpp, LiteRowsDev): segments of 3-, 2- and 1-row trades, longest coupon counts first -
         // one for the trades of the 32-slot row table, one (with accrual ends and notional multipliers) for trades with
@@ -959,11 +973,13 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     // the chained fast kernel (packed layout) or the general kernel.
     const bool use_fast = curve->dev.packed_ok != 0;
     const bool use_lite = !want_gamma && trades->lite.n_units > 0;
-    adr::TradesDev fast = trades->dev, chained = trades->chained, general = trades->dev, lagged = trades->lagged;
+    adr::TradesDev fast = trades->dev, chained = trades->chained, general = trades->dev, lagged = trades->lagged,
+                   lagged_long = trades->lagged_chained;
     // (the payment-lag variant's ratio nodes are single exponentials: not under LINEAR_FWD_RATES, which go to the general kernel)
-    const bool use_lag = want_gamma && use_fast && lagged.n_rows > 0 && ctx->lag_scratch != nullptr &&
-                         curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
-    if (!use_lag) lagged.n_rows = 0;
+    const bool use_lag = want_gamma && use_fast && (lagged.n_rows > 0 || lagged_long.n_rows > 0) && ctx->lag_scratch != nullptr &&
+                         curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES &&
+                         trades->lagged_chained_blocks <= ctx->lag_blocks;
+    if (!use_lag) { lagged.n_rows = 0; lagged_long.n_rows = 0; }
     // (the lite kernel's payment-lag rows: PV / PV + delta of trades with payment lag or per-coupon notionals, log-linear schemes)
     const bool use_lite_lag = !want_gamma && trades->lite_lag.n_units > 0 && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
     if (use_lite || use_lite_lag) {
@@ -986,7 +1002,8 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     } else {
         fast.n_rows = 0; chained.n_rows = 0;   // general walks all n trades through the identity list
     }
-    int blocks_fast = 0, blocks_chained = 0, blocks_general = 0, blocks_lite = 0, blocks_lag = 0, blocks_litelag = 0;
+    int blocks_fast = 0, blocks_chained = 0, blocks_general = 0, blocks_lite = 0, blocks_lag = 0, blocks_litelag = 0, blocks_laglong = 0;
+    if (lagged_long.n_rows > 0) blocks_laglong = trades->lagged_chained_blocks;    // the chains are laid out for this grid
     if (lagged.n_rows > 0) {
         const int waves = adr::fast_kernel_threads(true) / 64;
         const int64_t units = (lagged.n_rows + adr::fast_kernel_groups() - 1) / adr::fast_kernel_groups();
@@ -1018,7 +1035,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         const int64_t need = (general.n_list + threads / 64 - 1) / (threads / 64);
         blocks_general = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * (threads == adr::kGeneralThreads ? 4 : 2)));
     }
-    if (blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag > ctx->max_blocks)
+    if (blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag + blocks_laglong > ctx->max_blocks)
         return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
     auto partials_at = [&](int first_block) {
         return agg_dev ? ctx->partials + static_cast<size_t>(first_block) * adr::kAggStride : nullptr;
@@ -1048,8 +1065,13 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag);
         ADR_HIP(adr::launch_price_lite(curve->dev, trades->lite_lag, o, want_delta, blocks_litelag, stream));
     }
+    if (blocks_laglong > 0) {
+        o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag);
+        o.lag_scratch = ctx->lag_scratch;
+        ADR_HIP(adr::launch_price_fast(curve->dev, lagged_long, o, want_delta, want_gamma, blocks_laglong, stream));
+    }
     if (agg_dev)
-        ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag,
+        ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag + blocks_laglong,
                                             P, want_gamma, agg_dev, stream));
     return ADR_OK;
 }

@@ -20,6 +20,7 @@ constexpr int kGeneralLdsThreads = 512;                              // ... 8 wi
 constexpr int kFastThreads = ADR_FAST_THREADS;
 constexpr int kRowSlots = 32;                                        // cash-flow slots per row of the fast table
 constexpr int kLagStashDoubles = 34;                                 // payment-lag variant: {v[32], omega, pad} per special node
+constexpr int kLagScratchNodes = 128;                               // ... special nodes a trade can leave: one per coupon, 4 rows of 32
 // lite kernel (kernels_lite.hip): 4 trades per wavefront, rows of 16 slots = 15 coupons + a spare lane
 constexpr int kLiteThreads = 512;
 constexpr int kLiteWavesPerSimd = 4;                                 // 2 blocks of 8 waves per CU (105 VGPRs)
@@ -141,7 +142,7 @@ struct OutputsDev {
     double* gamma;           // [n*P*P] or null
     double* block_partials;  // [grid][kAggStride] or null
     double* dump;            // [32*32] sink for the gamma stores of the idle trade slot of a wave's last unit
-    double* lag_scratch;     // payment-lag variant: [grid waves][2 groups][32 nodes][kLagStashDoubles]
+    double* lag_scratch;     // payment-lag variant: [grid waves][2 groups][kLagScratchNodes][kLagStashDoubles]
     unsigned long long* stamps;  // diagnostic builds only (ADR_STAMPS): [grid*waves][8] cycle sums per phase
 };
 

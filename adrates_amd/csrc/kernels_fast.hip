@@ -165,7 +165,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
     // 512-thread blocks, i.e. two waves per SIMD and up to 256 VGPRs, instead of 768 / three / 168
     constexpr int kThreads = LAG ? kLagThreads : kBlockThreads;
     constexpr int kWaves = kThreads / 64;
-    static_assert(!LAG || (GAMMA && DELTA && !LONG), "the payment-lag variant exists for gamma requests on plain rows");
+    static_assert(!LAG || (GAMMA && DELTA), "the payment-lag variant exists for gamma requests");
     constexpr int L = 64 / G;                          // lanes per trade
     constexpr int PPL = kPillarPad / L;                // pillars per lane: l + L*k
     constexpr int EPG = GAMMA ? EPG_ : 1;              // packed entries per lane: l + L*i
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
 #pragma unroll
         for (int i = 0; i < 16; ++i) tot_patch[i] = 0.0;
     }
-    double* lag_scratch = LAG ? out.lag_scratch + (static_cast<size_t>(blockIdx.x) * kWaves + wave) * (G * L * kLagStashDoubles) +
-                                    g * (L * kLagStashDoubles) : nullptr;
+    double* lag_scratch = LAG ? out.lag_scratch + (static_cast<size_t>(blockIdx.x) * kWaves + wave) * (G * kLagScratchNodes * kLagStashDoubles) +
+                                    g * (kLagScratchNodes * kLagStashDoubles) : nullptr;
 
     // running portfolio sums of this wave: pv per group (lane l == 0), delta per group lane/pillar,
     // gamma in the 64-lane packed layout (entry lane + 64 s)
@@ -349,6 +349,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
     // LONG: the accumulators live across the iterations of a chain; otherwise they are per iteration
     double pv_chain = 0.0, dacc_chain[PPL], acc_chain[EPG];
     bool fresh = true;                         // LONG: false while a trade's chain of rows is being walked
+    int n_special = 0;                         // LAG: special nodes of this group's trade so far (over the whole chain)
     for (; unit < n_units; unit += wave_stride) {
         double pv_unit = 0.0, dacc_unit[PPL], acc_unit[EPG];
         double& pv = LONG ? pv_chain : pv_unit;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
         double vacc[PPL];                         // LAG: v of the ratio node under construction
 #pragma unroll
         for (int k = 0; k < PPL; ++k) vacc[k] = 0.0;
-        int n_special = 0;                        // LAG: special nodes of this group's trade so far
+        if (!LONG || fresh) n_special = 0;
         const bool more_starts = __ballot(own_start) != 0, more_fixed = __ballot(own_fixed) != 0;
         ADR_STAMP(1);   // node folding
 
@@ -896,8 +897,8 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                     if (LAG && n_sp_gg > 0) {
                         // special ratio nodes of this trade: omega v_r v_c for this lane's elements that have no packed
                         // entry (their staging index is the zero entry), from the wave's scratch
-                        const double* sv = out.lag_scratch + (static_cast<size_t>(blockIdx.x) * kWaves + wave) * (G * L * kLagStashDoubles) +
-                                           gg * (L * kLagStashDoubles);
+                        const double* sv = out.lag_scratch + (static_cast<size_t>(blockIdx.x) * kWaves + wave) * (G * kLagScratchNodes * kLagStashDoubles) +
+                                           gg * (kLagScratchNodes * kLagStashDoubles);
                         for (int sp = 0; sp < n_sp_gg; ++sp, sv += kLagStashDoubles) {
                             // all of a node's operands for this part's bands are requested together (one L2 round trip)
                             double vr[kBands];
@@ -1116,7 +1117,7 @@ hipError_t set_fast_lindf_lds_limit(size_t bytes);
 int fast_kernel_groups() { return kGroups; }
 
 size_t fast_kernel_lag_scratch_bytes(int n_blocks) {
-    return sizeof(double) * static_cast<size_t>(n_blocks) * (kLagThreads / 64) * kGroups * kGroupLanes * kLagStashDoubles;
+    return sizeof(double) * static_cast<size_t>(n_blocks) * (kLagThreads / 64) * kGroups * kLagScratchNodes * kLagStashDoubles;
 }
 int fast_kernel_threads(bool lagged) { return lagged ? kLagThreads : kBlockThreads; }
 
@@ -1142,7 +1143,8 @@ hipError_t launch_price_fast(const CurveDev& cv, const TradesDev& tr, const Outp
     KernelFn fn;
     if (tr.rows_lagged) {
         if (!want_gamma) return hipErrorInvalidValue;        // the payment-lag rows exist for gamma requests only
-        fn = out.gamma != nullptr ? gamma_kernel_for<true, false, true>(cv) : gamma_kernel_for<false, false, true>(cv);
+        if (tr.rows_chained) fn = out.gamma != nullptr ? gamma_kernel_for<true, true, true>(cv) : gamma_kernel_for<false, true, true>(cv);
+        else fn = out.gamma != nullptr ? gamma_kernel_for<true, false, true>(cv) : gamma_kernel_for<false, false, true>(cv);
     } else {
         fn = tr.rows_chained ? pick_kernel<true>(cv, want_delta, want_gamma, out.gamma != nullptr)
                              : pick_kernel<false>(cv, want_delta, want_gamma, out.gamma != nullptr);
@@ -1175,6 +1177,8 @@ hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes) {
     collect_gamma_kernels<false, true, false>(fns);
     collect_gamma_kernels<true, false, true>(fns);
     collect_gamma_kernels<false, false, true>(fns);
+    collect_gamma_kernels<true, true, true>(fns);
+    collect_gamma_kernels<false, true, true>(fns);
     fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<true, false, false, false, false, 1, 1, kGroups>));
     fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<false, false, false, false, false, 1, 1, kGroups>));
     fns.push_back(reinterpret_cast<const void*>(&price_fast_kernel<true, false, false, true, false, 1, 1, kGroups>));

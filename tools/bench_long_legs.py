@@ -18,11 +18,11 @@ host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
 ctx = _native.Context(0)
 dc = _native.DeviceCurve(ctx, 4, host.times, host.dfs, host.jac, host.hess)
 rng = np.random.default_rng(2)
-months = rng.integers(120, 361, n) if mode == "long" else rng.integers(1, 361, n)
+months = rng.integers(120, 361, n) if mode in ("long", "longlag") else rng.integers(1, 361, n)
 terms = OISTerms(vd, [f"{int(m)}M" for m in months], rng.uniform(0.01, 0.07, n), np.round(rng.uniform(1e6, 5e7, n), -5),
                  rng.random(n) < 0.5, FrequencyTypes.ANNUAL, DayCountTypes.ACT_365F, CurveTypes.GBP_OIS_SONIA,
-                 CurrencyTypes.GBP, float_freq_type=FrequencyTypes.QUARTERLY if mode == "long" else FrequencyTypes.ANNUAL,
-                 float_dc_type=DayCountTypes.ACT_365F, payment_lag=0 if mode == "long" else 2,
+                 CurrencyTypes.GBP, float_freq_type=FrequencyTypes.QUARTERLY if mode in ("long", "longlag") else FrequencyTypes.ANNUAL,
+                 float_dc_type=DayCountTypes.ACT_365F, payment_lag=0 if mode == "long" else 2,       # "longlag": quarterly 10-30Y float legs paid 2 business days late
                  bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
 batch = compile_ois_terms(terms, vd)
 dt = _native.DeviceTrades(ctx, batch)
