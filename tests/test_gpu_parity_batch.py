@@ -285,6 +285,46 @@ def test_long_legs_as_row_chains_vs_c_oracle(gpu_ctx):
     print(f"long legs: worst error {worst:.2e}")
 
 
+@pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES])
+def test_long_legs_with_payment_lag_vs_c_oracle(gpu_ctx, interp):
+    """Payment-lag legs of 33-128 coupons (quarterly / semi-annual / monthly floats paid 1-3 business days late): chains
+    of rows of the payment-lag variant with GAMMA, 4-row lite rows (up to 60 coupons) or the general kernel without;
+    seasoned and front-stub trades put ratio nodes on the short-end knots (the patched elements) in every row position;
+    the per-trade results, the aggregates and a 7-trade batch (idle groups, one wave) are compared."""
+    from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
+    from adrates_amd.utils import BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes
+    vd = F.README_VALUE_DT
+    curve = F.gbp_model(vd, interp).curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    rng = np.random.default_rng(33)
+    for n in (2501, 7):
+        months = rng.integers(60, 361, n)
+        back = rng.integers(0, 7, n)                                       # seasoned by up to six months
+        lfreq = [[FrequencyTypes.QUARTERLY, FrequencyTypes.SEMI_ANNUAL, FrequencyTypes.MONTHLY][i]
+                 for i in rng.choice(3, size=n, p=[0.6, 0.3, 0.1])]
+        terms = OISTerms(effective_dt=[vd.add_months(-int(b)) for b in back], tenor=[f"{int(m)}M" for m in months],
+                         coupon=rng.uniform(0.01, 0.07, n), notional=np.round(rng.uniform(1e6, 5e7, n), -5),
+                         pay_fixed=rng.random(n) < 0.5, fixed_freq_type=FrequencyTypes.ANNUAL,
+                         fixed_dc_type=DayCountTypes.ACT_365F, floating_index=CurveTypes.GBP_OIS_SONIA,
+                         currency=CurrencyTypes.GBP, float_freq_type=lfreq, float_dc_type=DayCountTypes.ACT_365F,
+                         float_spread=np.where(rng.random(n) < 0.3, 0.002, 0.0), payment_lag=rng.integers(1, 4, n),
+                         bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
+        batch = compile_ois_terms(terms, vd)
+        n_flt = np.diff(batch.flt_off)
+        if n > 100:
+            assert ((n_flt > 32) & (n_flt <= 128)).sum() > 1200 and (n_flt > 128).any() and (n_flt <= 32).any()
+        ref = port.price(interp.value, host.times, host.dfs, host.jac, host.hess, batch)
+        got = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), aggregate=True)
+        worst = assert_batch_parity(got, ref, batch.notional)
+        assert np.allclose(got["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+        assert np.allclose(got["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
+        assert np.allclose(got["agg_pv"], ref["pv"].sum(), rtol=1e-10, atol=1e-3)
+        only_d = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), want_gamma=False, aggregate=True)
+        assert_batch_parity(only_d, ref, batch.notional)
+        assert np.allclose(only_d["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
+        print(f"{interp.name}, {n} long payment-lag trades: worst error {worst:.2e}")
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_random_curves_and_portfolios_vs_c_oracle(gpu_ctx, seed):
     """Random quote sets on the README tenors (flat, steep, inverted, humped, sub-1% and 8% levels), both
