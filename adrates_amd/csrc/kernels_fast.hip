@@ -72,7 +72,10 @@ constexpr int kBlockThreads = kFastThreads;
 #endif
 constexpr int kOutParts = ADR_OUT_PARTS;      // the 8 output bands of a trade are gathered in this many batches
 [[maybe_unused]] constexpr int kWavesPerBlock = kBlockThreads / 64;
-constexpr int kLagThreads = 512;              // block size of the payment-lag variant
+#ifndef ADR_LAG_THREADS
+#define ADR_LAG_THREADS 512
+#endif
+constexpr int kLagThreads = ADR_LAG_THREADS;  // block size of the payment-lag variant
 
 __device__ __forceinline__ double shfl_d(double x, int src) { return __shfl(x, src, 64); }
 
