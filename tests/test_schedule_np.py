@@ -105,3 +105,29 @@ def test_raw_from_terms_mixes_routes_in_book_order(monkeypatch):
     mixed = XE.raw_from_terms(terms, VALUE_DT, DayCountTypes.ACT_365F)
     monkeypatch.setattr(XE, "_FIXED_DENOMINATOR", {})
     _same(mixed, XE.raw_from_terms(terms, VALUE_DT, DayCountTypes.ACT_365F))
+
+
+def test_errors_match_the_object_path():
+    """The array route raises what the objects raise (same `LibError` texts) and refuses what it cannot represent."""
+    from adrates_amd.utils import LibError
+    eff = np.array([_serial(Date(30, 4, 2024))])
+    with pytest.raises(LibError, match="Effective date must be before termination date"):
+        S.backward_schedules(eff, eff, np.array([12]), BusDayAdjustTypes.FOLLOWING)
+    with pytest.raises(LibError, match="Unknown tenor type"):
+        S.parse_tenors(["5Q"])
+    with pytest.raises(LibError, match="Tenor must be a string"):
+        S.parse_tenors([5])
+    with pytest.raises(LibError, match="not supported"):
+        S.ymd_from_serial(np.array([10]))                          # before 1-Mar-1900: the Lotus leap-day region
+    with pytest.raises(LibError, match="not supported"):
+        S.add_tenor(eff, np.array([400]), np.array([3]))           # 400 years on: beyond the month table
+    # a zero-length tenor: the swap constructor's own check fires first on the object path, the schedule's here
+    terms = _terms(3, 1)
+    terms.tenor = (np.zeros(3, dtype=np.int64), ["0M"])
+    with pytest.raises(LibError, match="Effective date must be before termination date"):
+        XE.raw_from_terms(terms, VALUE_DT, DayCountTypes.ACT_365F)
+    # coded columns are validated
+    terms = _terms(3, 1)
+    terms.foreign_freq_type = (np.array([0, 1, 2]), [FrequencyTypes.ANNUAL, FrequencyTypes.SEMI_ANNUAL])
+    with pytest.raises(LibError, match="coded column"):
+        XE.raw_from_terms(terms, VALUE_DT, DayCountTypes.ACT_365F)
