@@ -200,10 +200,14 @@ def main(argv=None):
                          torch.empty((n_x, Px), dtype=torch.float64, device=dev) if want_delta else None,
                          torch.empty((n_x, Px, Px), dtype=torch.float64, device=dev) if want_gamma else None, agg_len))
             agg_len += 1 + Px + Px * Px
-    # one buffer for every aggregate ladder of the step: a single all-reduce whatever the book holds
-    agg = torch.zeros(agg_len, dtype=torch.float64, device=dev)
+    # one buffer for every aggregate ladder of the step: a single all-reduce whatever the book holds.  Two of them,
+    # used alternately: step k's all-reduce runs on RCCL's stream while step k + 1 prices into the other buffer
+    # (the collective is 8-28 KB and latency-bound: serialised it would idle the GPU for its whole round trip)
+    aggs = [torch.zeros(agg_len, dtype=torch.float64, device=dev) for _ in range(2)]
+    pending = [None, None]              # the all-reduce still reading / writing aggs[j]
+    step_no = [0]
 
-    def price_xccy():
+    def price_xccy(agg):
         for trades_x, cur, pv_x, de_x, ga_x, off in xccy:
             _native.price_dev(ctx, cur, trades_x, mask, pv_x.data_ptr(), de_x.data_ptr() if de_x is not None else 0,
                               ga_x.data_ptr() if ga_x is not None else 0, agg.data_ptr() + 8 * off, stream.cuda_stream)
@@ -212,15 +216,33 @@ def main(argv=None):
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
 
-    def step():
+    def step(events=None):
+        j = step_no[0] & 1
+        step_no[0] += 1
+        agg = aggs[j]
+        if pending[j] is not None:          # the launch stream waits for the collective that last used this buffer
+            pending[j].wait()
+            pending[j] = None
+        if events is not None:
+            events[0].record(stream)
         _native.price_dev(ctx, dev_curve, dev_trades, mask, pv.data_ptr(),
                           delta.data_ptr() if delta is not None else 0,
                           gamma.data_ptr() if gamma is not None else 0, agg.data_ptr(), stream.cuda_stream)
-        price_xccy()
+        if events is not None:
+            events[1].record(stream)
+        price_xccy(agg)
         if use_dist:
-            dist.all_reduce(agg)   # the one exchange step: 1 + P + P*P doubles (per curve) over RCCL/xGMI
+            # the one exchange step: 1 + P + P*P doubles (per curve) over RCCL/xGMI, started behind this step's kernels
+            if rehearse:
+                dist.all_reduce(agg)
+            else:
+                pending[j] = dist.all_reduce(agg, async_op=True)
 
     def fence():
+        for j in range(2):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -247,16 +269,7 @@ def main(argv=None):
     if not per_step:
         ev[0][0].record(stream)
     for i in range(args.steps):
-        if per_step:
-            ev[i][0].record(stream)
-        _native.price_dev(ctx, dev_curve, dev_trades, mask, pv.data_ptr(),
-                          delta.data_ptr() if delta is not None else 0,
-                          gamma.data_ptr() if gamma is not None else 0, agg.data_ptr(), stream.cuda_stream)
-        if per_step:
-            ev[i][1].record(stream)
-        price_xccy()
-        if use_dist:
-            dist.all_reduce(agg)
+        step(ev[i] if per_step else None)
     if not per_step:
         ev[0][1].record(stream)
     fence()
