@@ -202,17 +202,7 @@ def _raw_by_arrays(cols, value_serial, xdc) -> RawXccy:
     xden = _FIXED_DENOMINATOR[xdc]
 
     def leg(freq_key, dc_key, lag, pay_den):
-        off, dts, plain = S.backward_schedules(eff, term, mpp(freq_key), bd)
-        n_dates = off[1:] - off[:-1]
-        is_start = np.ones(off[-1], dtype=bool); is_start[off[1:] - 1] = False
-        is_end = np.ones(off[-1], dtype=bool); is_end[off[:-1]] = False
-        start, end = dts[is_start], dts[is_end]
-        lens = n_dates - 1
-        pay = S.add_business_days(end, np.repeat(lag, lens))
-        d = np.repeat(den(dc_key), lens)
-        t = lambda x, dd: (x - value_serial) / dd
-        return (np.concatenate(([0], np.cumsum(lens))).astype(np.int64), t(pay, d if pay_den is None else pay_den), t(start, d),
-                t(end, d), (end - start) / d, plain)
+        return S.leg_times(eff, term, mpp(freq_key), lag, bd, True, den(dc_key), value_serial, pay_den)
 
     d_off, dtp, dts_, dte, dal, d_plain = leg("dfreq", "ddc", cols["dlag"], None)
     f_off, ftp, fts, fte, fal, f_plain = leg("ffreq", "fdc", cols["flag"], xden)

@@ -151,32 +151,27 @@ def _column(value, n, kind):
     return (codes if seq else np.full(n, codes[0], dtype=np.int64)), table
 
 
-def compile_ois_terms(terms: OISTerms, value_dt) -> TradeBatch:
-    """`TradeBatch` for the trades described by ``terms`` as of ``value_dt``."""
+_FIXED_DENOMINATOR = None          # filled on first use: day counts whose year fraction is days / constant
+
+
+def _fixed_denominators():
+    global _FIXED_DENOMINATOR
+    if _FIXED_DENOMINATOR is None:
+        from ..utils.day_count import DayCountTypes
+        from ..utils.global_vars import gDaysInYear
+        _FIXED_DENOMINATOR = {DayCountTypes.ACT_365F: 365, DayCountTypes.ACT_360: 360, DayCountTypes.SIMPLE: gDaysInYear}
+    return _FIXED_DENOMINATOR
+
+
+def _legs_by_templates(cols, coded, pick, value_dt):
+    """Unit-notional, unit-coupon leg arrays of trades ``pick`` through one template `OIS` per distinct schedule (the
+    object path, once per distinct combination of schedule-defining terms; NumPy gathers)."""
     from ..utils.date import Date
     from .rates.ois import OIS
-
-    notional = np.asarray(terms.notional, dtype=np.float64).reshape(-1)
-    n = notional.shape[0]
-    coupon = _column(terms.coupon, n, "float")
-    spread = _column(terms.float_spread, n, "float")
-    pay_fixed = _column(terms.pay_fixed, n, "bool")
-    lag = _column(terms.payment_lag, n, "int")
-    eff = _column(terms.effective_dt, n, "date")
-    float_freq = terms.fixed_freq_type if terms.float_freq_type is None else terms.float_freq_type
-    float_dc = terms.fixed_dc_type if terms.float_dc_type is None else terms.float_dc_type
-    coded = {}
-    for name, value in (("tenor", terms.tenor), ("fixed_freq", terms.fixed_freq_type), ("float_freq", float_freq),
-                        ("fixed_dc", terms.fixed_dc_type), ("float_dc", float_dc), ("bd", terms.bd_type),
-                        ("cal", terms.cal_type), ("dg", terms.dg_type), ("index", terms.floating_index),
-                        ("ccy", terms.currency)):
-        coded[name] = _column(value, n, "code")
-    key_cols = [eff, lag] + [coded[k][0] for k in coded]
+    names = list(coded)
+    key_cols = [cols["eff"][pick], cols["lag"][pick]] + [coded[k][0][pick] for k in names]
     keys, inverse = np.unique(np.stack(key_cols, axis=1), axis=0, return_inverse=True)
     inverse = inverse.reshape(-1)
-
-    # one unit-coupon, unit-notional template per distinct schedule
-    names = list(coded)
     templates = []
     for row in keys:
         kw = {k: coded[k][1][int(row[2 + j])] for j, k in enumerate(names)}
@@ -193,7 +188,6 @@ def compile_ois_terms(terms: OISTerms, value_dt) -> TradeBatch:
                    float_freq_type=kw["float_freq"], float_dc_type=kw["float_dc"], payment_lag=int(row[1]),
                    **optional)
         templates.append(compile_ois([swap], value_dt))
-
     n_fix = np.array([t.fix_tp.shape[0] for t in templates], dtype=np.int64)
     n_flt = np.array([t.flt_tp.shape[0] for t in templates], dtype=np.int64)
 
@@ -203,16 +197,124 @@ def compile_ois_terms(terms: OISTerms, value_dt) -> TradeBatch:
         cat = np.concatenate([getattr(t, fld) for t in templates]) if templates else np.zeros(0)
         starts = np.concatenate(([0], np.cumsum(counts)))[:-1]
         idx = np.repeat(starts[inverse] - off[:-1], lens) + np.arange(off[-1])
-        return off.astype(np.int64), cat[idx], lens
+        return off.astype(np.int64), cat[idx]
 
-    fix_off, fix_tp, fix_len = gather(n_fix, "fix_tp")
-    _, fix_alpha, _ = gather(n_fix, "fix_pay")          # unit notional * unit coupon = the accrual fraction
-    flt_off, flt_tp, _ = gather(n_flt, "flt_tp")
-    _, flt_ts, _ = gather(n_flt, "flt_ts")
-    _, flt_te, _ = gather(n_flt, "flt_te")
-    _, flt_alpha, _ = gather(n_flt, "flt_alpha")
+    fix_off, fix_tp = gather(n_fix, "fix_tp")
+    flt_off, flt_tp = gather(n_flt, "flt_tp")
+    return {"pick": pick, "fix_off": fix_off, "fix_tp": fix_tp, "fix_alpha": gather(n_fix, "fix_pay")[1],   # unit notional * unit coupon
+            "flt_off": flt_off, "flt_tp": flt_tp, "flt_ts": gather(n_flt, "flt_ts")[1],
+            "flt_te": gather(n_flt, "flt_te")[1], "flt_alpha": gather(n_flt, "flt_alpha")[1]}
+
+
+def _legs_by_arrays(cols, coded, pick, value_dt, bd, weekend):
+    """The same arrays with the schedules, payment lags and year fractions of all trades ``pick`` computed on arrays
+    (`utils.schedule_np`; one business-day rule and calendar per call).  Returns the piece and the mask of trades (of
+    ``pick``) whose two schedules are plain - the others have to go through `_legs_by_templates`."""
+    from ..utils import schedule_np as S
+    from ..utils.calendar import Calendar, CalendarTypes
+    from ..utils.frequency import annual_frequency
+    den_of = _fixed_denominators()
+    eff = cols["eff"][pick]
+    count, unit = S.parse_tenors(coded["tenor"][1])
+    code = coded["tenor"][0][pick]
+    term = S.add_tenor(eff, count[code], unit[code])
+    if (eff > S.adjust(term, bd, weekend)).any():
+        raise LibError("Start date after maturity date")
+    value_serial = int(value_dt.excel_dt())
+    den = lambda key: np.array([den_of.get(d, 0) for d in coded[key][1]])[coded[key][0][pick]]
+    mpp = lambda key: np.array([int(12 / annual_frequency(f)) for f in coded[key][1]], dtype=np.int64)[coded[key][0][pick]]
+    lag = cols["lag"][pick]
+    fix_off, fix_tp, _, _, fix_alpha, fix_plain = S.leg_times(eff, term, mpp("fixed_freq"), lag, bd, weekend, den("fixed_dc"), value_serial)
+    flt_off, flt_tp, flt_ts, flt_te, flt_alpha, flt_plain = S.leg_times(eff, term, mpp("float_freq"), lag, bd, weekend,
+                                                                       den("float_dc"), value_serial)
+    piece = {"pick": pick, "fix_off": fix_off, "fix_tp": fix_tp, "fix_alpha": fix_alpha, "flt_off": flt_off, "flt_tp": flt_tp,
+             "flt_ts": flt_ts, "flt_te": flt_te, "flt_alpha": flt_alpha}
+    return piece, fix_plain & flt_plain
+
+
+def _take_piece(piece, keep):
+    """Trades ``keep`` (positions inside the piece) of a piece."""
+    out = {"pick": piece["pick"][keep]}
+    for side, fields in (("fix", ("fix_tp", "fix_alpha")), ("flt", ("flt_tp", "flt_ts", "flt_te", "flt_alpha"))):
+        src = piece[side + "_off"]
+        lens = (src[1:] - src[:-1])[keep]
+        off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+        idx = np.repeat(src[:-1][keep] - off[:-1], lens) + np.arange(off[-1])
+        out[side + "_off"] = off
+        for f in fields:
+            out[f] = piece[f][idx]
+    return out
+
+
+def _merge_pieces(pieces, n):
+    """Pieces (disjoint sets of trades, any order) -> CSR arrays in trade order."""
+    out = {}
+    for side, fields in (("fix", ("fix_tp", "fix_alpha")), ("flt", ("flt_tp", "flt_ts", "flt_te", "flt_alpha"))):
+        lens = np.zeros(n, dtype=np.int64)
+        for p in pieces:
+            lens[p["pick"]] = p[side + "_off"][1:] - p[side + "_off"][:-1]
+        off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+        cols = {f: np.empty(off[-1], dtype=np.float64) for f in fields}
+        for p in pieces:
+            pl = p[side + "_off"][1:] - p[side + "_off"][:-1]
+            dst = np.repeat(off[:-1][p["pick"]] - p[side + "_off"][:-1], pl) + np.arange(p[side + "_off"][-1])
+            for f in fields:
+                cols[f][dst] = p[f]
+        out[side + "_off"], out[side + "_len"] = off, lens
+        out.update(cols)
+    return out
+
+
+def compile_ois_terms(terms: OISTerms, value_dt) -> TradeBatch:
+    """`TradeBatch` for the trades described by ``terms`` as of ``value_dt``.
+
+    Schedules, payment lags and year fractions are computed on arrays for the whole book (`utils.schedule_np`:
+    BACKWARD date generation, WEEKEND / NONE calendar, any business-day rule, day counts with a fixed denominator) -
+    bit for bit what the `OIS` objects produce; trades on other conventions, or whose schedule hits the reference's
+    front-dropping de-duplication (schedule.py:256-266), go through one template object per distinct schedule."""
+    from ..utils.calendar import BusDayAdjustTypes, CalendarTypes, DateGenRuleTypes
+
+    notional = np.asarray(terms.notional, dtype=np.float64).reshape(-1)
+    n = notional.shape[0]
+    coupon = _column(terms.coupon, n, "float")
+    spread = _column(terms.float_spread, n, "float")
+    pay_fixed = _column(terms.pay_fixed, n, "bool")
+    cols = {"eff": _column(terms.effective_dt, n, "date"), "lag": _column(terms.payment_lag, n, "int")}
+    float_freq = terms.fixed_freq_type if terms.float_freq_type is None else terms.float_freq_type
+    float_dc = terms.fixed_dc_type if terms.float_dc_type is None else terms.float_dc_type
+    coded = {}
+    for name, value in (("tenor", terms.tenor), ("fixed_freq", terms.fixed_freq_type), ("float_freq", float_freq),
+                        ("fixed_dc", terms.fixed_dc_type), ("float_dc", float_dc), ("bd", terms.bd_type),
+                        ("cal", terms.cal_type), ("dg", terms.dg_type), ("index", terms.floating_index),
+                        ("ccy", terms.currency)):
+        coded[name] = _column(value, n, "code")
+
+    # which trades the arrays can do: by table entry, then per trade
+    den_of = _fixed_denominators()
+    table_ok = lambda key, ok: np.array([ok(v) for v in coded[key][1]], dtype=bool)[coded[key][0]]
+    by_arrays = (table_ok("fixed_dc", lambda d: d in den_of) & table_ok("float_dc", lambda d: d in den_of) &
+                 table_ok("dg", lambda g: g is None or g == DateGenRuleTypes.BACKWARD) &
+                 table_ok("cal", lambda c: c is None or c in (CalendarTypes.WEEKEND, CalendarTypes.NONE)))
+    pieces = []
+    if by_arrays.any():
+        # one call per (business-day rule, calendar) present - normally one
+        combo = coded["bd"][0] * len(coded["cal"][1]) + coded["cal"][0]
+        for c in np.unique(combo[by_arrays]):
+            pick = np.nonzero(by_arrays & (combo == c))[0]
+            bd = coded["bd"][1][int(c) // len(coded["cal"][1])]
+            cal = coded["cal"][1][int(c) % len(coded["cal"][1])]
+            piece, plain = _legs_by_arrays(cols, coded, pick, value_dt, BusDayAdjustTypes.FOLLOWING if bd is None else bd,
+                                           cal is None or cal == CalendarTypes.WEEKEND)
+            if not plain.all():
+                by_arrays[pick[~plain]] = False
+                piece = _take_piece(piece, np.nonzero(plain)[0])
+            pieces.append(piece)
+    rest = np.nonzero(~by_arrays)[0]
+    if rest.size:
+        pieces.append(_legs_by_templates(cols, coded, rest, value_dt))
+    m = _merge_pieces(pieces, n)
     # payment = year_frac * notional * coupon, in the leg's evaluation order (swap_fixed_leg.py:190)
-    fix_pay = fix_alpha * np.repeat(notional, fix_len) * np.repeat(coupon, fix_len)
+    fix_pay = m["fix_alpha"] * np.repeat(notional, m["fix_len"]) * np.repeat(coupon, m["fix_len"])
     sign_fix = np.where(pay_fixed, -1.0, 1.0)
-    return TradeBatch(fix_off, flt_off, fix_tp, fix_pay, flt_tp, flt_ts, flt_te, flt_alpha,
+    return TradeBatch(m["fix_off"], m["flt_off"], m["fix_tp"], fix_pay, m["flt_tp"], m["flt_ts"], m["flt_te"], m["flt_alpha"],
                       notional.copy(), spread, sign_fix, -sign_fix)

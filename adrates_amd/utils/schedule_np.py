@@ -174,3 +174,24 @@ def backward_schedules(effective, termination, months_per_period, bd_type, weeke
     np.greater(dates[1:], dates[:-1], out=increasing[1:])
     increasing[off[:-1]] = True
     return off, dates, np.logical_and.reduceat(increasing, off[:-1])
+
+
+def leg_times(effective, termination, months_per_period, payment_lag, bd_type, weekend_calendar, denominator,
+              value_serial, payment_denominator=None):
+    """The arrays `SwapFixedLeg.generate_payments` / `SwapFloatLeg.generate_payment_dts` produce, for many legs on a day
+    count with a fixed denominator (ACT/365F, ACT/360, SIMPLE): CSR offsets over the coupons, payment / accrual start /
+    accrual end times as year fractions from ``value_serial`` (``payment_denominator``: another day count's denominator
+    for the payment times, e.g. the discounting curve's), accrual fractions, and the mask of legs whose schedule is
+    plain (see `backward_schedules`).  ``denominator``: per leg."""
+    off, dts, plain = backward_schedules(effective, termination, months_per_period, bd_type, weekend_calendar)
+    is_start = np.ones(off[-1], dtype=bool)
+    is_start[off[1:] - 1] = False
+    is_end = np.ones(off[-1], dtype=bool)
+    is_end[off[:-1]] = False
+    start, end = dts[is_start], dts[is_end]
+    lens = off[1:] - off[:-1] - 1
+    pay = add_business_days(end, np.repeat(np.asarray(payment_lag, dtype=np.int64), lens))
+    d = np.repeat(np.asarray(denominator), lens)
+    dp = d if payment_denominator is None else payment_denominator
+    coupons = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    return (coupons, (pay - value_serial) / dp, (start - value_serial) / d, (end - value_serial) / d, (end - start) / d, plain)

@@ -77,3 +77,41 @@ def test_large_batch_is_fast():
                                    float_freq_type=FrequencyTypes.ANNUAL, float_dc_type=DayCountTypes.ACT_365F,
                                    bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING), vd)
     assert b.n_trades == n and time.perf_counter() - t0 < 30.0
+
+
+def test_array_route_is_the_template_route_bit_for_bit(monkeypatch):
+    """Schedules on arrays (`utils.schedule_np`) against one `OIS` object per distinct schedule, the route they replace:
+    distinct effective dates (seasoned, forward starting, month ends, a leap day), tenors in months and years, four
+    frequencies, payment lags, two business-day rules, both calendars the arrays know, serial dates; a day count
+    without a fixed denominator and FORWARD date generation on some trades, which take the template route inside the
+    same call; all arrays bitwise equal and in the caller's order."""
+    from adrates_amd.trades import compiler as C
+    from adrates_amd.utils import CalendarTypes, DateGenRuleTypes
+    from adrates_amd.utils.date import Date
+    vd = F.README_VALUE_DT
+    rng = np.random.default_rng(11)
+    n = 3000
+    days = rng.integers(-400, 200, n)
+    eff = np.array([int(vd.excel_dt()) + int(d) for d in days], dtype=np.int64)
+    eff[:3] = [int(Date(29, 2, 2024).excel_dt()), int(Date(31, 1, 2024).excel_dt()), int(Date(31, 8, 2023).excel_dt())]
+    tenor_table = [f"{m}M" for m in range(18, 361, 7)] + ["2Y", "5Y", "10Y", "30Y"]
+    freqs = [FrequencyTypes.ANNUAL, FrequencyTypes.SEMI_ANNUAL, FrequencyTypes.QUARTERLY, FrequencyTypes.MONTHLY]
+    pick = lambda table, p=None: [table[i] for i in rng.choice(len(table), size=n, p=p)]
+    terms = OISTerms(effective_dt=eff, tenor=(rng.integers(0, len(tenor_table), n), tenor_table),
+                     coupon=rng.uniform(0.01, 0.07, n), notional=np.round(rng.uniform(1e6, 5e7, n), -5),
+                     pay_fixed=rng.random(n) < 0.5, fixed_freq_type=pick(freqs[:2]),
+                     fixed_dc_type=pick([DayCountTypes.ACT_365F, DayCountTypes.ACT_360]),
+                     floating_index=CurveTypes.GBP_OIS_SONIA, currency=CurrencyTypes.GBP, float_freq_type=pick(freqs),
+                     float_dc_type=pick([DayCountTypes.ACT_365F, DayCountTypes.ACT_360, DayCountTypes.THIRTY_E_360], [0.6, 0.3, 0.1]),
+                     float_spread=np.where(rng.random(n) < 0.3, 0.0025, 0.0), payment_lag=rng.integers(0, 4, n),
+                     bd_type=pick([BusDayAdjustTypes.FOLLOWING, BusDayAdjustTypes.MODIFIED_FOLLOWING]),
+                     cal_type=pick([CalendarTypes.WEEKEND, CalendarTypes.NONE], [0.8, 0.2]),
+                     dg_type=pick([DateGenRuleTypes.BACKWARD, DateGenRuleTypes.FORWARD], [0.95, 0.05]))
+    fast = compile_ois_terms(terms, vd)
+    calls = []
+    real = C._legs_by_arrays
+    monkeypatch.setattr(C, "_legs_by_arrays", lambda *a, **k: calls.append(1) or real(*a, **k))
+    compile_ois_terms(terms, vd)
+    assert len(calls) == 4                                                 # two rules x two calendars
+    monkeypatch.setattr(C, "_FIXED_DENOMINATOR", {})                       # forces the template route for every trade
+    _same(fast, compile_ois_terms(terms, vd))
