@@ -163,9 +163,8 @@ def _raw_by_templates(cols, singles, value_dt, xdc) -> RawXccy:
     from ...trades.rates.xccy_basis_swap import XccyBasisSwap
     from ...utils.date import Date
     names = ("tenor", "dfreq", "ffreq", "ddc", "fdc")
-    keys, inverse = np.unique(np.stack([cols["eff"], cols["dlag"], cols["flag"]] + [cols[k][0] for k in names], axis=1),
-                              axis=0, return_inverse=True)
-    inverse = inverse.reshape(-1)
+    from ...trades.compiler import unique_rows
+    keys, inverse = unique_rows([cols["eff"], cols["dlag"], cols["flag"]] + [cols[k][0] for k in names])
     templates = []
     for row in keys:
         kw = {k: cols[k][1][int(row[3 + j])] for j, k in enumerate(names)}

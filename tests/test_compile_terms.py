@@ -115,3 +115,18 @@ def test_array_route_is_the_template_route_bit_for_bit(monkeypatch):
     assert len(calls) == 4                                                 # two rules x two calendars
     monkeypatch.setattr(C, "_FIXED_DENOMINATOR", {})                       # forces the template route for every trade
     _same(fast, compile_ois_terms(terms, vd))
+
+
+def test_unique_rows_is_numpy_unique_axis0():
+    """The mixed-radix key of `compiler.unique_rows` orders rows like ``np.unique(axis=0)`` (same rows, same inverse),
+    negative entries and single rows included; columns too wide for one int64 fall back to NumPy's."""
+    from adrates_amd.trades.compiler import unique_rows
+    rng = np.random.default_rng(0)
+    for cols in ([rng.integers(40000, 46000, 5000), rng.integers(-2, 3, 5000), rng.integers(0, 5, 5000)],
+                 [np.array([7]), np.array([-1])],
+                 [rng.integers(-2 ** 40, 2 ** 40, 300), rng.integers(-2 ** 40, 2 ** 40, 300)]):
+        rows, inverse = unique_rows(cols)
+        want_rows, want_inverse = np.unique(np.stack(cols, axis=1), axis=0, return_inverse=True)
+        assert np.array_equal(rows, want_rows) and np.array_equal(inverse, want_inverse.reshape(-1))
+    rows, inverse = unique_rows([np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)])
+    assert rows.shape == (0, 2) and inverse.shape == (0,)
