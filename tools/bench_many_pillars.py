@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Throughput on a 40-pillar curve (ladders in tiles of 32 pillars, general kernel once per tile pair) and on the
+32-pillar curve forced off the packed layout paths for comparison: 100 000 benchmark trades, PV + delta + gamma."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from adrates_amd import _native
+from adrates_amd.market.curves.curve_tables import build_engine_curve
+from adrates_amd.trades import synthetic
+from adrates_amd.trades.market_data import GBP_PX, README_VALUE_DT as vd, TENORS, gbp_model
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+EXTRA = ["11Y", "13Y", "14Y", "16Y", "17Y", "18Y", "19Y", "35Y"]
+years = lambda t: int(t[:-1]) / {"D": 365.0, "W": 52.0, "M": 12.0, "Y": 1.0}[t[-1]]
+base_t = np.array([years(t) for t in TENORS])
+tenors = sorted(list(TENORS) + EXTRA, key=years)
+px = [float(np.interp(years(t), base_t, GBP_PX)) if t in EXTRA else GBP_PX[TENORS.index(t)] for t in tenors]
+ctx = _native.Context(0)
+batch = synthetic.synthesize(vd, n)
+dt = _native.DeviceTrades(ctx, batch)
+dev = torch.device("cuda", 0)
+for label, model in (("40 pillars", gbp_model(vd, px=px, tenors=tenors)), ("32 pillars", gbp_model(vd))):
+    curve = model.curves.GBP_OIS_SONIA
+    host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    dc = _native.DeviceCurve(ctx, 4, host.times, host.dfs, host.jac, host.hess)
+    P = dc.n_pillars
+    pv = torch.empty(n, dtype=torch.float64, device=dev); de = torch.empty((n, P), dtype=torch.float64, device=dev)
+    ga = torch.empty((n, P, P), dtype=torch.float64, device=dev); ag = torch.empty(1 + P + P * P, dtype=torch.float64, device=dev)
+    for mask in (7, 3):
+        for _ in range(5):
+            _native.price_dev(ctx, dc, dt, mask, pv.data_ptr(), de.data_ptr(), ga.data_ptr() if mask & 4 else 0, ag.data_ptr())
+        ctx.sync()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); a.record()
+        for _ in range(10):
+            _native.price_dev(ctx, dc, dt, mask, pv.data_ptr(), de.data_ptr(), ga.data_ptr() if mask & 4 else 0, ag.data_ptr())
+        ctx.sync(); b.record(); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 10
+        print(json.dumps({"curve": label, "pillars": P, "trades": n, "mask": mask, "ms": ms, "trades_per_s": n / ms * 1e3}))
