@@ -117,6 +117,9 @@ x = xccy.position(model).compute([RequestTypes.VALUE, RequestTypes.DELTA, Reques
 print(f"7Y GBP/USD basis swap: PV {x.value.amount:,.2f} GBP; delta per bp - SONIA {x.risk.GBP_OIS_SONIA.value.amount:,.2f}, "
       f"SOFR {x.risk.USD_OIS_SOFR.value.amount:,.2f}, basis {x.risk.USD_GBP_BASIS.value.amount:,.2f}; "
       f"basis gamma {x.gamma.USD_GBP_BASIS.value.amount:.4f}")
+cross = x.gamma.cross_gamma(CurveTypes.USD_OIS_SOFR, CurveTypes.USD_GBP_BASIS)     # d2 PV / d(SOFR quote) d(basis spread), per bp^2
+print(f"foreign OIS x basis cross-gamma: {cross.risk_matrix.shape[0]} x {cross.risk_matrix.shape[1]} ladder, total "
+      f"{cross.value.amount:.6f} {cross.value.currency.name}")
 c = swap.position(model).compute([RequestTypes.VALUE, RequestTypes.DELTA], collateral_type=CollateralType.USD)
 print(f"the 10Y OIS under USD collateral: PV {c.value.amount:,.2f} {c.value.currency.name} "
       f"(vs {res.value.amount / 0.79:,.2f} converted at spot), basis delta {c.risk.USD_GBP_BASIS.value.amount:,.2f} per bp")
