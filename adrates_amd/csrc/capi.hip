@@ -110,7 +110,7 @@ struct adr_trades {
     adr::LiteRowsDev lite{};
     int64_t n_lite = 0, n_nonlite = 0;
     const int32_t* list_nonlite = nullptr;
-    // ... and the trades with payment lag or per-coupon notionals and at most 60 coupons per leg as rows of the lite
+    // ... and the trades with payment lag or per-coupon notionals and at most 135 coupons per leg as rows of the lite
     // kernel's payment-lag variant; list_general_b / list_nonlite_b = list_general / list_nonlite without them
     adr::LiteRowsDev lite_lag{};
     int64_t n_lite_lag = 0, n_general_b = 0, n_nonlite_b = 0;
@@ -810,7 +810,7 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     }
     {   // lite tables (kernels.hpp, LiteRowsDev): segments of 3-, 2- and 1-row trades, longest coupon counts first -
         // one for the trades of the 32-slot row table, one (with accrual ends and notional multipliers) for trades with
-        // payment lag or per-coupon notionals of at most 60 coupons per leg (4 rows)
+        // payment lag or per-coupon notionals of at most 135 coupons per leg (9 rows)
         constexpr int S = adr::kLiteSlots, C = adr::kLiteCoupons, G = 64 / adr::kLiteSlots;
         auto lite_rows = [&](int64_t t) {
             const int64_t m = std::max(flt_off[t + 1] - flt_off[t], fix_off[t + 1] - fix_off[t]);
@@ -845,30 +845,40 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         auto build_lite = [&](std::vector<int32_t> (&seg_trades)[adr::kLiteSegments], adr::LiteRowsDev& lt, int64_t& n_out,
                               bool with_te) {
         int64_t units = 0, rows = 0;
+        int used[adr::kLiteSegments];                 // the non-empty row counts, longest first, packed to the front
+        lt.n_seg = 0;
         for (int k = 0; k < adr::kLiteSegments; ++k) {
+            lt.seg_rows[k] = 1; lt.seg_unit0[k] = 0; lt.seg_row0[k] = 0;
+            if (seg_trades[k].empty()) continue;
+            used[lt.n_seg++] = k;
+        }
+        for (int j = 0; j < lt.n_seg; ++j) {
+            const int k = used[j];
             std::stable_sort(seg_trades[k].begin(), seg_trades[k].end(), [&](int32_t a, int32_t b) {
                 return hdr[static_cast<size_t>(a)].n_flt > hdr[static_cast<size_t>(b)].n_flt;
             });
             n_out += static_cast<int64_t>(seg_trades[k].size());
-            lt.seg_rows[k] = adr::kLiteSegments - k;
-            lt.seg_unit0[k] = units;
-            lt.seg_row0[k] = rows;
+            lt.seg_rows[j] = adr::kLiteSegments - k;
+            lt.seg_unit0[j] = units;
+            lt.seg_row0[j] = rows;
             const int64_t seg_units = (static_cast<int64_t>(seg_trades[k].size()) + G - 1) / G;
             units += seg_units;
-            rows += seg_units * G * lt.seg_rows[k];
+            rows += seg_units * G * lt.seg_rows[j];
         }
+        for (int j = lt.n_seg; j < adr::kLiteSegments; ++j) { lt.seg_unit0[j] = units; lt.seg_row0[j] = rows; }   // (never reached)
         lt.n_units = units;
         if (rows * S > static_cast<int64_t>(UINT32_MAX)) { too_many_rows = true; return; }   // the kernel indexes with 32 bits
         const size_t n_slots = static_cast<size_t>(units) * G, n_rows = static_cast<size_t>(rows);
         std::vector<double> r_tpts(n_rows * S * 2, 0.0), r_alxtp(n_rows * S * 2, 0.0), r_xpay(n_rows * S, 0.0);
         std::vector<double> r_tew(with_te ? n_rows * S * 2 : 0, 0.0);
         std::vector<adr::LiteTrade> r_slot(n_slots, adr::LiteTrade{0.0, 0.0, 0, -1, 0});
-        for (int k = 0; k < adr::kLiteSegments; ++k) {
-            const int R = lt.seg_rows[k];
+        for (int j = 0; j < lt.n_seg; ++j) {
+            const int k = used[j];
+            const int R = lt.seg_rows[j];
             for (size_t i = 0; i < seg_trades[k].size(); ++i) {
                 const int64_t t = seg_trades[k][i];
-                const size_t slot = static_cast<size_t>(lt.seg_unit0[k]) * G + i;
-                const size_t row0 = static_cast<size_t>(lt.seg_row0[k]) + i * static_cast<size_t>(R);
+                const size_t slot = static_cast<size_t>(lt.seg_unit0[j]) * G + i;
+                const size_t row0 = static_cast<size_t>(lt.seg_row0[j]) + i * static_cast<size_t>(R);
                 const int64_t ml = flt_off[t + 1] - flt_off[t], mf = fix_off[t + 1] - fix_off[t];
                 for (int64_t j = 0; j < ml; ++j) {
                     const size_t at = (row0 + static_cast<size_t>(j / C)) * S + static_cast<size_t>(j % C);
@@ -968,7 +978,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     // Routing.  With GAMMA: trades without payment lag go to the fast kernel when the curve has the packed layout
     // (those with more than 32 coupons per leg as chains of rows, in a launch of their own), everything else to the
     // general kernel.  Without GAMMA (PV / PV + delta): the lite kernel takes every trade without payment lag and
-    // with at most 32 coupons per leg (with payment lag or per-coupon notionals, on a log-linear scheme: at most 60),
+    // with at most 32 coupons per leg (with payment lag or per-coupon notionals, on a log-linear scheme: at most 135),
     // whatever the curve's structure or scheme; the rest goes to
     // the chained fast kernel (packed layout) or the general kernel.
     const bool use_fast = curve->dev.packed_ok != 0;

@@ -26,7 +26,7 @@ constexpr int kLiteThreads = 512;
 constexpr int kLiteWavesPerSimd = 4;                                 // 2 blocks of 8 waves per CU (105 VGPRs)
 constexpr int kLiteSlots = 16;
 constexpr int kLiteCoupons = 15;
-constexpr int kLiteSegments = 4;                                     // trades of 4, 3, 2 and 1 rows (up to 60 coupons per leg)
+constexpr int kLiteSegments = 9;                                     // at most: trades of 9 ... 1 rows (up to 135 coupons per leg)
 
 // Per-trade header, 32 bytes, read once per trade with scalar loads.
 struct TradeHeader {
@@ -77,7 +77,7 @@ struct TradesDev {
 };
 
 // Row table of the lite kernel: the trades of the 32-slot row table (no payment lag, at most 32 coupons per leg) - or,
-// with `te_w`, trades with payment lag / per-coupon notionals of at most 60 coupons per leg -, grouped into
+// with `te_w`, trades with payment lag / per-coupon notionals of at most 135 coupons per leg -, grouped into
 // segments of equal row count (3, 2, 1 rows per trade; inside a segment sorted by coupon count), every segment padded
 // to a multiple of 4 trades (one unit = the 4 trades of a wavefront) with empty slots (trade = -1).
 struct LiteTrade {                    // 32 bytes: one 16-byte and one 8-byte load per lane
@@ -94,6 +94,7 @@ struct LiteRowsDev {
     int64_t seg_unit0[kLiteSegments]; // first unit of segment k
     int64_t seg_row0[kLiteSegments];  // first row of segment k
     int seg_rows[kLiteSegments];      // rows per trade in segment k
+    int n_seg;                        // segments in use (the non-empty ones, longest rows first): entries 0 .. n_seg - 1 above
     // row arrays, interleaved in pairs so that a lane fetches 16 bytes per load (8-byte-per-lane streams reach only
     // 0.5-0.7 of the 16-byte rate on gfx950, MI355X guide)
     const double* tp_ts;              // [n_rows][kLiteSlots][2] float payment time, accrual start time

@@ -14,7 +14,7 @@
 // (2 trades per wavefront at ~400 VALU instructions per trade), so the mapping is chosen to
 // spend as few wave-instructions per trade as possible:
 //   * a wavefront prices FOUR trades at a time, 16 lanes each, and a trade's coupons arrive as rows of 16 slots
-//     (15 coupons + a spare lane for the leg's start node; trades of 16-60 coupons are 2 to 4 consecutive rows), so
+//     (15 coupons + a spare lane for the leg's start node; longer trades are 2 to 9 consecutive rows), so
 //     half-empty 32-slot rows are neither loaded nor computed on: ~0.95 KB of row data per trade on the benchmark
 //     portfolio instead of 1.3 KB, fetched as 16-byte-per-lane loads of pair-interleaved arrays;
 //   * lanes = coupons for folding, lookup and exp; then every lane leaves its node as two 16-byte entries
@@ -25,6 +25,8 @@
 // Any curve of the three schemes qualifies (no packed layout, any pillar count up to 32).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <vector>
 
 #include "curve_lookup.hpp"
 #include "kernels.hpp"
@@ -99,7 +101,9 @@ struct CurveLds {
 // notional multiplier (`te_w`): a coupon is the ratio node N w D(ts) D(tp) / D(te) - one exponential, three lookups -
 // plus the payment node -N w (1 - spread a) D(tp).  The first-order sum is linear in a node's knot weights, so the
 // lane simply leaves three pairs of entries (ts: +, te: -, tp: + with both amounts) in three sweeps; no telescoping.
-template <bool DELTA, bool LINDF, bool LAG>
+// NSEG: segments of the row table the kernel looks at (3 covers tables of at most three distinct row counts - every
+// table of trades without payment lag; kLiteSegments otherwise)
+template <bool DELTA, bool LINDF, bool LAG, int NSEG>
 __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                                                                                        OutputsDev out) {
     static_assert(!(LAG && LINDF), "payment-lag trades under LINEAR_FWD_RATES go to the general kernel");
@@ -159,9 +163,9 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
     // All index arithmetic is 32-bit and wave-uniform (scalar unit) except one multiply-add per lane.
     const uint32_t n_units = static_cast<uint32_t>(tr.n_units);
     const uint32_t wave_stride = gridDim.x * kWavesPerBlock;
-    uint32_t seg_u0[kLiteSegments], seg_at0[kLiteSegments];
+    uint32_t seg_u0[NSEG], seg_at0[NSEG];
 #pragma unroll
-    for (int k = 0; k < kLiteSegments; ++k) {
+    for (int k = 0; k < NSEG; ++k) {
         seg_u0[k] = static_cast<uint32_t>(tr.seg_unit0[k]);
         seg_at0[k] = static_cast<uint32_t>(tr.seg_row0[k]) * L;
     }
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
         uint32_t unit0 = seg_u0[0];
         at0 = seg_at0[0];
 #pragma unroll
-        for (int k = 1; k < kLiteSegments; ++k)
+        for (int k = 1; k < NSEG; ++k)
             if (u >= seg_u0[k]) { R = tr.seg_rows[k]; unit0 = seg_u0[k]; at0 = seg_at0[k]; }
         at0 += (u - unit0) * (G * L) * R;
     };
@@ -411,6 +415,21 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
 
 }  // namespace
 
+namespace {
+using LiteFn = void (*)(CurveDev, LiteRowsDev, OutputsDev);
+
+template <bool DELTA, bool LINDF, bool LAG>
+LiteFn lite_kernel_nseg(bool many) {
+    return many ? &price_lite_kernel<DELTA, LINDF, LAG, kLiteSegments> : &price_lite_kernel<DELTA, LINDF, LAG, 3>;
+}
+
+LiteFn lite_kernel(bool delta, bool lindf, bool lag, bool many_segments) {
+    if (lag) return delta ? lite_kernel_nseg<true, false, true>(many_segments) : lite_kernel_nseg<false, false, true>(many_segments);
+    if (lindf) return delta ? lite_kernel_nseg<true, true, false>(many_segments) : lite_kernel_nseg<false, true, false>(many_segments);
+    return delta ? lite_kernel_nseg<true, false, false>(many_segments) : lite_kernel_nseg<false, false, false>(many_segments);
+}
+}  // namespace
+
 size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta) {
     size_t bytes = delta ? static_cast<size_t>(kWavesPerBlock) * kRecBytesPerWave + sizeof(double) * cv.Kc * kPillarPad : 0;
     bytes += sizeof(double) * (2 * static_cast<size_t>(cv.K) + 2 * cv.Kc);
@@ -424,27 +443,18 @@ hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const Ou
                              int n_blocks, hipStream_t stream) {
     const size_t lds = lite_kernel_lds_bytes(cv, want_delta);
     const dim3 grid(n_blocks), block(kBlockThreads);
-    if (tr.te_w) {                     // payment-lag rows
-        if (cv.method == 2) return hipErrorInvalidValue;
-        if (want_delta) hipLaunchKernelGGL((price_lite_kernel<true, false, true>), grid, block, lds, stream, cv, tr, out);
-        else hipLaunchKernelGGL((price_lite_kernel<false, false, true>), grid, block, lds, stream, cv, tr, out);
-    } else if (cv.method == 2) {
-        if (want_delta) hipLaunchKernelGGL((price_lite_kernel<true, true, false>), grid, block, lds, stream, cv, tr, out);
-        else hipLaunchKernelGGL((price_lite_kernel<false, true, false>), grid, block, lds, stream, cv, tr, out);
-    } else {
-        if (want_delta) hipLaunchKernelGGL((price_lite_kernel<true, false, false>), grid, block, lds, stream, cv, tr, out);
-        else hipLaunchKernelGGL((price_lite_kernel<false, false, false>), grid, block, lds, stream, cv, tr, out);
-    }
+    if (tr.te_w && cv.method == 2) return hipErrorInvalidValue;        // payment-lag rows: log-linear schemes only
+    hipLaunchKernelGGL(lite_kernel(want_delta, cv.method == 2, tr.te_w != nullptr, tr.n_seg > 3), grid, block, lds, stream, cv, tr, out);
     return hipGetLastError();
 }
 
 hipError_t set_lite_kernel_lds_limit(size_t bytes) {
-    const void* fns[] = {reinterpret_cast<const void*>(&price_lite_kernel<true, false, false>),
-                         reinterpret_cast<const void*>(&price_lite_kernel<false, false, false>),
-                         reinterpret_cast<const void*>(&price_lite_kernel<true, true, false>),
-                         reinterpret_cast<const void*>(&price_lite_kernel<false, true, false>),
-                         reinterpret_cast<const void*>(&price_lite_kernel<true, false, true>),
-                         reinterpret_cast<const void*>(&price_lite_kernel<false, false, true>)};
+    std::vector<const void*> fns;
+    for (int d = 0; d < 2; ++d)
+        for (int lin = 0; lin < 2; ++lin)
+            for (int lag = 0; lag < 2; ++lag)
+                for (int many = 0; many < 2; ++many)
+                    if (!(lin && lag)) fns.push_back(reinterpret_cast<const void*>(lite_kernel(d != 0, lin != 0, lag != 0, many != 0)));
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
         if (e != hipSuccess) return e;
