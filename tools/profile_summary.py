@@ -23,6 +23,18 @@ for r in csv.DictReader(open(stats)):
         out["kernel"] = r["Name"].split("(")[0]
         out["avg_ns"] = float(r["AverageNs"]); out["calls"] = int(r["Calls"])
         out["min_ns"] = float(r["MinNs"]); out["max_ns"] = float(r["MaxNs"])
+# the timed region alone: the last `steps` launches of the kernel in the trace (the all-launch average of the stats file
+# also holds the ~90 warm-up launches, the first of them on a cold clock)
+try:
+    trace = newest(f"{base}/trace/*/*kernel_trace.csv")
+    rows = [r for r in csv.DictReader(open(trace)) if "price_" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    steps = 20
+    last = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[-steps:]]
+    out["timed_region_launches"] = len(last)
+    out["avg_ns_timed_region"] = sum(last) / len(last)
+except (ValueError, OSError, KeyError):
+    pass
 # bench.py's own HIP-event kernel time inside the profiled (kernel-trace) run: must agree with rocprofv3's average
 import re
 try:
