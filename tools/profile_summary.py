@@ -30,6 +30,13 @@ try:
     rows = [r for r in csv.DictReader(open(trace)) if "price_" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     steps = 20
+    try:
+        import re as _re
+        m_ = _re.search(r'"steps": ([0-9]+)', open(f"{base}.trace.log").read())
+        if m_:
+            steps = int(m_.group(1))
+    except OSError:
+        pass
     last = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[-steps:]]
     out["timed_region_launches"] = len(last)
     out["avg_ns_timed_region"] = sum(last) / len(last)
