@@ -428,7 +428,8 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
         // (Carrying the right knot's Jacobian entries to the next node as well - one LDS read less per node - was
         // measured 7 % SLOWER: the select and its branch sit on the node's critical path.  Requesting the NEXT node's
         // Jacobian entries inside the current node's rank-one update, so that the record -> rows round trip leaves the
-        // head of a node's chain: 1-4 % slower, at the same 167 registers.)
+        // head of a node's chain: 1-4 % slower, at the same 167 registers.  Reading the right knot's convexity row in the
+        // rank-one update's batches as well, instead of carrying it: 5 % slower, 12 bytes of scratch.)
         auto lc_row_pass = [&](int row, double w) {
             double lr[CPG > 0 ? CPG : 1];
             if (HUB) {
