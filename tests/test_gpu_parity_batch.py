@@ -285,6 +285,69 @@ def test_long_legs_as_row_chains_vs_c_oracle(gpu_ctx):
     print(f"long legs: worst error {worst:.2e}")
 
 
+def test_payment_lag_properties_at_scale(gpu_ctx):
+    """200 000 annual payment-lag trades plus 20 000 quarterly ones (chained rows) - the sizes of the payment-lag
+    benches - through properties that need no oracle: pay / receive antisymmetry and exact doubling (bitwise: signs
+    and powers of two commute with every operation of the kernels, the patched elements included), aggregate == sum of
+    the per-trade ladders, symmetric gammas; PV + delta alone (lite kernel's payment-lag rows) equals the full request's."""
+    import torch
+    from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
+    from adrates_amd.utils import BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes
+    vd = F.README_VALUE_DT
+    curve = F.readme_model().curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    rng = np.random.default_rng(8)
+    n_a, n_q = 200_000, 20_000
+    n = n_a + n_q
+    months = np.concatenate((rng.integers(1, 361, n_a), rng.integers(120, 361, n_q)))
+    table = [f"{m}M" for m in range(1, 361)]
+    freq = (np.concatenate((np.zeros(n_a, dtype=np.int64), np.ones(n_q, dtype=np.int64))),
+            [FrequencyTypes.ANNUAL, FrequencyTypes.QUARTERLY])
+    terms = OISTerms(effective_dt=vd, tenor=(months - 1, table), coupon=rng.uniform(0.01, 0.07, n),
+                     notional=np.round(rng.uniform(1e6, 5e7, n), -5), pay_fixed=rng.random(n) < 0.5,
+                     fixed_freq_type=FrequencyTypes.ANNUAL, fixed_dc_type=DayCountTypes.ACT_365F,
+                     floating_index=CurveTypes.GBP_OIS_SONIA, currency=CurrencyTypes.GBP, float_freq_type=freq,
+                     float_dc_type=DayCountTypes.ACT_365F, float_spread=np.where(rng.random(n) < 0.3, 0.002, 0.0),
+                     payment_lag=2, bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
+    batch = compile_ois_terms(terms, vd)
+    P = dc.n_pillars
+    dev = torch.device("cuda", 0)
+
+    def run(b, mask=7):
+        dt = _native.DeviceTrades(gpu_ctx, b)
+        pv = torch.empty(n, dtype=torch.float64, device=dev)
+        de = torch.empty((n, P), dtype=torch.float64, device=dev)
+        ga = torch.zeros((n, P, P), dtype=torch.float64, device=dev) if mask & 4 else None
+        ag = torch.empty(1 + P + P * P, dtype=torch.float64, device=dev)
+        _native.price_dev(gpu_ctx, dc, dt, mask, pv.data_ptr(), de.data_ptr(), ga.data_ptr() if ga is not None else 0, ag.data_ptr())
+        gpu_ctx.sync()
+        dt.close()
+        return pv, de, ga, ag
+
+    pv, de, ga, ag = run(batch)
+    asym = (ga - ga.transpose(1, 2)).abs().amax(dim=(1, 2)) / ga.abs().amax(dim=(1, 2)).clamp_min(1e-300)
+    assert float(asym.max()) <= REL_TOL
+    assert float((ag[1 + P:].view(P, P) - ga.sum(0)).abs().max()) <= 1e-10 * float(ga.abs().sum(0).max())
+    assert float((ag[1:1 + P] - de.sum(0)).abs().max()) <= 1e-10 * float(de.abs().sum(0).max())
+    assert abs(float(ag[0] - pv.sum())) <= 1e-10 * float(pv.abs().sum())
+    pv_d, de_d, _, ag_d = run(batch, mask=3)                       # another kernel, another order of operations
+    assert float((pv_d - pv).abs().max()) <= 1e-10 * float(pv.abs().max())
+    assert float((de_d - de).abs().max()) <= 1e-10 * float(de.abs().max())
+    assert float((ag_d[1:1 + P] - ag[1:1 + P]).abs().max()) <= 1e-10 * float(ag[1:1 + P].abs().max())
+    del pv_d, de_d
+    flipped = TradeBatch(batch.fix_off, batch.flt_off, batch.fix_tp, batch.fix_pay, batch.flt_tp, batch.flt_ts,
+                         batch.flt_te, batch.flt_alpha, batch.notional, batch.spread, -batch.fix_sign, -batch.flt_sign)
+    pv2, de2, ga2, _ = run(flipped)
+    assert float((pv + pv2).abs().max()) == 0.0 and float((de + de2).abs().max()) == 0.0
+    assert float((ga + ga2).abs().max()) == 0.0
+    del pv2, de2, ga2
+    doubled = TradeBatch(batch.fix_off, batch.flt_off, batch.fix_tp, 2.0 * batch.fix_pay, batch.flt_tp, batch.flt_ts,
+                         batch.flt_te, batch.flt_alpha, 2.0 * batch.notional, batch.spread, batch.fix_sign,
+                         batch.flt_sign)
+    pv3, de3, ga3, _ = run(doubled)
+    assert torch.equal(pv3, 2.0 * pv) and torch.equal(de3, 2.0 * de) and torch.equal(ga3, 2.0 * ga)
+
+
 @pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES])
 def test_long_legs_with_payment_lag_vs_c_oracle(gpu_ctx, interp):
     """Payment-lag legs of 33-128 coupons (quarterly / semi-annual / monthly floats paid 1-3 business days late): chains
