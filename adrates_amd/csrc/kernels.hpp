@@ -8,6 +8,12 @@
 #ifndef ADR_FAST_THREADS
 #define ADR_FAST_THREADS 768
 #endif
+#ifndef ADR_OUT_PRIO
+#define ADR_OUT_PRIO 3      // fast kernel: wave priority during the output phase (next unit's loads, expansion, stores): -2 % on the bench pass
+#endif
+#ifndef ADR_WALK_PRIO
+#define ADR_WALK_PRIO 1     // ... during the node walk (between the build phase at 0 and the output phase): another -2 %
+#endif
 #ifndef ADR_FAST_BATCH
 #define ADR_FAST_BATCH 4    // packed entries whose LDS operands are fetched together
 #endif

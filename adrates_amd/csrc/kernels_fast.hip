@@ -580,6 +580,9 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
             for (int off = L; off < 64; off <<= 1) any_row |= any_row >> off;
             any_row &= kGroupMask;
             if (!any_row) continue;
+#if ADR_WALK_PRIO
+            if (GAMMA) __builtin_amdgcn_s_setprio(ADR_WALK_PRIO);
+#endif
             int n = __builtin_ctzll(any_row);
             any_row &= any_row - 1;
             const double2* rec_g = reinterpret_cast<const double2*>(rec + gbase * 4);
@@ -821,6 +824,9 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                 }
             }
 
+#if ADR_WALK_PRIO
+            if (GAMMA) __builtin_amdgcn_s_setprio(0);
+#endif
             ADR_STAMP(3);   // node consumption
         }
         if (GAMMA && __ballot(carry_row != zero_row)) lc_row_pass(carry_row, carry_w);
@@ -862,6 +868,9 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
         // ---- inputs of the wave's next unit, requested before this unit's (large) gamma stores
         if (GAMMA) load_unit(unit + wave_stride);
 
+#if ADR_OUT_PRIO
+        if (GAMMA) __builtin_amdgcn_s_setprio(ADR_OUT_PRIO);
+#endif
         if (GAMMA) {
 #pragma unroll
             for (int gg = 0; gg < G; ++gg) {
@@ -937,6 +946,9 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                 }
             }
         }
+#if ADR_OUT_PRIO
+        if (GAMMA) __builtin_amdgcn_s_setprio(0);
+#endif
         ADR_STAMP(4);   // outputs
         pin_next();
     }
