@@ -14,6 +14,12 @@
 #ifndef ADR_WALK_PRIO
 #define ADR_WALK_PRIO 1     // ... during the node walk (between the build phase at 0 and the output phase): another -2 %
 #endif
+#ifndef ADR_LITE_SWEEP_PRIO
+#define ADR_LITE_SWEEP_PRIO 1     // lite kernel: wave priority during the entry sweeps (-3 % on the PV + delta pass)
+#endif
+#ifndef ADR_LITE_OUT_PRIO
+#define ADR_LITE_OUT_PRIO 0
+#endif
 #ifndef ADR_FAST_BATCH
 #define ADR_FAST_BATCH 4    // packed entries whose LDS operands are fetched together
 #endif

@@ -280,6 +280,9 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
             // the first of a run - is never the next node's left-hand knot - the last of that run -, so merging
             // neighbours' entries buys nothing: tried, slower.)
             auto sweep = [&](bool on, double ca, double cb, int off_a, int off_b) {
+#if ADR_LITE_SWEEP_PRIO
+                __builtin_amdgcn_s_setprio(ADR_LITE_SWEEP_PRIO);
+#endif
                 __builtin_amdgcn_wave_barrier();
                 {
                     double2* wp = reinterpret_cast<double2*>(rec_mine);
@@ -290,7 +293,12 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                 unsigned long long any = __ballot(on);
                 any |= any >> 32; any |= any >> 16;
                 const unsigned rows_any = static_cast<unsigned>(any) & 0xffffu;
-                if (!rows_any) return;
+                if (!rows_any) {
+#if ADR_LITE_SWEEP_PRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
+                    return;
+                }
                 const int n_e = 2 * (32 - __builtin_clz(rows_any));      // entries up to the highest live lane of any row
                 for (int e = 0; e < n_e; e += kBatch) {                   // lanes past n_e wrote zero entries
                     double2 rc[kBatch], rw[kBatch];
@@ -304,6 +312,9 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                         else { d0 = fma(rc[i].x, rw[i].x, d0); d1 = fma(rc[i].x, rw[i].y, d1); }
                     }
                 }
+#if ADR_LITE_SWEEP_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             };
             if (LAG) {
                 // ---- the row's coupons: ratio node + payment node (lane = coupon); three lookups, two exponentials
@@ -362,6 +373,9 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
         if (!last_row) { ++r; continue; }
 
         // ---- results of the unit's trades
+#if ADR_LITE_OUT_PRIO
+        __builtin_amdgcn_s_setprio(ADR_LITE_OUT_PRIO);
+#endif
         pv = row_sum(pv);
         if (live && l == 0) {
             if (out.pv) out.pv[t] = pv;
@@ -381,6 +395,9 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
             }
         }
         unit = next_unit; R = next_R; at0 = next_at0; r = 0;
+#if ADR_LITE_OUT_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         ADR_STAMP(4);   // outputs
     }
 #ifdef ADR_STAMPS
