@@ -20,6 +20,9 @@
 #ifndef ADR_LITE_OUT_PRIO
 #define ADR_LITE_OUT_PRIO 0
 #endif
+#ifndef ADR_BUILD_PRIO
+#define ADR_BUILD_PRIO 0    // ... during folding, lookups and exponentials
+#endif
 #ifndef ADR_FAST_BATCH
 #define ADR_FAST_BATCH 4    // packed entries whose LDS operands are fetched together
 #endif

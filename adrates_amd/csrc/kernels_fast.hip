@@ -420,6 +420,9 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
         for (int k = 0; k < PPL; ++k) vacc[k] = 0.0;
         if (!LONG || fresh) n_special = 0;
         const bool more_starts = __ballot(own_start) != 0, more_fixed = __ballot(own_fixed) != 0;
+#if ADR_BUILD_PRIO
+        if (GAMMA) __builtin_amdgcn_s_setprio(ADR_BUILD_PRIO);
+#endif
         ADR_STAMP(1);   // node folding
 
         // convexity row whose weight is still to be added (see the consume loop), per group
@@ -824,8 +827,8 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                 }
             }
 
-#if ADR_WALK_PRIO
-            if (GAMMA) __builtin_amdgcn_s_setprio(0);
+#if ADR_WALK_PRIO || ADR_BUILD_PRIO
+            if (GAMMA) __builtin_amdgcn_s_setprio(ADR_BUILD_PRIO);
 #endif
             ADR_STAMP(3);   // node consumption
         }
