@@ -12,7 +12,8 @@
 #define ADR_OUT_PRIO 3      // fast kernel: wave priority during the output phase (next unit's loads, expansion, stores): -2 % on the bench pass
 #endif
 #ifndef ADR_WALK_PRIO
-#define ADR_WALK_PRIO 1     // ... during the node walk (between the build phase at 0 and the output phase): another -2 %
+#define ADR_WALK_PRIO 3     // ... during the node walk outside the rank-one update (record, Jacobian rows, v, hand-off: the
+                            // latency chain of a node); with the output phase at 3 and the rest at 0 / 1: another -3 %
 #endif
 #ifndef ADR_LITE_SWEEP_PRIO
 #define ADR_LITE_SWEEP_PRIO 1     // lite kernel: wave priority during the entry sweeps (-3 % on the PV + delta pass)
@@ -22,6 +23,9 @@
 #endif
 #ifndef ADR_BUILD_PRIO
 #define ADR_BUILD_PRIO 0    // ... during folding, lookups and exponentials
+#endif
+#ifndef ADR_RANK_PRIO
+#define ADR_RANK_PRIO 1     // ... inside the rank-one update (the gathers and FMAs: the walk's throughput part)
 #endif
 #ifndef ADR_FAST_BATCH
 #define ADR_FAST_BATCH 4    // packed entries whose LDS operands are fetched together

@@ -690,6 +690,9 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
 #pragma unroll
                     for (int k = 0; k < PPL; ++k) vbuf[l + L * k] = vv_[k];
                     wave_lds_sync();
+#if ADR_RANK_PRIO
+                    __builtin_amdgcn_s_setprio(ADR_RANK_PRIO);
+#endif
                     const double* rowa = c.lcc + __mul24(row, c.ec_stride) + (HUB ? 0 : l);
                     // All operands of a batch of entries are fetched before any of them is used: the scheduling barrier
                     // keeps the compiler from pairing each LDS read with its FMA (which would expose one LDS round trip
@@ -723,6 +726,9 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+#if ADR_RANK_PRIO
+                    __builtin_amdgcn_s_setprio(ADR_WALK_PRIO);
+#endif
                 };
                 auto rank_one = [&](auto with_row, double om_r, const double (&vv_)[PPL], double coa) {
                     rank_one_row(with_row, om_r, vv_, coa, ra);
