@@ -55,8 +55,6 @@ struct adr_ctx {
     double* dump = nullptr;                 // [32*32] store sink (kernels.hpp, OutputsDev::dump)
     unsigned long long* stamps = nullptr;   // diagnostic builds: [max_blocks*16][8]
     int max_blocks = 0;
-    double* lag_scratch = nullptr;          // payment-lag variant of the fast kernel: per-wave stash (kernels.hpp), allocated
-    int lag_blocks = 0;                     // with the first batch that has such trades; the grid it was sized for
 };
 
 struct adr_curve {
@@ -106,6 +104,10 @@ struct adr_trades {
     adr::TradesDev lagged_chained{};   // ... those of 33-128 coupons per leg as chains of rows (LONG + LAG), laid out for
     int lagged_chained_blocks = 0;     // this grid
     int64_t n_lagged = 0, n_lagged_long = 0, n_rest = 0;
+    // per-wave stash of the payment-lag variant (kernels.hpp, OutputsDev::lag_scratch), sized for a grid of lag_blocks
+    // blocks.  It belongs to the BATCH (not to the ctx): two batches priced on two streams never share it.
+    double* lag_scratch = nullptr;
+    int lag_blocks = 0;
     const int32_t* list_rest = nullptr;
     adr::LiteRowsDev lite{};
     int64_t n_lite = 0, n_nonlite = 0;
@@ -186,7 +188,6 @@ void adr_free_ctx(adr_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->dump) hipFree(ctx->dump);
-    if (ctx->lag_scratch) hipFree(ctx->lag_scratch);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -792,11 +793,10 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     }
     if (!list_lagged.empty() || !list_lagged_long.empty()) {
         const int blocks = std::max(1, ctx->n_cu);
-        if (e == hipSuccess && ctx->lag_blocks < blocks) {
-            if (ctx->lag_scratch) hipFree(ctx->lag_scratch);
-            ctx->lag_scratch = nullptr; ctx->lag_blocks = 0;
-            e = hipMalloc(reinterpret_cast<void**>(&ctx->lag_scratch), adr::fast_kernel_lag_scratch_bytes(blocks));
-            if (e == hipSuccess) ctx->lag_blocks = blocks;
+        if (e == hipSuccess) {
+            void* p = nullptr;
+            e = hipMalloc(&p, adr::fast_kernel_lag_scratch_bytes(blocks));
+            if (e == hipSuccess) { tr->allocations.push_back(p); tr->lag_scratch = static_cast<double*>(p); tr->lag_blocks = blocks; }
         }
     }
     if (!list_lagged.empty()) {   // payment-lag rows: one row per trade, sorted by coupon count like the plain table
@@ -951,15 +951,18 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         const int threads = adr::kGeneralThreads;
         const int64_t need = (n + threads / 64 - 1) / (threads / 64);
         const int blocks = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * 4));
-        const int n_launch = want_gamma ? T * (T + 1) / 2 : T;
+        const int n_launch = want_gamma ? T * (T + 1) / 2 : (want_delta ? T : 1);
         if (blocks * n_launch > ctx->max_blocks) return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
         adr::TradesDev all = trades->dev;
         all.list = nullptr; all.n_list = n;
         const size_t pair_tile = static_cast<size_t>(curve->dev.Kc) * 64 * adr::kGammaPerLane;
         int launch = 0;
+        if (agg_dev)   // tiles no launch covers (no GAMMA: the off-diagonal ones; PV alone: every delta tile) stay zero
+            ADR_HIP(hipMemsetAsync(agg_dev, 0, sizeof(double) * (1 + P + static_cast<size_t>(P) * P), stream));
         for (int tj = 0; tj < T; ++tj)
             for (int ti = 0; ti <= tj; ++ti) {
                 if (!want_gamma && ti != tj) continue;               // PV / delta live on the diagonal tiles
+                if (!want_delta && tj > 0) continue;                 // PV alone: tile (0, 0) has it
                 adr::CurveDev cv = curve->dev;
                 cv.tile_i = ti; cv.tile_j = tj;
                 if (cv.lc_lanes) cv.lc_lanes += static_cast<size_t>(adr::tile_pair(ti, tj)) * pair_tile;
@@ -970,8 +973,6 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
                     ADR_HIP(adr::launch_reduce_partials(o.block_partials, blocks, P, want_gamma, agg_dev, stream, ti, tj));
                 ++launch;
             }
-        if (agg_dev && !want_gamma)       // no off-diagonal launches ran: the gamma part of the aggregate is all zero
-            ADR_HIP(hipMemsetAsync(agg_dev + 1 + P, 0, sizeof(double) * static_cast<size_t>(P) * P, stream));
         return ADR_OK;
     }
 
@@ -982,16 +983,19 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     // whatever the curve's structure or scheme; the rest goes to
     // the chained fast kernel (packed layout) or the general kernel.
     const bool use_fast = curve->dev.packed_ok != 0;
-    const bool use_lite = !want_gamma && trades->lite.n_units > 0;
+    // (a large curve that uploads fine for the general kernel can still be too big for the lite kernel's LDS image,
+    // which adds per-wave record slots and 1/dx: such a curve leaves its PV / delta requests to the other kernels)
+    const bool lite_fits = adr::lite_kernel_lds_bytes(curve->dev, want_delta) <= kLdsBudget;
+    const bool use_lite = !want_gamma && lite_fits && trades->lite.n_units > 0;
     adr::TradesDev fast = trades->dev, chained = trades->chained, general = trades->dev, lagged = trades->lagged,
                    lagged_long = trades->lagged_chained;
     // (the payment-lag variant's ratio nodes are single exponentials: not under LINEAR_FWD_RATES, which go to the general kernel)
-    const bool use_lag = want_gamma && use_fast && (lagged.n_rows > 0 || lagged_long.n_rows > 0) && ctx->lag_scratch != nullptr &&
+    const bool use_lag = want_gamma && use_fast && (lagged.n_rows > 0 || lagged_long.n_rows > 0) && trades->lag_scratch != nullptr &&
                          curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES &&
-                         trades->lagged_chained_blocks <= ctx->lag_blocks;
+                         trades->lagged_chained_blocks <= trades->lag_blocks;
     if (!use_lag) { lagged.n_rows = 0; lagged_long.n_rows = 0; }
     // (the lite kernel's payment-lag rows: PV / PV + delta of trades with payment lag or per-coupon notionals, log-linear schemes)
-    const bool use_lite_lag = !want_gamma && trades->lite_lag.n_units > 0 && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
+    const bool use_lite_lag = !want_gamma && lite_fits && trades->lite_lag.n_units > 0 && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
     if (use_lite || use_lite_lag) {
         if (use_lite) fast.n_rows = 0;                     // the lite table holds exactly the 32-slot row table's trades
         if (use_fast) {                                    // long trades keep their chained rows
@@ -1018,7 +1022,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         const int waves = adr::fast_kernel_threads(true) / 64;
         const int64_t units = (lagged.n_rows + adr::fast_kernel_groups() - 1) / adr::fast_kernel_groups();
         const int64_t need = (units + waves - 1) / waves;
-        blocks_lag = static_cast<int>(std::min<int64_t>(need, std::min(ctx->lag_blocks, ctx->n_cu)));
+        blocks_lag = static_cast<int>(std::min<int64_t>(need, std::min(trades->lag_blocks, ctx->n_cu)));
     }
     if (use_lite) {
         const size_t lds = adr::lite_kernel_lds_bytes(curve->dev, want_delta);
@@ -1068,7 +1072,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     }
     if (blocks_lag > 0) {
         o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general);
-        o.lag_scratch = ctx->lag_scratch;
+        o.lag_scratch = trades->lag_scratch;
         ADR_HIP(adr::launch_price_fast(curve->dev, lagged, o, want_delta, want_gamma, blocks_lag, stream));
     }
     if (blocks_litelag > 0) {
@@ -1077,7 +1081,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     }
     if (blocks_laglong > 0) {
         o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag);
-        o.lag_scratch = ctx->lag_scratch;
+        o.lag_scratch = trades->lag_scratch;
         ADR_HIP(adr::launch_price_fast(curve->dev, lagged_long, o, want_delta, want_gamma, blocks_laglong, stream));
     }
     if (agg_dev)

@@ -475,12 +475,28 @@ def price_xccy_batch(engine, swaps, reqs, per_trade=True, aggregate=False, cross
     return out
 
 
+# What `Risk.cross_gamma(foreign OIS, basis)` of a GAMMA request holds:
+#   "direct" (default) - d2 PV / d r_for d s_basis with the XCCY curve's knot DFs held fixed w.r.t. the foreign curve:
+#                        sum_j grad_r[N D_f(ts_j)/D_f(te_j)] (x) grad_s[D_x(tp_j)] (`cross_gamma_for_basis`); the matrix is
+#                        labelled `definition="direct"`.  NOT the reference's block (engine.py:1892-1958), which keeps
+#                        only the bootstrap's mixed-Hessian term and contracts tensors of different sizes;
+#   "off"              - no cross-gamma is attached (`has_cross_gamma` is False), for consumers that compare slot by slot
+#                        with the reference and would otherwise read a differently defined number.
+# Like the reference (engine.py:1894) nothing is attached when the XCCY curve carries no `_mixed_hess_foreign_basis`.
+CROSS_GAMMA_MODE = "direct"
+
+
 def compute_xccy(engine, derivative, reqs):
     if RequestTypes.CASHFLOWS in reqs:
         # the reference's block for this request (engine.py:1970-1986) ends in a NameError (`risk_ccy` is never
         # assigned in _compute_xccy), so there is no behaviour to mirror
         raise NotImplementedError("CASHFLOWS is not available for cross-currency swaps")
-    res = price_xccy_batch(engine, [derivative], reqs, cross_gamma=True)
+    model = engine.model
+    x_name = f"{derivative._foreign_currency.name}_{derivative._domestic_currency.name}_BASIS"
+    x_curve = getattr(model.curves, x_name, None)             # (a missing curve is reported by `_curves_for` below)
+    attach = (CROSS_GAMMA_MODE == "direct" and RequestTypes.GAMMA in reqs
+              and getattr(x_curve, "_mixed_hess_foreign_basis", None) is not None)
+    res = price_xccy_batch(engine, [derivative], reqs, cross_gamma=attach)
     ccy = derivative._domestic_currency
     curves = (derivative._domestic_floating_index, derivative._foreign_floating_index, CurveTypes.USD_GBP_BASIS)
     value = delta = gamma = None
@@ -490,12 +506,14 @@ def compute_xccy(engine, derivative, reqs):
         delta = Risk([Delta(np.array(res[k][0]), t, ccy, c)
                       for k, t, c in zip(("delta_dom", "delta_for", "delta_basis"), res["tenors"], curves)])
     if RequestTypes.GAMMA in reqs:
-        cross = CrossGamma(risk_matrix=np.array(res["cross_for_basis"][0]), tenors_curve1=res["tenors"][1],
-                           tenors_curve2=res["tenors"][2], curve_type_1=derivative._foreign_floating_index,
-                           curve_type_2=CurveTypes.USD_GBP_BASIS, currency=ccy)
+        cross = None
+        if attach:
+            cross = [CrossGamma(risk_matrix=np.array(res["cross_for_basis"][0]), tenors_curve1=res["tenors"][1],
+                                tenors_curve2=res["tenors"][2], curve_type_1=derivative._foreign_floating_index,
+                                curve_type_2=CurveTypes.USD_GBP_BASIS, currency=ccy, definition="direct")]
         gamma = Risk([Gamma(np.array(res[k][0]), t, ccy, c)
                       for k, t, c in zip(("gamma_dom", "gamma_for", "gamma_basis"), res["tenors"], curves)],
-                     cross_gammas=[cross])
+                     cross_gammas=cross)
     return AnalyticsResult(value=value, risk=delta, gamma=gamma)
 
 

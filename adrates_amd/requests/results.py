@@ -222,6 +222,9 @@ class CrossGamma:
     curve_type_1: Any
     curve_type_2: Any
     currency: Any
+    # what the matrix holds when it is not the reference's own block (None = as the reference defines it); the
+    # cross-currency engine labels its foreign OIS x basis matrix "direct" (xccy_engine.CROSS_GAMMA_MODE)
+    definition: Any = None
 
     def __post_init__(self):
         arr = np.asarray(self.risk_matrix, dtype=np.float64)

@@ -68,8 +68,10 @@ def test_forty_pillar_curve_vs_c_oracle(gpu_ctx, interp):
     only_d = _native.price(gpu_ctx, dc, dt, want_gamma=False, aggregate=True)
     assert_batch_parity(only_d, dict(pv=ref["pv"], delta=ref["delta"]), batch.notional)
     assert np.allclose(only_d["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6) and np.all(only_d["agg_gamma"] == 0.0)
-    only_v = _native.price(gpu_ctx, dc, dt, want_delta=False, want_gamma=False)
+    only_v = _native.price(gpu_ctx, dc, dt, want_delta=False, want_gamma=False, aggregate=True)   # one launch: tile (0, 0)
     assert_batch_parity(only_v, dict(pv=ref["pv"]), batch.notional)
+    assert np.allclose(only_v["agg_pv"], ref["pv"].sum(), rtol=1e-10, atol=1e-3)
+    assert np.all(only_v["agg_delta"] == 0.0) and np.all(only_v["agg_gamma"] == 0.0)
     dt.close()
     print(f"40 pillars, {interp.name}: worst error {worst:.2e}")
 

@@ -439,3 +439,53 @@ def test_random_curves_and_portfolios_vs_c_oracle(gpu_ctx, seed):
         assert np.max(np.abs(again[k] - got[k])) <= 1e-12 * scale
     cset.close(); plan.close()
     print(f"seed {seed} ({interp.name}, level {level:.2f}%): worst error {worst:.2e}")
+
+
+def test_two_payment_lag_batches_on_two_streams_of_one_ctx(gpu_ctx):
+    """include/adrates.h, stream rule of adr_price_dev: calls without an aggregate may run concurrently on any streams
+    of one ctx.  The payment-lag variant's per-wave stash belongs to the batch (`adr_trades`), so two such batches
+    priced at the same time on two streams give exactly what they give one after the other."""
+    import torch
+    from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
+    from adrates_amd.utils import BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes
+    vd = F.README_VALUE_DT
+    curve = F.readme_model().curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    dev = torch.device("cuda", 0)
+    P = 32
+
+    def lagged_batch(seed, n):
+        rng = np.random.default_rng(seed)
+        terms = OISTerms(effective_dt=vd, tenor=[f"{int(m)}M" for m in rng.integers(1, 361, n)],
+                         coupon=rng.uniform(0.01, 0.07, n), notional=np.round(rng.uniform(1e6, 5e7, n), -5),
+                         pay_fixed=rng.random(n) < 0.5, fixed_freq_type=FrequencyTypes.ANNUAL,
+                         fixed_dc_type=DayCountTypes.ACT_365F, floating_index=CurveTypes.GBP_OIS_SONIA,
+                         currency=CurrencyTypes.GBP,
+                         float_freq_type=[[FrequencyTypes.ANNUAL, FrequencyTypes.QUARTERLY][i] for i in rng.choice(2, size=n, p=[0.8, 0.2])],
+                         float_dc_type=DayCountTypes.ACT_365F, payment_lag=2, bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
+        return compile_ois_terms(terms, vd)
+
+    n = 60_000
+    batches = [lagged_batch(101, n), lagged_batch(202, n)]
+    trades = [_native.DeviceTrades(gpu_ctx, b) for b in batches]
+    out = [[torch.empty(n, dtype=torch.float64, device=dev), torch.empty((n, P), dtype=torch.float64, device=dev),
+            torch.empty((n, P, P), dtype=torch.float64, device=dev)] for _ in range(4)]
+
+    def launch(k, slot, stream):
+        pv, de, ga = out[slot]
+        _native.price_dev(gpu_ctx, dc, trades[k], 7, pv.data_ptr(), de.data_ptr(), ga.data_ptr(), 0, stream.cuda_stream)
+
+    s0, s1 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    launch(0, 0, s0); s0.synchronize()                 # serial reference results
+    launch(1, 1, s0); s0.synchronize()
+    for _ in range(3):                                 # concurrent: both launches in flight together
+        launch(0, 2, s0); launch(1, 3, s1)
+    s0.synchronize(); s1.synchronize()
+    for k in range(2):
+        for a, b in zip(out[k], out[2 + k]):
+            assert torch.equal(a, b)
+    ref = port.price(4, host.times, host.dfs, host.jac, host.hess, batches[1])
+    got = dict(pv=out[3][0].cpu().numpy(), delta=out[3][1].cpu().numpy(), gamma=out[3][2].cpu().numpy())
+    assert_batch_parity(got, ref, batches[1].notional)
+    for t in trades:
+        t.close()

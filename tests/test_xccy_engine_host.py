@@ -397,3 +397,23 @@ def test_cross_gamma_is_the_bump_of_the_basis_delta(host_engine):
         assert np.max(np.abs(out["cross_for_basis"][i] - w)) <= 1e-10 * max(np.max(np.abs(w)), 1e-12 * abs(book[i]._domestic_leg._notional))
     tot = sum(wants)
     assert np.max(np.abs(out["agg_cross_for_basis"] - tot)) <= 1e-10 * np.max(np.abs(tot))
+
+
+def test_cross_gamma_is_labelled_and_can_be_switched_off(host_engine, monkeypatch):
+    """The foreign OIS x basis matrix is not the reference's block (engine.py:1892-1958): it says so
+    (`definition == "direct"`), is attached under the reference's condition (the XCCY curve carries
+    `_mixed_hess_foreign_basis`, :1894) and `xccy_engine.CROSS_GAMMA_MODE = "off"` leaves the slot empty."""
+    m = host_engine
+    swap = _swap("5Y", 0.003, notional=10_000_000)
+    reqs = [RequestTypes.VALUE, RequestTypes.GAMMA]
+    res = swap.position(m).compute(reqs)
+    cross = res.gamma.cross_gamma(CurveTypes.USD_OIS_SOFR, CurveTypes.USD_GBP_BASIS)
+    assert cross is not None and cross.definition == "direct"
+    monkeypatch.setattr(xccy_engine, "CROSS_GAMMA_MODE", "off")
+    off = swap.position(m).compute(reqs)
+    assert not off.gamma.has_cross_gamma(CurveTypes.USD_OIS_SOFR, CurveTypes.USD_GBP_BASIS)
+    assert np.array_equal(off.gamma(CurveTypes.USD_GBP_BASIS).risk_ladder, res.gamma(CurveTypes.USD_GBP_BASIS).risk_ladder)
+    monkeypatch.setattr(xccy_engine, "CROSS_GAMMA_MODE", "direct")
+    x = m.curves.USD_GBP_BASIS
+    monkeypatch.setattr(x, "_mixed_hess_foreign_basis", None)
+    assert not swap.position(m).compute(reqs).gamma.has_cross_gamma(CurveTypes.USD_OIS_SOFR, CurveTypes.USD_GBP_BASIS)
