@@ -82,6 +82,98 @@ def cpu_baseline(curve, value_dt, interp_value, want_gamma, budget_s):
     return cpu_port.timed_baseline(curve, value_dt, interp_value, want_gamma, budget_s)
 
 
+def cpu_baseline_b0(curve, value_dt, interp_value, want_gamma, budget_s):
+    """the single-thread, one-trade-at-a-time loop over the autodiff restatement."""
+    try:
+        from oracle import port as cpu_port
+        return cpu_port.timed_baseline_b0(curve, value_dt, interp_value, want_gamma, budget_s)
+    except Exception as exc:
+        return {"value": None, "unit": "trades/s", "cores": 0, "kind": "port", "sample": f"unavailable: {exc}"}
+
+
+def parity_spot_check(host_curve, interp_value, batch, pv, delta, gamma, n_sample=1024):
+    """After the timed region: ~1 000 trades of the batch that was timed (four contiguous runs spread over the batch,
+    i.e. over the kernel's blocks) against oracle/port.c on the same inputs.  The oracle only checks here."""
+    import numpy as np
+    from oracle import port as cpu_port
+    n = batch.n_trades
+    run = max(1, min(n, n_sample) // 4)
+    starts = sorted({min(max(0, n - run), (n * k) // 4) for k in range(4)})
+    worst, checked = 0.0, 0
+    for lo in starts:
+        hi = min(n, lo + run)
+        sub = batch.slice(lo, hi)
+        ref = cpu_port.price(interp_value, host_curve.times, host_curve.dfs, host_curve.jac, host_curve.hess, sub,
+                             want_delta=delta is not None, want_gamma=gamma is not None, n_threads=4)
+        got = {"pv": pv[lo:hi].cpu().numpy(),
+               "delta": None if delta is None else delta[lo:hi].cpu().numpy(),
+               "gamma": None if gamma is None else gamma[lo:hi].cpu().numpy()}
+        worst = max(worst, cpu_port.parity_error(got, ref, sub.notional))
+        checked += hi - lo
+    return {"max_error": worst, "trades": checked, "tolerance": 1e-10, "ok": bool(worst <= 1e-10),
+            "against": "oracle/port.c (C restatement of the reference algorithm), metric of tests/_parity.py, "
+                       "computed after the timed region on the timed batch's own outputs"}
+
+
+def measured_fp64(n, want_gamma, kind, interp, kern_ms):
+    """fp64 vector-ALU figures of the dominant kernel (the gamma configuration sits within ~2x
+    of the FMA bound): wave-instruction counts per trade from the committed PMC pass of this same command
+    (tools/pmc.sh -> profiles/r*_final_fp64.json), turned into TFLOP/s with THIS run's kernel time.  Peak: 78.6 TFLOP/s
+    fp64 vector (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz, MI355X_MICROARCH.md)."""
+    import glob
+    if not (want_gamma and kind == "offgrid" and interp == "LINEAR_ZERO_RATES"):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_fp64.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            c = json.load(f)
+        per_trade = {k: float(c["per_trade"][k]) for k in ("fma_f64", "mul_f64", "add_f64", "trans_f64", "valu_total")}
+        flops = 64.0 * (2.0 * per_trade["fma_f64"] + per_trade["mul_f64"] + per_trade["add_f64"] + per_trade["trans_f64"])
+        tf = flops * n / (kern_ms * 1e-3) / 1e12
+        return {"wave_instructions_per_trade": per_trade, "flop_per_trade": flops, "achieved_tflops": tf,
+                "peak_tflops": 78.6, "frac": tf / 78.6,
+                "valu_issue_frac": per_trade["valu_total"] * n * 4.0 / (kern_ms * 1e-3 * 2.4e9 * 1024),
+                "source": f"profiles/{os.path.basename(files[-1])}: rocprofv3 SQ_INSTS_VALU_*_F64 pass of this command on an "
+                          "earlier box (counts are per trade and box independent); time from this run"}
+    except Exception:
+        return None
+
+
+class HostStagedAllReduce:
+    """The rehearsal's stand-in for RCCL's asynchronous all-reduce (gloo reduces host tensors): `start` queues a D2H copy
+    of the buffer into pinned memory behind the step's kernels; the collective itself is issued (async_op=True) once
+    that copy has completed - checked when the NEXT step has been launched, so the host never idles the GPU - and `wait`
+    completes it and copies the reduced ladder back before the buffer is priced into again.  Same `pending[j]` /
+    two-buffer protocol as the RCCL branch: with two ranks both buffers' collectives are in flight across steps."""
+
+    def __init__(self, dist, torch, stream, agg):
+        self.dist, self.torch, self.stream, self.agg = dist, torch, stream, agg
+        self.host = torch.empty(agg.shape, dtype=agg.dtype, pin_memory=True)
+        self.copied = torch.cuda.Event()
+        self.work = None
+        self.staged = False
+
+    def start(self):
+        self.host.copy_(self.agg, non_blocking=True)          # on the launch stream, behind this step's kernels
+        self.copied.record(self.stream)
+        self.staged = True
+
+    def issue(self):
+        if self.staged and self.work is None:
+            self.copied.synchronize()
+            self.work = self.dist.all_reduce(self.host, async_op=True)
+
+    def wait(self):
+        self.issue()
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+            self.agg.copy_(self.host, non_blocking=True)      # back on the launch stream, ahead of the next pricing call
+        self.staged = False
+
+
 def measured_traffic(n, want_gamma, kind, interp):
     """(HBM bytes per launch, where the figure comes from): the committed rocprofv3 PMC summary of this same
     command (tools/profile.sh + tools/profile_summary.py -> profiles/*_traffic.json), or (None, reason) when the
@@ -135,13 +227,6 @@ def main(argv=None):
     if use_dist:
         if rehearse:
             dist.init_process_group("gloo")
-            _all_reduce = dist.all_reduce
-
-            def all_reduce_via_host(tensor, op=dist.ReduceOp.SUM):
-                host = tensor.detach().cpu()
-                _all_reduce(host, op=op)
-                tensor.copy_(host)
-            dist.all_reduce = all_reduce_via_host
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -170,7 +255,10 @@ def main(argv=None):
     n_total = world * args.trades
     batch, (lo, hi) = synthetic.shard_of_portfolio(README_VALUE_DT, n_total, rank, world, kind=args.kind)
     n = batch.n_trades
-    dev_trades = _native.DeviceTrades(ctx, batch)
+    torch.cuda.synchronize()
+    t_up = time.perf_counter()
+    dev_trades = _native.DeviceTrades(ctx, batch)       # host-side row tables + H2D copies (blocking): reported apart
+    upload_ms = (time.perf_counter() - t_up) * 1e3
     in_bytes = dev_trades.input_bytes
     out_bytes = 8 * n * (1 + (P if want_delta else 0) + (P * P if want_gamma else 0))
     curve_bytes = 16 * host_curve.n_knots + 8 * host_curve.n_knots * P * (1 + (P if want_gamma else 0))
@@ -216,6 +304,18 @@ def main(argv=None):
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
 
+    staged = [HostStagedAllReduce(dist, torch, stream, a) for a in aggs] if (use_dist and rehearse) else None
+
+    def reduce_small(t, op=None):
+        """Blocking all-reduce of a small device tensor (timings, counts): over RCCL, or through the host for gloo."""
+        op = op or dist.ReduceOp.SUM
+        if rehearse:
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+
     def step(events=None):
         j = step_no[0] & 1
         step_no[0] += 1
@@ -234,7 +334,10 @@ def main(argv=None):
         if use_dist:
             # the one exchange step: 1 + P + P*P doubles (per curve) over RCCL/xGMI, started behind this step's kernels
             if rehearse:
-                dist.all_reduce(agg)
+                staged[j].start()
+                pending[j] = staged[j]
+                if pending[j ^ 1] is not None:
+                    pending[j ^ 1].issue()      # the previous step's ladder has reached the host by now: reduce it
             else:
                 pending[j] = dist.all_reduce(agg, async_op=True)
 
@@ -281,13 +384,37 @@ def main(argv=None):
         kern_ms = ev[0][0].elapsed_time(ev[0][1]) / args.steps
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        reduce_small(t, dist.ReduceOp.MAX)
     elapsed = float(t.item())
     counts = torch.tensor([n, n_x], dtype=torch.int64, device=dev)
     if use_dist:
-        dist.all_reduce(counts)                          # units all ranks processed per step
+        reduce_small(counts)                             # units all ranks processed per step
+    # the reduced ladder of the LAST timed step against the per-rank ladders, gathered once and summed in rank order
+    allreduce_check = None
+    if use_dist:
+        reduced = aggs[(step_no[0] - 1) & 1].detach().cpu()
+        local = torch.zeros(agg_len, dtype=torch.float64, device=dev)
+        _native.price_dev(ctx, dev_curve, dev_trades, mask, pv.data_ptr(), delta.data_ptr() if delta is not None else 0,
+                          gamma.data_ptr() if gamma is not None else 0, local.data_ptr(), stream.cuda_stream)
+        price_xccy(local)
+        stream.synchronize()
+        parts = [torch.zeros(agg_len, dtype=torch.float64) for _ in range(world)]
+        if rehearse:
+            dist.all_gather(parts, local.cpu())
+        else:
+            dev_parts = [torch.zeros(agg_len, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(dev_parts, local)
+            parts = [p.cpu() for p in dev_parts]
+        total = parts[0].clone()
+        for p_ in parts[1:]:
+            total += p_
+        err = float((reduced - total).abs().max() / max(float(total.abs().max()), 1e-300))
+        allreduce_check = {"status": "ok" if err <= 1e-12 else "MISMATCH", "max_rel_error": err, "ranks": world,
+                           "what": "all-reduced aggregate of the last timed step vs the sum, in rank order, of the "
+                                   "per-rank aggregates gathered once after the timed region"}
     n_all, nx_all = int(counts[0].item()), int(counts[1].item())
 
+    spot_ok = True
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = (n_all + nx_all) * args.steps / elapsed
@@ -320,13 +447,30 @@ def main(argv=None):
             line["config"]["xccy_swaps_per_gpu"] = args.xccy_swaps
             line["config"]["xccy_swaps_total"] = nx_all
             line["config"]["allreduce_doubles"] = agg_len
+        line["upload_ms"] = {"trades": upload_ms, "what": "adr_trades_upload of rank 0's batch: host-side construction of "
+                             "the row tables + H2D copies, blocking, once per portfolio; outside `value`",
+                             "input_bytes": in_bytes}
+        if allreduce_check is not None:
+            line["allreduce_check"] = allreduce_check
+            spot_ok = spot_ok and allreduce_check["status"] == "ok"
+        fp64 = measured_fp64(n, want_gamma, args.kind, args.interp, kern_ms)
+        if fp64 is not None:
+            line["roofline"]["fp64_valu"] = fp64
+        if n_x == 0:
+            check = parity_spot_check(host_curve, interp.value, batch, pv, delta, gamma)
+            line["parity_spot_check"] = check
+            spot_ok = spot_ok and check["ok"]
         if args.cpu_baseline_seconds > 0 and world == 1 and n_x == 0:
             line["cpu_baseline"] = cpu_baseline(curve, README_VALUE_DT, interp.value, want_gamma,
                                                 args.cpu_baseline_seconds)
+            line["cpu_baseline_b0"] = cpu_baseline_b0(curve, README_VALUE_DT, interp.value, want_gamma,
+                                                      min(6.0, args.cpu_baseline_seconds))
         print(json.dumps(line), flush=True)
 
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0 and not spot_ok:
+        raise SystemExit("bench.py: parity_spot_check (timed batch vs oracle, 1e-10) or allreduce_check failed - see the JSON line")
 
 
 if __name__ == "__main__":

@@ -96,3 +96,55 @@ def timed_baseline(curve, value_dt, method, want_gamma, budget_s, kind="offgrid"
             "sample": f"{n} trades of the same synthetic portfolio ({kind}), PV+delta"
                       + ("+gamma" if want_gamma else "") + f", {dt:.1f} s wall on {threads} OpenMP threads "
                       "(oracle/port.c: C restatement of the reference algorithm; the JAX reference cannot run here)"}
+
+
+def parity_error(got, ref, notional):
+    """Worst error of a batch against this port, in the metric of tests/_parity.py (north_star's 1e-10): per trade and
+    ladder max|a-b| / max(max|b|, floor N) with floors 1e-4 (PV), 1e-8 (delta), 1e-12 (gamma), and SURVEY section 7's
+    per-unit-notional |a-b| / max(1, |b|)."""
+    n = np.abs(np.asarray(notional, dtype=np.float64))
+    worst = 0.0
+    for key, floor in (("pv", 1e-4), ("delta", 1e-8), ("gamma", 1e-12)):
+        if ref.get(key) is None or got.get(key) is None:
+            continue
+        a = np.asarray(got[key], dtype=np.float64).reshape(len(n), -1)
+        b = np.asarray(ref[key], dtype=np.float64).reshape(len(n), -1)
+        diff = np.max(np.abs(a - b), axis=1)
+        scale = np.maximum(np.max(np.abs(b), axis=1), floor * n)
+        unit = np.max(np.abs(a - b) / n[:, None] / np.maximum(1.0, np.abs(b) / n[:, None]), axis=1)
+        worst = max(worst, float(np.max(diff / scale)), float(np.max(unit)))
+    return worst
+
+
+def timed_baseline_b0(curve, value_dt, method, want_gamma, budget_s, kind="offgrid"):
+    """the reference-style loop - one trade at a time through the autodiff restatement
+    (oracle/cavour_oracle.py: grad / hessian w.r.t. the knot DFs, then the chain rule, as engine.py:2541-2576 does per
+    trade), ONE thread, one curve cache shared by all trades (kinder than the reference, which rebuilds it per trade)."""
+    import torch
+    from adrates_amd.trades import synthetic
+    from . import cavour_oracle as O
+
+    cache = O.cached_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    batch = synthetic.synthesize(value_dt, 256, kind=kind)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        done, t0 = 0, time.perf_counter()
+        while done < batch.n_trades and (done < 3 or time.perf_counter() - t0 < budget_s):
+            f0, f1 = int(batch.fix_off[done]), int(batch.fix_off[done + 1])
+            l0, l1 = int(batch.flt_off[done]), int(batch.flt_off[done + 1])
+            fixed = dict(payment_times=batch.fix_tp[f0:f1], payments=batch.fix_pay[f0:f1], principal=0.0,
+                         leg_sign=float(batch.fix_sign[done]))
+            floating = dict(payment_times=batch.flt_tp[l0:l1], start_times=batch.flt_ts[l0:l1],
+                            end_times=batch.flt_te[l0:l1], pay_alphas=batch.flt_alpha[l0:l1],
+                            spread=float(batch.spread[done]), notional=float(batch.notional[done]), principal=0.0,
+                            leg_sign=float(batch.flt_sign[done]))
+            O.ois_analytics(cache, method, fixed, floating, want_gamma=want_gamma)
+            done += 1
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(threads)
+    return {"value": done / dt, "unit": "trades/s", "cores": 1, "kind": "port",
+            "sample": f"{done} trades of the same synthetic portfolio ({kind}), one at a time, PV+delta"
+                      + ("+gamma" if want_gamma else "") + f", {dt:.1f} s wall on 1 thread (oracle/cavour_oracle.py: "
+                      "per-trade autodiff through the knot DFs + chain rule, the reference's method; shared curve cache)"}

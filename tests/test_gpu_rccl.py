@@ -72,6 +72,11 @@ def test_bench_process_group_path_with_one_rank(tmp_path):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f64"
     assert d["value"] > 1e6 and d["roofline"]["bound"] == "hbm" and 0.0 < d["roofline"]["frac"] < 1.0
     assert abs(d["value"] - 20000 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    # the round-3 keys: upload time apart from `value`, the in-run parity spot check, the RCCL all-reduce check
+    assert d["upload_ms"]["trades"] > 0.0
+    assert d["parity_spot_check"]["ok"] and d["parity_spot_check"]["trades"] >= 1000
+    assert d["parity_spot_check"]["max_error"] <= 1e-10
+    assert d["allreduce_check"]["status"] == "ok" and d["allreduce_check"]["ranks"] == 1
 
 
 def test_bench_two_ranks_rehearsed_on_one_gpu():
@@ -99,3 +104,7 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     cfg = d["config"]
     assert cfg["trades_total"] == 60000 and 0 < cfg["rank0_trades"] < 60000 and cfg["xccy_swaps_total"] == 4000
     assert d["value"] > 1e5
+    # the async, double-buffered all-reduce protocol ran with two ranks (host-staged over gloo here, RCCL on a real
+    # node) and the reduced ladder of the last step equals the sum of the two ranks' own ladders
+    chk = d["allreduce_check"]
+    assert chk["status"] == "ok" and chk["ranks"] == 2 and chk["max_rel_error"] <= 1e-12
