@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/adrates.h"
@@ -598,11 +599,30 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     const int64_t n_fix = n ? fix_off[n] : 0, n_flt = n ? flt_off[n] : 0;
     if (n > 0 && (fix_off[0] != 0 || flt_off[0] != 0))
         return fail(ADR_ERR_INVALID, "adr_trades_upload: offsets must start at 0");
+
+    // Host side of the upload: validation, the routing class of every trade and the row orders.  All of it is a
+    // single pass over the caller's arrays, cut into contiguous trade ranges for a pool of threads; the tables
+    // themselves are gathered on the device (trades_build.hip).
+    const int n_threads = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(std::thread::hardware_concurrency()),
+                                                                                 16, n / 4096 + 1})));
+    auto parallel_ranges = [&](auto&& body) {          // body(thread, first trade, one past the last trade)
+        std::vector<std::thread> pool;
+        for (int k = 1; k < n_threads; ++k)
+            pool.emplace_back([&, k] { body(k, n * k / n_threads, n * (k + 1) / n_threads); });
+        body(0, 0, n / n_threads);
+        for (auto& th : pool) th.join();
+    };
     // the offsets index the caller's arrays: check them before anything walks those arrays
-    for (int64_t t = 0; t < n; ++t) {
-        const int64_t mf = fix_off[t + 1] - fix_off[t], ml = flt_off[t + 1] - flt_off[t];
-        if (mf < 0 || ml < 0 || mf > INT16_MAX || ml > INT16_MAX)
-            return fail(ADR_ERR_INVALID, "adr_trades_upload: offsets must be non-decreasing, <= 32767 flows per leg");
+    {
+        std::vector<char> bad(static_cast<size_t>(n_threads), 0);
+        parallel_ranges([&](int k, int64_t t0, int64_t t1) {
+            for (int64_t t = t0; t < t1; ++t) {
+                const int64_t mf = fix_off[t + 1] - fix_off[t], ml = flt_off[t + 1] - flt_off[t];
+                if (mf < 0 || ml < 0 || mf > INT16_MAX || ml > INT16_MAX) { bad[static_cast<size_t>(k)] = 1; return; }
+            }
+        });
+        for (char b : bad)
+            if (b) return fail(ADR_ERR_INVALID, "adr_trades_upload: offsets must be non-decreasing, <= 32767 flows per leg");
     }
     if (n_fix > INT32_MAX || n_flt > INT32_MAX)
         return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^31 cash flows in one batch; shard the portfolio");
@@ -610,46 +630,71 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         return fail(ADR_ERR_INVALID, "adr_trades_upload: null cash-flow array");
 
     // NaN / infinite inputs would only produce NaN outputs (every table index in the kernels is clamped), but a
-    // batch that contains them is a caller error: say so here instead of returning a ladder of NaNs
-    auto all_finite = [](const double* a, int64_t m) {
-        for (int64_t i = 0; i < m; ++i)
-            if (!std::isfinite(a[i])) return false;
-        return true;
-    };
-    if (!all_finite(fix_tp, n_fix) || !all_finite(fix_pay, n_fix) || !all_finite(flt_tp, n_flt) ||
-        !all_finite(flt_ts, n_flt) || !all_finite(flt_te, n_flt) || !all_finite(flt_alpha, n_flt) ||
-        (flt_weight && !all_finite(flt_weight, n_flt)) || !all_finite(notional, n) || !all_finite(spread, n))
-        return fail(ADR_ERR_INVALID, "adr_trades_upload: times, amounts, accruals, notionals and spreads must be finite");
+    // batch that contains them is a caller error: say so here instead of returning a ladder of NaNs.
+    // Class of a trade: bit 0 = a coupon accrues to a date other than its payment date (payment lag: ratio terms) or
+    // carries a notional multiplier != 1.
+    constexpr int64_t kMaxChain = 12, kMaxChainLag = adr::kLagScratchNodes / adr::kRowSlots;   // rows per trade in the chained tables:
+    // plain legs of up to 384 coupons (a 30Y monthly leg is 360, cavour/utils/frequency.py:46); payment-lag legs of up to
+    // 128 (the variant's per-trade stash, kLagScratchNodes)
+    std::vector<uint8_t> lagged_of(static_cast<size_t>(n), 0);
+    {
+        std::vector<char> bad(static_cast<size_t>(n_threads), 0);       // 1: not finite, 2: bad sign
+        parallel_ranges([&](int k, int64_t t0, int64_t t1) {
+            char err = 0;
+            auto finite = [](const double* a, int64_t lo, int64_t hi) {
+                bool ok = true;
+                for (int64_t i = lo; i < hi; ++i) ok &= std::isfinite(a[i]);
+                return ok;
+            };
+            if (t1 > t0) {
+                const int64_t f0 = fix_off[t0], f1 = fix_off[t1], l0 = flt_off[t0], l1 = flt_off[t1];
+                if (!finite(fix_tp, f0, f1) || !finite(fix_pay, f0, f1) || !finite(flt_tp, l0, l1) || !finite(flt_ts, l0, l1) ||
+                    !finite(flt_te, l0, l1) || !finite(flt_alpha, l0, l1) || (flt_weight && !finite(flt_weight, l0, l1)) ||
+                    !finite(notional, t0, t1) || !finite(spread, t0, t1))
+                    err = 1;
+            }
+            for (int64_t t = t0; t < t1 && !err; ++t) {
+                if (!(fix_sign[t] == 1.0 || fix_sign[t] == -1.0) || !(flt_sign[t] == 1.0 || flt_sign[t] == -1.0)) { err = 2; break; }
+                bool lag = false;
+                for (int64_t j = flt_off[t]; j < flt_off[t + 1] && !lag; ++j)
+                    lag = (flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j]) || (flt_weight && flt_weight[j] != 1.0);
+                lagged_of[static_cast<size_t>(t)] = lag ? 1 : 0;
+            }
+            bad[static_cast<size_t>(k)] = err;
+        });
+        for (char b : bad)
+            if (b == 1) return fail(ADR_ERR_INVALID, "adr_trades_upload: times, amounts, accruals, notionals and spreads must be finite");
+        for (char b : bad)
+            if (b == 2) return fail(ADR_ERR_INVALID, "adr_trades_upload: leg signs must be +1 or -1");
+    }
 
-    std::vector<int32_t> list_fast, list_long, list_general, list_lagged, list_lagged_long, list_rest;
-    std::vector<adr::TradeHeader> hdr(static_cast<size_t>(n));
-    constexpr int64_t kMaxChain = 4;     // rows per trade in the chained table: legs of up to 128 coupons
+    auto coupons_of = [&](int64_t t) { return flt_off[t + 1] - flt_off[t]; };
     auto rows_of = [&](int64_t t) {
         const int64_t m = std::max(flt_off[t + 1] - flt_off[t], fix_off[t + 1] - fix_off[t]);
         return std::max<int64_t>(1, (m + adr::kRowSlots - 1) / adr::kRowSlots);
     };
+    // stable order by float-coupon count, longest first (the trades sharing a wavefront then have similar lengths):
+    // a counting sort for the one-row tables (at most 32 coupons), std::stable_sort for the short lists of longer trades
+    auto sort_by_coupons = [&](std::vector<int32_t>& list) {
+        bool small = true;
+        for (int32_t t : list) small &= coupons_of(t) <= 64;
+        if (!small) {
+            std::stable_sort(list.begin(), list.end(), [&](int32_t a, int32_t b) { return coupons_of(a) > coupons_of(b); });
+            return;
+        }
+        size_t count[66] = {0};
+        for (int32_t t : list) ++count[64 - coupons_of(t) + 1];
+        for (int b = 1; b < 66; ++b) count[b] += count[b - 1];
+        std::vector<int32_t> sorted(list.size());
+        for (int32_t t : list) sorted[count[64 - coupons_of(t)]++] = t;
+        list.swap(sorted);
+    };
+    std::vector<int32_t> list_fast, list_long, list_general, list_lagged, list_lagged_long, list_rest;
     for (int64_t t = 0; t < n; ++t) {
-        bool general = rows_of(t) > kMaxChain;
-        for (int64_t j = flt_off[t]; j < flt_off[t + 1] && !general; ++j)
-            general = (flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j])      // payment lag: ratio terms
-                      || (flt_weight && flt_weight[j] != 1.0);              // per-coupon notionals
-        (general ? list_general : rows_of(t) > 1 ? list_long : list_fast).push_back(static_cast<int32_t>(t));
-        if (general) (rows_of(t) == 1 ? list_lagged : rows_of(t) <= kMaxChain ? list_lagged_long : list_rest).push_back(static_cast<int32_t>(t));
-    }
-    for (int64_t t = 0; t < n; ++t) {
-        const int64_t mf = fix_off[t + 1] - fix_off[t], ml = flt_off[t + 1] - flt_off[t];
-        if (!(fix_sign[t] == 1.0 || fix_sign[t] == -1.0) || !(flt_sign[t] == 1.0 || flt_sign[t] == -1.0))
-            return fail(ADR_ERR_INVALID, "adr_trades_upload: leg signs must be +1 or -1");
-        adr::TradeHeader& h = hdr[static_cast<size_t>(t)];
-        h.notional = notional[t];
-        h.spread = spread[t];
-        h.flt_begin = static_cast<int32_t>(flt_off[t]);
-        h.fix_begin = static_cast<int32_t>(fix_off[t]);
-        h.n_flt = static_cast<int16_t>(ml);
-        h.n_fix = static_cast<int16_t>(mf);
-        h.fix_sign = static_cast<int8_t>(fix_sign[t]);
-        h.flt_sign = static_cast<int8_t>(flt_sign[t]);
-        h.pad = 0;
+        const int64_t rows = rows_of(t);
+        const bool general = rows > kMaxChain || lagged_of[static_cast<size_t>(t)];
+        (general ? list_general : rows > 1 ? list_long : list_fast).push_back(static_cast<int32_t>(t));
+        if (general) (rows == 1 ? list_lagged : rows <= kMaxChainLag ? list_lagged_long : list_rest).push_back(static_cast<int32_t>(t));
     }
 
     ADR_HIP(hipSetDevice(ctx->device));
@@ -659,81 +704,99 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     tr->n_fix_flows = n_fix;
     tr->n_flt_flows = n_flt;
     hipError_t e = hipSuccess;
-    auto put = [&](const void* src, size_t bytes) -> void* {
+    hipStream_t stream = ctx->stream;
+    auto alloc = [&](size_t bytes) -> void* {
         if (bytes == 0 || e != hipSuccess) return nullptr;
         // over-allocate one header's worth so that the kernels' neighbour reads never leave the buffer
         void* p = nullptr;
         e = hipMalloc(&p, bytes + 64);
         if (e != hipSuccess) return nullptr;
         tr->allocations.push_back(p);
-        e = hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
         return p;
     };
+    auto put = [&](const void* src, size_t bytes) -> void* {
+        void* p = alloc(bytes);
+        if (p && e == hipSuccess) e = hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, stream);
+        return p;
+    };
+    // (host vectors handed to `put` must outlive the asynchronous copies: they are kept until the final synchronisation)
+    std::vector<std::vector<int32_t>> keep32;
+    std::vector<std::vector<uint8_t>> keep8;
+    auto put32 = [&](std::vector<int32_t>&& v) -> const int32_t* {
+        keep32.push_back(std::move(v));
+        return static_cast<const int32_t*>(put(keep32.back().data(), keep32.back().size() * sizeof(int32_t)));
+    };
+    auto put8 = [&](std::vector<uint8_t>&& v) -> const uint8_t* {
+        keep8.push_back(std::move(v));
+        return static_cast<const uint8_t*>(put(keep8.back().data(), keep8.back().size()));
+    };
+
+    // the caller's arrays, once
+    adr::CsrDev csr{};
+    csr.n = n;
+    csr.fix_off = static_cast<const int64_t*>(put(fix_off, (n ? n + 1 : 0) * sizeof(int64_t)));
+    csr.flt_off = static_cast<const int64_t*>(put(flt_off, (n ? n + 1 : 0) * sizeof(int64_t)));
+    csr.fix_tp = static_cast<const double*>(put(fix_tp, n_fix * sizeof(double)));
+    csr.fix_pay = static_cast<const double*>(put(fix_pay, n_fix * sizeof(double)));
+    csr.flt_tp = static_cast<const double*>(put(flt_tp, n_flt * sizeof(double)));
+    csr.flt_ts = static_cast<const double*>(put(flt_ts, n_flt * sizeof(double)));
+    csr.flt_te = static_cast<const double*>(put(flt_te, n_flt * sizeof(double)));
+    csr.flt_alpha = static_cast<const double*>(put(flt_alpha, n_flt * sizeof(double)));
+    csr.flt_weight = flt_weight ? static_cast<const double*>(put(flt_weight, n_flt * sizeof(double))) : nullptr;
+    csr.notional = static_cast<const double*>(put(notional, n * sizeof(double)));
+    csr.spread = static_cast<const double*>(put(spread, n * sizeof(double)));
+    csr.fix_sign = static_cast<const double*>(put(fix_sign, n * sizeof(double)));
+    csr.flt_sign = static_cast<const double*>(put(flt_sign, n * sizeof(double)));
+
     tr->dev.n = n;
-    tr->dev.header = static_cast<const adr::TradeHeader*>(put(hdr.data(), hdr.size() * sizeof(adr::TradeHeader)));
-    tr->dev.fix_tp = static_cast<const double*>(put(fix_tp, n_fix * sizeof(double)));
-    tr->dev.fix_pay = static_cast<const double*>(put(fix_pay, n_fix * sizeof(double)));
-    tr->dev.flt_tp = static_cast<const double*>(put(flt_tp, n_flt * sizeof(double)));
-    tr->dev.flt_ts = static_cast<const double*>(put(flt_ts, n_flt * sizeof(double)));
-    tr->dev.flt_te = static_cast<const double*>(put(flt_te, n_flt * sizeof(double)));
-    tr->dev.flt_alpha = static_cast<const double*>(put(flt_alpha, n_flt * sizeof(double)));
-    tr->dev.flt_weight = flt_weight ? static_cast<const double*>(put(flt_weight, n_flt * sizeof(double))) : nullptr;
+    {
+        adr::TradeHeader* hdr = static_cast<adr::TradeHeader*>(alloc(static_cast<size_t>(n) * sizeof(adr::TradeHeader)));
+        if (e == hipSuccess && n > 0) e = adr::launch_build_headers(csr, hdr, stream);
+        tr->dev.header = hdr;
+    }
+    tr->dev.fix_tp = csr.fix_tp; tr->dev.fix_pay = csr.fix_pay; tr->dev.flt_tp = csr.flt_tp; tr->dev.flt_ts = csr.flt_ts;
+    tr->dev.flt_te = csr.flt_te; tr->dev.flt_alpha = csr.flt_alpha; tr->dev.flt_weight = csr.flt_weight;
     tr->dev.list = nullptr;
     tr->dev.n_list = n;
     tr->n_fast = static_cast<int64_t>(list_fast.size());
     tr->n_long = static_cast<int64_t>(list_long.size());
     tr->n_general = static_cast<int64_t>(list_general.size());
-    std::stable_sort(list_fast.begin(), list_fast.end(), [&](int32_t a, int32_t b) {
-        return hdr[static_cast<size_t>(a)].n_flt > hdr[static_cast<size_t>(b)].n_flt;
-    });
+    sort_by_coupons(list_fast);
     tr->list_general = static_cast<const int32_t*>(put(list_general.data(), list_general.size() * sizeof(int32_t)));
 
-    // Row tables of the fast kernel (kernels.hpp): 32 zero-padded slots per row and array.  `pieces` lists, row
-    // by row, (trade or -1 for an empty row, first coupon of the piece, "the trade continues" flag).
+    // Row tables of the fast kernel (kernels.hpp): 32 zero-padded slots per row and array, gathered on the device
+    // from the work list (trade or -1 for an empty row, first coupon of the piece, "the trade continues" flag).
     struct Piece { int64_t trade; int64_t first; bool more; };
-    auto build_rows = [&](const std::vector<Piece>& pieces, adr::TradesDev& dst, bool lagged = false) {
-        const size_t rows = pieces.size(), S = adr::kRowSlots;
-        std::vector<double> r_tp(rows * S, 0.0), r_ts(rows * S, 0.0), r_al(rows * S, 0.0), r_xtp(rows * S, 0.0),
-            r_xpay(rows * S, 0.0), r_n(rows, 0.0), r_sp(rows, 0.0), r_te(lagged ? rows * S : 0, 0.0),
-            r_w(lagged && flt_weight ? rows * S : 0, 1.0);
-        std::vector<int32_t> r_meta(rows, 0), r_trade(rows, -1);
-        for (size_t r = 0; r < rows; ++r) {
-            const int64_t t = pieces[r].trade;
-            r_meta[r] = pieces[r].more ? 0x40000 : 0;
-            if (t < 0) continue;
-            const int64_t l0 = flt_off[t] + pieces[r].first, f0 = fix_off[t] + pieces[r].first;
-            const int64_t ml = std::clamp<int64_t>(flt_off[t + 1] - l0, 0, adr::kRowSlots);
-            const int64_t mf = std::clamp<int64_t>(fix_off[t + 1] - f0, 0, adr::kRowSlots);
-            for (int64_t j = 0; j < ml; ++j) {
-                r_tp[r * S + j] = flt_tp[l0 + j]; r_ts[r * S + j] = flt_ts[l0 + j]; r_al[r * S + j] = flt_alpha[l0 + j];
-                if (lagged) r_te[r * S + j] = flt_te[l0 + j];
-                if (lagged && flt_weight) r_w[r * S + j] = flt_weight[l0 + j];
-            }
-            for (int64_t j = 0; j < mf; ++j) { r_xtp[r * S + j] = fix_tp[f0 + j]; r_xpay[r * S + j] = fix_pay[f0 + j]; }
-            r_n[r] = notional[t]; r_sp[r] = spread[t];
-            r_trade[r] = static_cast<int32_t>(t);
-            r_meta[r] |= static_cast<int32_t>(ml | (mf << 8) | ((flt_sign[t] < 0.0) ? 0x10000 : 0) |
-                                              ((fix_sign[t] < 0.0) ? 0x20000 : 0));
-        }
+    auto build_rows = [&](std::vector<int32_t>&& piece_trade, std::vector<int32_t>&& piece_first, std::vector<uint8_t>&& piece_more,
+                          adr::TradesDev& dst, bool lagged = false) {
+        const size_t rows = piece_trade.size(), S = adr::kRowSlots;
+        const bool chained = !piece_first.empty();
+        adr::RowBuildDev rb{};
+        rb.rows = static_cast<int64_t>(rows);
+        rb.piece_trade = put32(std::move(piece_trade));
+        rb.piece_first = chained ? put32(std::move(piece_first)) : nullptr;
+        rb.piece_more = chained ? put8(std::move(piece_more)) : nullptr;
+        rb.row_tp = static_cast<double*>(alloc(rows * S * sizeof(double)));
+        rb.row_ts = static_cast<double*>(alloc(rows * S * sizeof(double)));
+        rb.row_alpha = static_cast<double*>(alloc(rows * S * sizeof(double)));
+        rb.row_xtp = static_cast<double*>(alloc(rows * S * sizeof(double)));
+        rb.row_xpay = static_cast<double*>(alloc(rows * S * sizeof(double)));
+        rb.row_te = lagged ? static_cast<double*>(alloc(rows * S * sizeof(double))) : nullptr;
+        rb.row_w = (lagged && flt_weight) ? static_cast<double*>(alloc(rows * S * sizeof(double))) : nullptr;
+        rb.row_notional = static_cast<double*>(alloc(rows * sizeof(double)));
+        rb.row_spread = static_cast<double*>(alloc(rows * sizeof(double)));
+        rb.row_meta = static_cast<int32_t*>(alloc(rows * sizeof(int32_t)));
+        rb.row_trade = static_cast<int32_t*>(alloc(rows * sizeof(int32_t)));
+        if (e == hipSuccess) e = adr::launch_build_rows(csr, rb, stream);
         dst.n_rows = static_cast<int64_t>(rows);
-        dst.row_tp = static_cast<const double*>(put(r_tp.data(), r_tp.size() * sizeof(double)));
-        dst.row_ts = static_cast<const double*>(put(r_ts.data(), r_ts.size() * sizeof(double)));
-        dst.row_alpha = static_cast<const double*>(put(r_al.data(), r_al.size() * sizeof(double)));
-        dst.row_xtp = static_cast<const double*>(put(r_xtp.data(), r_xtp.size() * sizeof(double)));
-        dst.row_xpay = static_cast<const double*>(put(r_xpay.data(), r_xpay.size() * sizeof(double)));
-        dst.row_notional = static_cast<const double*>(put(r_n.data(), r_n.size() * sizeof(double)));
-        dst.row_spread = static_cast<const double*>(put(r_sp.data(), r_sp.size() * sizeof(double)));
-        dst.row_meta = static_cast<const int32_t*>(put(r_meta.data(), r_meta.size() * sizeof(int32_t)));
-        dst.row_trade = static_cast<const int32_t*>(put(r_trade.data(), r_trade.size() * sizeof(int32_t)));
+        dst.row_tp = rb.row_tp; dst.row_ts = rb.row_ts; dst.row_alpha = rb.row_alpha; dst.row_xtp = rb.row_xtp; dst.row_xpay = rb.row_xpay;
+        dst.row_notional = rb.row_notional; dst.row_spread = rb.row_spread; dst.row_meta = rb.row_meta; dst.row_trade = rb.row_trade;
         dst.rows_lagged = lagged ? 1 : 0;
-        dst.row_te = lagged ? static_cast<const double*>(put(r_te.data(), r_te.size() * sizeof(double))) : nullptr;
-        dst.row_w = (lagged && flt_weight) ? static_cast<const double*>(put(r_w.data(), r_w.size() * sizeof(double))) : nullptr;
+        dst.row_te = rb.row_te; dst.row_w = rb.row_w;
     };
     {   // plain table: one row per trade, sorted by coupon count
-        std::vector<Piece> pieces(list_fast.size());
-        for (size_t r = 0; r < list_fast.size(); ++r) pieces[r] = {list_fast[r], 0, false};
         tr->dev.rows_chained = 0;
-        build_rows(pieces, tr->dev);
+        build_rows(std::vector<int32_t>(list_fast), {}, {}, tr->dev);
     }
     // Chained tables.  The kernel's wave w walks units w, w + W, w + 2W, ... (W = waves of the launch), so the
     // rows of a pair of trades (one per group of a wave) go to consecutive "rounds" of one wave column;
@@ -764,13 +827,17 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
             height[w] += len;
         }
         const int64_t rounds = *std::max_element(height.begin(), height.end());
-        std::vector<Piece> pieces(static_cast<size_t>(rounds * W * G), Piece{-1, 0, false});
+        const size_t total = static_cast<size_t>(rounds * W * G);
+        std::vector<int32_t> p_trade(total, -1), p_first(total, 0);
+        std::vector<uint8_t> p_more(total, 0);
         for (int64_t w = 0; w < W; ++w)
             for (size_t r = 0; r < column[static_cast<size_t>(w)].size(); ++r)
-                for (int g = 0; g < G; ++g)
-                    pieces[static_cast<size_t>((static_cast<int64_t>(r) * W + w) * G + g)] = column[static_cast<size_t>(w)][r][static_cast<size_t>(g)];
-        dst.rows_chained = 1;
-        build_rows(pieces, dst, lagged);
+                for (int g = 0; g < G; ++g) {
+                    const Piece& pc = column[static_cast<size_t>(w)][r][static_cast<size_t>(g)];
+                    const size_t at = static_cast<size_t>((static_cast<int64_t>(r) * W + w) * G + g);
+                    p_trade[at] = static_cast<int32_t>(pc.trade); p_first[at] = static_cast<int32_t>(pc.first); p_more[at] = pc.more ? 1 : 0;
+                }
+        build_rows(std::move(p_trade), std::move(p_first), std::move(p_more), dst, lagged);
         dst.rows_chained = 1;
     };
     tr->chained = tr->dev;
@@ -800,35 +867,36 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         }
     }
     if (!list_lagged.empty()) {   // payment-lag rows: one row per trade, sorted by coupon count like the plain table
-        std::stable_sort(list_lagged.begin(), list_lagged.end(), [&](int32_t a, int32_t b) {
-            return hdr[static_cast<size_t>(a)].n_flt > hdr[static_cast<size_t>(b)].n_flt;
-        });
-        std::vector<Piece> pieces(list_lagged.size());
-        for (size_t r = 0; r < list_lagged.size(); ++r) pieces[r] = {list_lagged[r], 0, false};
+        sort_by_coupons(list_lagged);
         tr->lagged.rows_chained = 0;
-        build_rows(pieces, tr->lagged, true);
+        build_rows(std::vector<int32_t>(list_lagged), {}, {}, tr->lagged, true);
     }
-    {   // lite tables (kernels.hpp, LiteRowsDev): segments of 3-, 2- and 1-row trades, longest coupon counts first -
+    bool too_many_rows = false;
+    {   // lite tables (kernels.hpp, LiteRowsDev): segments of equal row count, longest coupon counts first -
         // one for the trades of the 32-slot row table, one (with accrual ends and notional multipliers) for trades with
-        // payment lag or per-coupon notionals of at most 135 coupons per leg (9 rows)
+        // payment lag or per-coupon notionals of at most 360 coupons per leg (24 rows)
         constexpr int S = adr::kLiteSlots, C = adr::kLiteCoupons, G = 64 / adr::kLiteSlots;
-        auto lite_rows = [&](int64_t t) {
+        // rows per trade, rounded up to one of kLiteSegments row counts (the kernel keeps one segment per distinct count):
+        // 1, 2, 3, 4, 6, 8, 12, 16, 24 rows = up to 360 coupons per leg; kLiteSegments = too long for the table
+        static const int64_t kRowBuckets[adr::kLiteSegments] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
+        auto lite_bucket = [&](int64_t t) {
             const int64_t m = std::max(flt_off[t + 1] - flt_off[t], fix_off[t + 1] - fix_off[t]);
-            return std::max<int64_t>(1, (m + C - 1) / C);
+            const int64_t rows = std::max<int64_t>(1, (m + C - 1) / C);
+            int b = 0;
+            while (b < adr::kLiteSegments && kRowBuckets[b] < rows) ++b;
+            return b;                                           // index into kRowBuckets
         };
         std::vector<int32_t> seg_plain[adr::kLiteSegments], seg_lag[adr::kLiteSegments], nonlite, nonlite_b, general_b;
         std::vector<char> lite_lag(static_cast<size_t>(n), 0);
         for (int64_t t = 0; t < n; ++t) {
-            bool lagged = false;
-            for (int64_t j = flt_off[t]; j < flt_off[t + 1] && !lagged; ++j)
-                lagged = (flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j]) || (flt_weight && flt_weight[j] != 1.0);
-            const int64_t rows = lite_rows(t);
+            const bool lagged = lagged_of[static_cast<size_t>(t)] != 0;
+            const int bucket = lite_bucket(t);
             // plain: the same trades as the 32-slot row table holds (at most 32 coupons per leg, i.e. up to 3 lite
-            // rows); longer ones keep their chained rows
-            if (!lagged && rows_of(t) == 1) { seg_plain[adr::kLiteSegments - rows].push_back(static_cast<int32_t>(t)); continue; }
+            // rows); longer ones keep their chained rows.  (seg_*[k] holds bucket kLiteSegments - 1 - k: longest first)
+            if (!lagged && rows_of(t) == 1) { seg_plain[adr::kLiteSegments - 1 - bucket].push_back(static_cast<int32_t>(t)); continue; }
             nonlite.push_back(static_cast<int32_t>(t));
-            if (lagged && rows <= adr::kLiteSegments) {
-                seg_lag[adr::kLiteSegments - rows].push_back(static_cast<int32_t>(t));
+            if (lagged && bucket < adr::kLiteSegments) {
+                seg_lag[adr::kLiteSegments - 1 - bucket].push_back(static_cast<int32_t>(t));
                 lite_lag[static_cast<size_t>(t)] = 1;
             } else {
                 nonlite_b.push_back(static_cast<int32_t>(t));
@@ -836,81 +904,74 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         }
         for (int32_t t : list_general) if (!lite_lag[static_cast<size_t>(t)]) general_b.push_back(t);
         tr->n_nonlite = static_cast<int64_t>(nonlite.size());
-        tr->list_nonlite = static_cast<const int32_t*>(put(nonlite.data(), nonlite.size() * sizeof(int32_t)));
+        tr->list_nonlite = put32(std::move(nonlite));
         tr->n_nonlite_b = static_cast<int64_t>(nonlite_b.size());
-        tr->list_nonlite_b = static_cast<const int32_t*>(put(nonlite_b.data(), nonlite_b.size() * sizeof(int32_t)));
+        tr->list_nonlite_b = put32(std::move(nonlite_b));
         tr->n_general_b = static_cast<int64_t>(general_b.size());
-        tr->list_general_b = static_cast<const int32_t*>(put(general_b.data(), general_b.size() * sizeof(int32_t)));
-        bool too_many_rows = false;
+        tr->list_general_b = put32(std::move(general_b));
         auto build_lite = [&](std::vector<int32_t> (&seg_trades)[adr::kLiteSegments], adr::LiteRowsDev& lt, int64_t& n_out,
                               bool with_te) {
-        int64_t units = 0, rows = 0;
-        int used[adr::kLiteSegments];                 // the non-empty row counts, longest first, packed to the front
-        lt.n_seg = 0;
-        for (int k = 0; k < adr::kLiteSegments; ++k) {
-            lt.seg_rows[k] = 1; lt.seg_unit0[k] = 0; lt.seg_row0[k] = 0;
-            if (seg_trades[k].empty()) continue;
-            used[lt.n_seg++] = k;
-        }
-        for (int j = 0; j < lt.n_seg; ++j) {
-            const int k = used[j];
-            std::stable_sort(seg_trades[k].begin(), seg_trades[k].end(), [&](int32_t a, int32_t b) {
-                return hdr[static_cast<size_t>(a)].n_flt > hdr[static_cast<size_t>(b)].n_flt;
-            });
-            n_out += static_cast<int64_t>(seg_trades[k].size());
-            lt.seg_rows[j] = adr::kLiteSegments - k;
-            lt.seg_unit0[j] = units;
-            lt.seg_row0[j] = rows;
-            const int64_t seg_units = (static_cast<int64_t>(seg_trades[k].size()) + G - 1) / G;
-            units += seg_units;
-            rows += seg_units * G * lt.seg_rows[j];
-        }
-        for (int j = lt.n_seg; j < adr::kLiteSegments; ++j) { lt.seg_unit0[j] = units; lt.seg_row0[j] = rows; }   // (never reached)
-        lt.n_units = units;
-        if (rows * S > static_cast<int64_t>(UINT32_MAX)) { too_many_rows = true; return; }   // the kernel indexes with 32 bits
-        const size_t n_slots = static_cast<size_t>(units) * G, n_rows = static_cast<size_t>(rows);
-        std::vector<double> r_tpts(n_rows * S * 2, 0.0), r_alxtp(n_rows * S * 2, 0.0), r_xpay(n_rows * S, 0.0);
-        std::vector<double> r_tew(with_te ? n_rows * S * 2 : 0, 0.0);
-        std::vector<adr::LiteTrade> r_slot(n_slots, adr::LiteTrade{0.0, 0.0, 0, -1, 0});
-        for (int j = 0; j < lt.n_seg; ++j) {
-            const int k = used[j];
-            const int R = lt.seg_rows[j];
-            for (size_t i = 0; i < seg_trades[k].size(); ++i) {
-                const int64_t t = seg_trades[k][i];
-                const size_t slot = static_cast<size_t>(lt.seg_unit0[j]) * G + i;
-                const size_t row0 = static_cast<size_t>(lt.seg_row0[j]) + i * static_cast<size_t>(R);
-                const int64_t ml = flt_off[t + 1] - flt_off[t], mf = fix_off[t + 1] - fix_off[t];
-                for (int64_t j = 0; j < ml; ++j) {
-                    const size_t at = (row0 + static_cast<size_t>(j / C)) * S + static_cast<size_t>(j % C);
-                    r_tpts[2 * at] = flt_tp[flt_off[t] + j]; r_tpts[2 * at + 1] = flt_ts[flt_off[t] + j];
-                    r_alxtp[2 * at] = flt_alpha[flt_off[t] + j];
-                    if (with_te) {
-                        r_tew[2 * at] = flt_te[flt_off[t] + j];
-                        r_tew[2 * at + 1] = flt_weight ? flt_weight[flt_off[t] + j] : 1.0;
-                    }
-                }
-                for (int64_t j = 0; j < mf; ++j) {
-                    const size_t at = (row0 + static_cast<size_t>(j / C)) * S + static_cast<size_t>(j % C);
-                    r_alxtp[2 * at + 1] = fix_tp[fix_off[t] + j]; r_xpay[at] = fix_pay[fix_off[t] + j];
-                }
-                r_slot[slot].notional = notional[t]; r_slot[slot].spread = spread[t];
-                r_slot[slot].trade = static_cast<int32_t>(t);
-                r_slot[slot].meta = static_cast<int32_t>(ml | (mf << 8) | ((flt_sign[t] < 0.0) ? 0x10000 : 0) |
-                                                         ((fix_sign[t] < 0.0) ? 0x20000 : 0));
+            int64_t units = 0, rows = 0;
+            int used[adr::kLiteSegments];                 // the non-empty row counts, longest first, packed to the front
+            lt.n_seg = 0;
+            for (int k = 0; k < adr::kLiteSegments; ++k) {
+                lt.seg_rows[k] = 1; lt.seg_unit0[k] = 0; lt.seg_row0[k] = 0;
+                if (seg_trades[k].empty()) continue;
+                used[lt.n_seg++] = k;
             }
-        }
-        lt.tp_ts = static_cast<const double*>(put(r_tpts.data(), r_tpts.size() * sizeof(double)));
-        lt.al_xtp = static_cast<const double*>(put(r_alxtp.data(), r_alxtp.size() * sizeof(double)));
-        lt.xpay = static_cast<const double*>(put(r_xpay.data(), r_xpay.size() * sizeof(double)));
-        lt.te_w = with_te ? static_cast<const double*>(put(r_tew.data(), r_tew.size() * sizeof(double))) : nullptr;
-        lt.slot = static_cast<const adr::LiteTrade*>(put(r_slot.data(), r_slot.size() * sizeof(adr::LiteTrade)));
+            for (int j = 0; j < lt.n_seg; ++j) {
+                const int k = used[j];
+                sort_by_coupons(seg_trades[k]);
+                n_out += static_cast<int64_t>(seg_trades[k].size());
+                lt.seg_rows[j] = static_cast<int>(kRowBuckets[adr::kLiteSegments - 1 - k]);
+                lt.seg_unit0[j] = units;
+                lt.seg_row0[j] = rows;
+                const int64_t seg_units = (static_cast<int64_t>(seg_trades[k].size()) + G - 1) / G;
+                units += seg_units;
+                rows += seg_units * G * lt.seg_rows[j];
+            }
+            for (int j = lt.n_seg; j < adr::kLiteSegments; ++j) { lt.seg_unit0[j] = units; lt.seg_row0[j] = rows; }   // (never reached)
+            lt.n_units = units;
+            if (rows * S > static_cast<int64_t>(UINT32_MAX)) { too_many_rows = true; return; }   // the kernel indexes with 32 bits
+            const size_t n_slots = static_cast<size_t>(units) * G, n_rows = static_cast<size_t>(rows);
+            std::vector<int32_t> slot_trade(n_slots, -1), row_slot(n_rows, -1);
+            std::vector<uint8_t> row_piece(n_rows, 0);
+            for (int j = 0; j < lt.n_seg; ++j) {
+                const int k = used[j];
+                const int R = lt.seg_rows[j];
+                const size_t slot0 = static_cast<size_t>(lt.seg_unit0[j]) * G, row0 = static_cast<size_t>(lt.seg_row0[j]);
+                for (size_t i = 0; i < seg_trades[k].size(); ++i) slot_trade[slot0 + i] = seg_trades[k][i];
+                const size_t slots_here = ((seg_trades[k].size() + G - 1) / G) * G;
+                for (size_t i = 0; i < slots_here; ++i)
+                    for (int r = 0; r < R; ++r) {
+                        row_slot[row0 + i * static_cast<size_t>(R) + static_cast<size_t>(r)] = static_cast<int32_t>(slot0 + i);
+                        row_piece[row0 + i * static_cast<size_t>(R) + static_cast<size_t>(r)] = static_cast<uint8_t>(r);
+                    }
+            }
+            adr::LiteBuildDev lb{};
+            lb.rows = static_cast<int64_t>(n_rows); lb.n_slots = static_cast<int64_t>(n_slots);
+            lb.slot_trade = put32(std::move(slot_trade));
+            lb.row_slot = put32(std::move(row_slot));
+            lb.row_piece = put8(std::move(row_piece));
+            lb.tp_ts = static_cast<double*>(alloc(n_rows * S * 2 * sizeof(double)));
+            lb.al_xtp = static_cast<double*>(alloc(n_rows * S * 2 * sizeof(double)));
+            lb.xpay = static_cast<double*>(alloc(n_rows * S * sizeof(double)));
+            lb.te_w = with_te ? static_cast<double*>(alloc(n_rows * S * 2 * sizeof(double))) : nullptr;
+            lb.slot = static_cast<adr::LiteTrade*>(alloc(n_slots * sizeof(adr::LiteTrade)));
+            if (e == hipSuccess) e = adr::launch_build_lite(csr, lb, stream);
+            lt.tp_ts = lb.tp_ts; lt.al_xtp = lb.al_xtp; lt.xpay = lb.xpay; lt.te_w = lb.te_w; lt.slot = lb.slot;
         };
         build_lite(seg_plain, tr->lite, tr->n_lite, false);
         if (!too_many_rows && tr->n_nonlite > tr->n_nonlite_b) build_lite(seg_lag, tr->lite_lag, tr->n_lite_lag, true);
-        if (too_many_rows) {
-            adr_free_trades(tr);
-            return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^28 rows in the delta-only table; shard the portfolio");
-        }
+    }
+    // the copies and the table builders run on the ctx's stream: the batch is usable once they are done
+    {
+        const hipError_t es = hipStreamSynchronize(stream);        // (also on errors: the copies read this function's vectors)
+        if (e == hipSuccess) e = es;
+    }
+    if (too_many_rows) {
+        adr_free_trades(tr);
+        return fail(ADR_ERR_UNSUPPORTED, "adr_trades_upload: more than 2^28 rows in the delta-only table; shard the portfolio");
     }
     if (e != hipSuccess) { adr_free_trades(tr); return fail_hip(e, "adr_trades_upload: copying trades"); }
     *out = tr;

@@ -45,7 +45,8 @@ constexpr int kLiteThreads = 512;
 constexpr int kLiteWavesPerSimd = 4;                                 // 2 blocks of 8 waves per CU (105 VGPRs)
 constexpr int kLiteSlots = 16;
 constexpr int kLiteCoupons = 15;
-constexpr int kLiteSegments = 9;                                     // at most: trades of 9 ... 1 rows (up to 135 coupons per leg)
+constexpr int kLiteSegments = 9;                                     // distinct row counts per table: 1, 2, 3, 4, 6, 8, 12, 16, 24 rows
+                                                                     // (capi.hip) = up to 360 coupons per leg
 
 // Per-trade header, 32 bytes, read once per trade with scalar loads.
 struct TradeHeader {
@@ -102,7 +103,7 @@ struct TradesDev {
 struct LiteTrade {                    // 32 bytes: one 16-byte and one 8-byte load per lane
     double notional;
     double spread;
-    int32_t meta;                     // n_flt | n_fix << 8 | (float leg pays) << 16 | (fixed leg pays) << 17 (whole trade)
+    int32_t meta;                     // n_flt | n_fix << 9 | (float leg pays) << 18 | (fixed leg pays) << 19 (whole trade)
     int32_t trade;                    // index of the trade in the batch, -1 for an empty slot
     int64_t pad;
 };
@@ -122,6 +123,35 @@ struct LiteRowsDev {
     const double* te_w;               // [n_rows][kLiteSlots][2] accrual end time, notional multiplier - payment-lag rows only (else null)
     const LiteTrade* slot;            // [4 * n_units] per-trade scalars
 };
+
+// The caller's CSR batch on the device (adr_trades_upload) and the work lists of the table builders (trades_build.hip).
+struct CsrDev {
+    int64_t n;
+    const int64_t* fix_off;      // [n + 1]
+    const int64_t* flt_off;
+    const double *fix_tp, *fix_pay, *flt_tp, *flt_ts, *flt_te, *flt_alpha;
+    const double* flt_weight;    // or null
+    const double *notional, *spread, *fix_sign, *flt_sign;      // [n]
+};
+struct RowBuildDev {
+    int64_t rows;
+    const int32_t* piece_trade;  // [rows] trade of the row, -1 for an empty row
+    const int32_t* piece_first;  // [rows] first coupon of the piece, or null (= 0)
+    const uint8_t* piece_more;   // [rows] the trade continues in the group's next row, or null
+    double *row_tp, *row_ts, *row_alpha, *row_xtp, *row_xpay, *row_te, *row_w, *row_notional, *row_spread;   // row_te / row_w may be null
+    int32_t *row_meta, *row_trade;
+};
+struct LiteBuildDev {
+    int64_t rows, n_slots;
+    const int32_t* slot_trade;   // [n_slots] trade in the slot, -1 for an empty one
+    const int32_t* row_slot;     // [rows]
+    const uint8_t* row_piece;    // [rows] which 15-coupon piece of the slot's trade
+    double *tp_ts, *al_xtp, *xpay, *te_w;    // te_w may be null
+    LiteTrade* slot;
+};
+hipError_t launch_build_headers(const CsrDev& csr, TradeHeader* out, hipStream_t stream);
+hipError_t launch_build_rows(const CsrDev& csr, const RowBuildDev& rb, hipStream_t stream);
+hipError_t launch_build_lite(const CsrDev& csr, const LiteBuildDev& lb, hipStream_t stream);
 
 // Curve tables in HBM.
 struct CurveDev {

@@ -227,8 +227,8 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
         ADR_STAMP(0);   // waiting for the step's inputs
         if (r == 0) {
             N = nx_N; spread = nx_spread; t = nx_trade; live = t >= 0;
-            n_flt = nx_meta & 0xff; n_fix = (nx_meta >> 8) & 0xff;
-            sl = (nx_meta & 0x10000) ? -1.0 : 1.0; sf = (nx_meta & 0x20000) ? -1.0 : 1.0;
+            n_flt = nx_meta & 0x1ff; n_fix = (nx_meta >> 9) & 0x1ff;            // (up to 360 coupons per leg: 24 rows)
+            sl = (nx_meta & 0x40000) ? -1.0 : 1.0; sf = (nx_meta & 0x80000) ? -1.0 : 1.0;
             pv = d0 = d1 = e0 = e1 = 0.0;
         }
         // ---- request the next step's inputs

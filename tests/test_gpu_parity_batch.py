@@ -489,3 +489,38 @@ def test_two_payment_lag_batches_on_two_streams_of_one_ctx(gpu_ctx):
     assert_batch_parity(got, ref, batches[1].notional)
     for t in trades:
         t.close()
+
+
+def test_monthly_legs_of_up_to_360_coupons_vs_c_oracle(gpu_ctx):
+    """Legs of 129-360 coupons (`FrequencyTypes.MONTHLY`, cavour/utils/frequency.py:46: a 30Y monthly leg is 360 coupons):
+    chains of up to 12 rows in the fast kernel, up to 24 rows in the lite kernel's payment-lag table; with payment lag
+    and GAMMA they stay on the general kernel (the variant's stash holds 128 nodes per trade).  Same numbers either way."""
+    from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
+    from adrates_amd.utils import BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes
+    vd = F.README_VALUE_DT
+    curve = F.readme_model().curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    rng = np.random.default_rng(31)
+    n = 1501
+    months = rng.integers(130, 361, n)
+    lag = rng.choice([0, 2], size=n, p=[0.7, 0.3])
+    terms = OISTerms(effective_dt=vd, tenor=[f"{int(m)}M" for m in months], coupon=rng.uniform(0.01, 0.07, n),
+                     notional=np.round(rng.uniform(1e6, 5e7, n), -5), pay_fixed=rng.random(n) < 0.5,
+                     fixed_freq_type=[[FrequencyTypes.ANNUAL, FrequencyTypes.MONTHLY][i] for i in rng.choice(2, size=n, p=[0.6, 0.4])],
+                     fixed_dc_type=DayCountTypes.ACT_365F, floating_index=CurveTypes.GBP_OIS_SONIA, currency=CurrencyTypes.GBP,
+                     float_freq_type=FrequencyTypes.MONTHLY, float_dc_type=DayCountTypes.ACT_365F,
+                     float_spread=np.where(rng.random(n) < 0.3, 0.001, 0.0), payment_lag=lag,
+                     bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
+    batch = compile_ois_terms(terms, vd)
+    n_flt = np.diff(batch.flt_off)
+    assert n_flt.min() > 128 and n_flt.max() >= 355
+    dt = _native.DeviceTrades(gpu_ctx, batch)
+    got = _native.price(gpu_ctx, dc, dt, aggregate=True)
+    ref = port.price(4, host.times, host.dfs, host.jac, host.hess, batch)
+    worst = assert_batch_parity(got, ref, batch.notional)
+    assert np.allclose(got["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+    only_d = _native.price(gpu_ctx, dc, dt, want_gamma=False, aggregate=True)
+    assert_batch_parity(only_d, dict(pv=ref["pv"], delta=ref["delta"]), batch.notional)
+    assert np.allclose(only_d["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
+    dt.close()
+    print(f"monthly legs: worst error {worst:.2e}")
