@@ -104,7 +104,8 @@ struct adr_trades {
     adr::TradesDev lagged{};
     adr::TradesDev lagged_chained{};   // ... those of 33-128 coupons per leg as chains of rows (LONG + LAG), laid out for
     int lagged_chained_blocks = 0;     // this grid
-    int64_t n_lagged = 0, n_lagged_long = 0, n_rest = 0;
+    int64_t n_lagged = 0, n_lagged_long = 0, n_rest = 0, n_rest_b = 0;
+    const int32_t* list_rest_b = nullptr;     // list_general without the one-row payment-lag trades (the older variant takes only those)
     // per-wave stash of the payment-lag variant (kernels.hpp, OutputsDev::lag_scratch), sized for a grid of lag_blocks
     // blocks.  It belongs to the BATCH (not to the ctx): two batches priced on two streams never share it.
     double* lag_scratch = nullptr;
@@ -854,16 +855,26 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     tr->n_lagged = static_cast<int64_t>(list_lagged.size());
     tr->n_rest = static_cast<int64_t>(list_rest.size());
     tr->list_rest = static_cast<const int32_t*>(put(list_rest.data(), list_rest.size() * sizeof(int32_t)));
+    {
+        std::vector<int32_t> rest_b;
+        for (int32_t t : list_general) if (rows_of(t) > 1) rest_b.push_back(t);
+        tr->n_rest_b = static_cast<int64_t>(rest_b.size());
+        tr->list_rest_b = put32(std::move(rest_b));
+    }
     if (!list_lagged_long.empty()) {   // payment-lag legs of 33-128 coupons: chains of rows for the grid of the variant
         tr->lagged_chained_blocks = std::max(1, ctx->n_cu);
-        build_chained(list_lagged_long, tr->lagged_chained, tr->lagged_chained_blocks, adr::fast_kernel_threads(true) / 64, true);
+        build_chained(list_lagged_long, tr->lagged_chained, tr->lagged_chained_blocks, adr::lag_kernel_threads() / 64, true);
     }
     if (!list_lagged.empty() || !list_lagged_long.empty()) {
         const int blocks = std::max(1, ctx->n_cu);
         if (e == hipSuccess) {
+            // per-wave scratch of the payment-lag kernels: kernels_lag.hip keeps the side rows beyond its register slots and
+            // their book totals there (and expects zeros), the older variant of kernels_fast.hip its special nodes' stash
             void* p = nullptr;
-            e = hipMalloc(&p, adr::fast_kernel_lag_scratch_bytes(blocks));
+            const size_t bytes = std::max(adr::fast_kernel_lag_scratch_bytes(blocks), adr::lag_kernel_scratch_bytes(blocks));
+            e = hipMalloc(&p, bytes);
             if (e == hipSuccess) { tr->allocations.push_back(p); tr->lag_scratch = static_cast<double*>(p); tr->lag_blocks = blocks; }
+            if (e == hipSuccess) e = hipMemsetAsync(p, 0, bytes, stream);
         }
     }
     if (!list_lagged.empty()) {   // payment-lag rows: one row per trade, sorted by coupon count like the plain table
@@ -1051,10 +1062,15 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     adr::TradesDev fast = trades->dev, chained = trades->chained, general = trades->dev, lagged = trades->lagged,
                    lagged_long = trades->lagged_chained;
     // (the payment-lag variant's ratio nodes are single exponentials: not under LINEAR_FWD_RATES, which go to the general kernel)
+    // kernels_lag.hip takes them on curves with the hub layout (chained rows included: they are laid out for its grid);
+    // other packed curves keep the older variant of kernels_fast.hip for the one-row trades
+    const bool new_lag = adr::lag_kernel_takes(curve->dev);
     const bool use_lag = want_gamma && use_fast && (lagged.n_rows > 0 || lagged_long.n_rows > 0) && trades->lag_scratch != nullptr &&
                          curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES &&
                          trades->lagged_chained_blocks <= trades->lag_blocks;
     if (!use_lag) { lagged.n_rows = 0; lagged_long.n_rows = 0; }
+    const bool lag_long_general = use_lag && !new_lag && lagged_long.n_rows > 0;     // (no chained rows for the older variant)
+    if (lag_long_general) lagged_long.n_rows = 0;
     // (the lite kernel's payment-lag rows: PV / PV + delta of trades with payment lag or per-coupon notionals, log-linear schemes)
     const bool use_lite_lag = !want_gamma && lite_fits && trades->lite_lag.n_units > 0 && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
     if (use_lite || use_lite_lag) {
@@ -1072,15 +1088,15 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
             }
         }
     } else if (use_fast) {
-        general.list = use_lag ? trades->list_rest : trades->list_general;
-        general.n_list = use_lag ? trades->n_rest : trades->n_general;
+        general.list = use_lag ? (lag_long_general ? trades->list_rest_b : trades->list_rest) : trades->list_general;
+        general.n_list = use_lag ? (lag_long_general ? trades->n_rest_b : trades->n_rest) : trades->n_general;
     } else {
         fast.n_rows = 0; chained.n_rows = 0;   // general walks all n trades through the identity list
     }
     int blocks_fast = 0, blocks_chained = 0, blocks_general = 0, blocks_lite = 0, blocks_lag = 0, blocks_litelag = 0, blocks_laglong = 0;
     if (lagged_long.n_rows > 0) blocks_laglong = trades->lagged_chained_blocks;    // the chains are laid out for this grid
     if (lagged.n_rows > 0) {
-        const int waves = adr::fast_kernel_threads(true) / 64;
+        const int waves = (new_lag ? adr::lag_kernel_threads() : adr::fast_kernel_threads(true)) / 64;
         const int64_t units = (lagged.n_rows + adr::fast_kernel_groups() - 1) / adr::fast_kernel_groups();
         const int64_t need = (units + waves - 1) / waves;
         blocks_lag = static_cast<int>(std::min<int64_t>(need, std::min(trades->lag_blocks, ctx->n_cu)));
@@ -1134,7 +1150,8 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     if (blocks_lag > 0) {
         o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general);
         o.lag_scratch = trades->lag_scratch;
-        ADR_HIP(adr::launch_price_fast(curve->dev, lagged, o, want_delta, want_gamma, blocks_lag, stream));
+        if (new_lag) ADR_HIP(adr::launch_price_lag(curve->dev, lagged, o, blocks_lag, stream));
+        else ADR_HIP(adr::launch_price_fast(curve->dev, lagged, o, want_delta, want_gamma, blocks_lag, stream));
     }
     if (blocks_litelag > 0) {
         o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag);
@@ -1143,7 +1160,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     if (blocks_laglong > 0) {
         o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag);
         o.lag_scratch = trades->lag_scratch;
-        ADR_HIP(adr::launch_price_fast(curve->dev, lagged_long, o, want_delta, want_gamma, blocks_laglong, stream));
+        ADR_HIP(adr::launch_price_lag(curve->dev, lagged_long, o, blocks_laglong, stream));
     }
     if (agg_dev)
         ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag + blocks_laglong,

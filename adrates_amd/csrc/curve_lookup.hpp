@@ -20,10 +20,9 @@ struct Lookup {
 // INV_DX: ``C`` also has inv_dx[K] (1 / (x[i] - x[i-1]), 0 where jnp.interp's dx guard applies) and the weight is a
 // multiplication instead of a division (a double-precision divide is about twenty vector instructions; the weight
 // differs from the divided one by an ulp at most, the discount factor by ~1e-16 relative).
-template <bool INV_DX = false, class C>
-__device__ __forceinline__ Lookup curve_lookup(const C& c, double t) {
-    const int K = c.K;
-    // j = first knot with x > t, searched inside the index range the time's bucket allows
+// j = index of the first knot later than t (K when there is none): the bucketed binary search.
+template <class C>
+__device__ __forceinline__ int curve_first_later(const C& c, double t) {
     const double tb = t * kLutPerYear;
     const int bucket = tb > 0.0 ? (tb < static_cast<double>(c.n_lut) ? static_cast<int>(tb) : c.n_lut - 1) : 0;
     int lo = c.lut[2 * bucket], hi = c.lut[2 * bucket + 1];
@@ -31,7 +30,20 @@ __device__ __forceinline__ Lookup curve_lookup(const C& c, double t) {
         const int mid = (lo + hi) >> 1;
         if (c.x[mid] > t) hi = mid; else lo = mid + 1;
     }
-    const int j = lo;
+    return lo;
+}
+
+// true when j IS the first knot later than t (x[j-1] <= t < x[j]): a neighbouring time's result can then be reused
+// instead of searching again - exactly the same j, hence exactly the same lookup.
+template <class C>
+__device__ __forceinline__ bool curve_first_later_is(const C& c, double t, int j) {
+    return (j <= 0 || c.x[j - 1] <= t) && (j >= c.K || c.x[j] > t);
+}
+
+// The lookup proper, given j = curve_first_later(c, t).
+template <bool INV_DX = false, class C>
+__device__ __forceinline__ Lookup curve_lookup_at(const C& c, double t, int j) {
+    const int K = c.K;
     // nearest knot; the first of equal candidates wins, the lower one on a distance tie (argmin)
     double best_dist = 1e300;
     int best = 0;
@@ -70,6 +82,11 @@ __device__ __forceinline__ Lookup curve_lookup(const C& c, double t) {
         r.bb = w;
     }
     return r;
+}
+
+template <bool INV_DX = false, class C>
+__device__ __forceinline__ Lookup curve_lookup(const C& c, double t) {
+    return curve_lookup_at<INV_DX>(c, t, curve_first_later(c, t));
 }
 
 }  // namespace adr
