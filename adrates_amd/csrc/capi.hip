@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -110,6 +111,10 @@ struct adr_trades {
     // blocks.  It belongs to the BATCH (not to the ctx): two batches priced on two streams never share it.
     double* lag_scratch = nullptr;
     int lag_blocks = 0;
+    // which payment-lag kernel the chained rows are laid out for: the date-record kernel (kernels_lag.hip, 12 waves per
+    // block; ADR_LAG_KERNEL=dates at upload time) or the older variant of kernels_fast.hip (8 waves per block, the default:
+    // it is the faster of the two on the benchmark portfolios)
+    bool lag_dates = false;
     const int32_t* list_rest = nullptr;
     adr::LiteRowsDev lite{};
     int64_t n_lite = 0, n_nonlite = 0;
@@ -702,6 +707,10 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     adr_trades* tr = new (std::nothrow) adr_trades();
     if (!tr) return fail(ADR_ERR_NOMEM, "adr_trades_upload: out of memory");
     tr->ctx = ctx;
+    {
+        const char* which = std::getenv("ADR_LAG_KERNEL");
+        tr->lag_dates = which && std::string(which) == "dates";
+    }
     tr->n_fix_flows = n_fix;
     tr->n_flt_flows = n_flt;
     hipError_t e = hipSuccess;
@@ -863,7 +872,8 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     }
     if (!list_lagged_long.empty()) {   // payment-lag legs of 33-128 coupons: chains of rows for the grid of the variant
         tr->lagged_chained_blocks = std::max(1, ctx->n_cu);
-        build_chained(list_lagged_long, tr->lagged_chained, tr->lagged_chained_blocks, adr::lag_kernel_threads() / 64, true);
+        build_chained(list_lagged_long, tr->lagged_chained, tr->lagged_chained_blocks,
+                      (tr->lag_dates ? adr::lag_kernel_threads() : adr::fast_kernel_threads(true)) / 64, true);
     }
     if (!list_lagged.empty() || !list_lagged_long.empty()) {
         const int blocks = std::max(1, ctx->n_cu);
@@ -1064,12 +1074,14 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     // (the payment-lag variant's ratio nodes are single exponentials: not under LINEAR_FWD_RATES, which go to the general kernel)
     // kernels_lag.hip takes them on curves with the hub layout (chained rows included: they are laid out for its grid);
     // other packed curves keep the older variant of kernels_fast.hip for the one-row trades
-    const bool new_lag = adr::lag_kernel_takes(curve->dev);
+    const bool new_lag = trades->lag_dates && adr::lag_kernel_takes(curve->dev);
     const bool use_lag = want_gamma && use_fast && (lagged.n_rows > 0 || lagged_long.n_rows > 0) && trades->lag_scratch != nullptr &&
                          curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES &&
                          trades->lagged_chained_blocks <= trades->lag_blocks;
     if (!use_lag) { lagged.n_rows = 0; lagged_long.n_rows = 0; }
-    const bool lag_long_general = use_lag && !new_lag && lagged_long.n_rows > 0;     // (no chained rows for the older variant)
+    // (chained rows are laid out for one kernel's grid: a batch uploaded for the date-record kernel on a curve that kernel
+    // does not take leaves its chained payment-lag trades to the general kernel)
+    const bool lag_long_general = use_lag && trades->lag_dates && !new_lag && lagged_long.n_rows > 0;
     if (lag_long_general) lagged_long.n_rows = 0;
     // (the lite kernel's payment-lag rows: PV / PV + delta of trades with payment lag or per-coupon notionals, log-linear schemes)
     const bool use_lite_lag = !want_gamma && lite_fits && trades->lite_lag.n_units > 0 && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
@@ -1160,7 +1172,8 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     if (blocks_laglong > 0) {
         o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag);
         o.lag_scratch = trades->lag_scratch;
-        ADR_HIP(adr::launch_price_lag(curve->dev, lagged_long, o, blocks_laglong, stream));
+        if (new_lag) ADR_HIP(adr::launch_price_lag(curve->dev, lagged_long, o, blocks_laglong, stream));
+        else ADR_HIP(adr::launch_price_fast(curve->dev, lagged_long, o, want_delta, want_gamma, blocks_laglong, stream));
     }
     if (agg_dev)
         ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag + blocks_laglong,

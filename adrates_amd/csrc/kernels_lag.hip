@@ -48,11 +48,16 @@ namespace {
 
 typedef double nt_pair __attribute__((ext_vector_type(2)));
 
-constexpr int kThreads = kFastThreads;            // 768: three waves per SIMD, one block per CU (LDS)
+#ifndef ADR_LAG2_THREADS
+#define ADR_LAG2_THREADS kFastThreads
+#endif
+#define ADR_LAG_BOUNDS ADR_LAG2_THREADS
+constexpr int kThreads = ADR_LAG2_THREADS;        // 768: three waves per SIMD, one block per CU (LDS)
 constexpr int kWaves = kThreads / 64;
 constexpr int G = 2, L = 32;                      // trades per wavefront, lanes per trade
 constexpr int kSideSlots = 4;                     // side rows kept in registers
 constexpr int kOutParts = 2;
+constexpr int kScratchPerWave = 2 * kPillarPad * 64 + 24 * 64;     // doubles of global scratch per wavefront (see the kernel)
 
 __device__ __forceinline__ double shfl_d(double x, int src) { return __shfl(x, src, 64); }
 
@@ -95,6 +100,12 @@ __host__ __device__ constexpr int lag_slot_doubles(int epg) {
     return hand_off > staging ? hand_off : staging;
 }
 
+#ifdef ADR_STAMPS
+#define LAG_STAMP(slot_) do { const unsigned long long now_ = clock64(); stamp_sum[slot_] += now_ - stamp_t; stamp_t = now_; } while (0)
+#else
+#define LAG_STAMP(slot_) do {} while (0)
+#endif
+
 constexpr int kNullPair = static_cast<int>((static_cast<unsigned>(-2) << 16) | (static_cast<unsigned>(-2) & 0xffffu));
 // record flags (high word of a record's class double)
 constexpr int kTileNext = 1, kSpecial = 2, kFire = 4;
@@ -102,7 +113,7 @@ constexpr int kTileNext = 1, kSpecial = 2, kFire = 4;
 // STORE: per-trade gamma matrices are written; LONG: rows are chains of 32-coupon pieces (meta bit 18, kernels_fast.hip);
 // EPG / CPG: packed entries per group lane and how many of them are core slots (exact hub variants: CPG = EPG - 2).
 template <bool STORE, bool LONG, int EPG, int CPG>
-__global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
+__global__ __launch_bounds__(ADR_LAG_BOUNDS) void price_lag_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
     static_assert(CPG == EPG - 2, "hub layout: the last two slots hold the fringe pairs");
     constexpr int EPL = (EPG * L + 63) / 64;
     constexpr unsigned long long kGroupMask = (1ull << L) - 1;
@@ -178,44 +189,60 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
 #pragma unroll
     for (int i = 0; i < CPG; ++i) pos[i] = cv.core_pos[l + L * i];
     constexpr int kZeroEntry = 64 * EPL;
-    int mm[8];
-    int beyond = 0;
+    // Output map of this lane (elements 2 lane, 2 lane + 1 of each 128-element band, kernels_fast.hip): read from the
+    // curve's table when a unit's results are written - eight registers the walks do not have to carry
+    auto load_out_map = [&](int (&mm)[8], int& beyond) {
+        beyond = 0;
 #pragma unroll
-    for (int band = 0; band < 8; ++band) {
-        const int raw = *reinterpret_cast<const int*>(cv.store_map + 2 * lane + band * 128);
-        const int m0 = static_cast<int16_t>(raw & 0xffff), m1 = raw >> 16;
-        if (m0 == -2) beyond |= 1 << band;
-        mm[band] = (m0 < 0 ? kZeroEntry : m0) | ((m1 < 0 ? kZeroEntry : m1) << 16);
-    }
+        for (int band = 0; band < 8; ++band) {
+            const int raw = *reinterpret_cast<const int*>(cv.store_map + 2 * lane + band * 128);
+            const int m0 = static_cast<int16_t>(raw & 0xffff), m1 = raw >> 16;
+            if (m0 == -2) beyond |= 1 << band;
+            mm[band] = (m0 < 0 ? kZeroEntry : m0) | ((m1 < 0 ? kZeroEntry : m1) << 16);
+        }
+    };
 
     // per-wave global scratch: [0] book totals of the side rows, [1] side rows beyond the register slots; [32][64] doubles each
-    double* scratch_tot = out.lag_scratch + (static_cast<size_t>(blockIdx.x) * kWaves + wave) * (2 * kPillarPad * 64) + lane;
-    double* scratch_ovf = scratch_tot + kPillarPad * 64;
+    double* const scratch_wave = out.lag_scratch + (static_cast<size_t>(blockIdx.x) * kWaves + wave) * kScratchPerWave;   // (wave-uniform)
+#define scratch_tot (scratch_wave + lane)
+#define scratch_ovf (scratch_wave + kPillarPad * 64 + lane)
+#define scratch_run (scratch_wave + 2 * kPillarPad * 64 + lane)      // [0] pv, [1] delta, [2 ..] packed gamma slices
     const bool want_agg = out.block_partials != nullptr;
     if (want_agg) {
 #pragma unroll 4
         for (int m = 0; m < kPillarPad; ++m) scratch_tot[m * 64] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 2 + EPG; ++i) scratch_run[i * 64] = 0.0;
     }
     unsigned tot_rows = 0;                      // (wave-uniform) pillars whose total row has been added to
 
-    double tot_pv = 0.0, tot_delta = 0.0, tot_gamma[EPL];
-#pragma unroll
-    for (int s = 0; s < EPL; ++s) tot_gamma[s] = 0.0;
+    // (the running book totals - pv, delta, the packed gamma slices - live in the wave's scratch, not in registers: five
+    // read-modify-writes of 512 bytes per unit, nothing waits for them)
 
     const int64_t n_units = (tr.n_rows + G - 1) / G;
     const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * kWaves;
     int64_t unit = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
 
-    // inputs of a unit: lane l of a group holds slot l of the group's row
+    // inputs of a unit, prefetched: the first sixteen coupons of the group's row in the arrangement the chunks work in
+    // (lane pair c holds coupon c); coupons 16-31 are fetched when their chunk starts, the odd fixed coupon of a date of
+    // its own in the fixed pass - nothing of a row stays in registers across the walks
     double nx_tp = 0.0, nx_ts = 0.0, nx_te = 0.0, nx_al = 0.0, nx_w = 1.0, nx_xtp = 0.0, nx_xpay = 0.0, nx_N = 0.0, nx_spread = 0.0;
     int nx_meta = 0, nx_trade = -1;
-    auto load_unit = [&](int64_t u) {
+    // A chunk's first lane pair can be a LEAD pair: no coupon of its own, only the accrual start of the chunk's first coupon
+    // (which otherwise would find no previous date record to ride on).  Chunks after a row's first have one (they hold
+    // fifteen coupons), and so does the first chunk of a row that continues a chain.
+    auto chunk_coupon = [&](bool lead_row, int chunk, int pair) {      // coupon (slot of the row) of a lane pair; the lead pair: its chunk's first
+        const int base = lead_row ? 15 * chunk : (chunk == 0 ? 0 : 16 + 15 * (chunk - 1));
+        const bool lead = lead_row || chunk > 0;
+        return base + (lead ? max(pair - 1, 0) : pair);
+    };
+    auto load_unit = [&](int64_t u, bool lead_row) {
         const int64_t row = u * G + g;
         nx_tp = nx_ts = nx_te = nx_al = nx_xtp = nx_xpay = nx_N = nx_spread = 0.0;
         nx_w = 1.0;
         nx_meta = 0; nx_trade = -1;
         if (u < n_units && row < tr.n_rows) {
-            const int64_t at = row * kRowSlots + l;
+            const int64_t at = row * kRowSlots + chunk_coupon(lead_row, 0, l >> 1);
             nx_tp = __builtin_nontemporal_load(tr.row_tp + at);
             nx_ts = __builtin_nontemporal_load(tr.row_ts + at);
             nx_te = __builtin_nontemporal_load(tr.row_te + at);
@@ -231,7 +258,7 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
         asm volatile("" : "+v"(nx_tp), "+v"(nx_ts), "+v"(nx_te), "+v"(nx_al), "+v"(nx_w), "+v"(nx_xtp), "+v"(nx_xpay),
                           "+v"(nx_N), "+v"(nx_spread), "+v"(nx_meta), "+v"(nx_trade));
     };
-    load_unit(unit);
+    load_unit(unit, false);
     pin_next();
 
     double pv_chain = 0.0, dacc_chain = 0.0, acc_chain[EPG];
@@ -241,12 +268,16 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
 #pragma unroll
     for (int s = 0; s < kSideSlots; ++s) { side[s] = 0.0; side_pillar[s] = -1; }
     bool fresh = true;
+#ifdef ADR_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = clock64();
+#endif
     for (; unit < n_units; unit += wave_stride) {
         double pv_unit = 0.0, dacc_unit = 0.0, acc_unit[EPG];
         double& pv = LONG ? pv_chain : pv_unit;
         double& dacc = LONG ? dacc_chain : dacc_unit;
         double (&acc)[EPG] = LONG ? acc_chain : acc_unit;
-        const double tp = nx_tp, ts = nx_ts, te = nx_te, al = nx_al, cw = nx_w, xtp = nx_xtp, xpay = nx_xpay;
+        double c_tp = nx_tp, c_ts = nx_ts, c_te = nx_te, c_al = nx_al, c_w = nx_w, c_xtp = nx_xtp, c_xpay = nx_xpay;   // chunk 0
         const double N = nx_N, spread = nx_spread;
         const int t = nx_trade;
         const bool live = t >= 0;
@@ -258,17 +289,32 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
 #pragma unroll
             for (int i = 0; i < EPG; ++i) acc[i] = 0.0;
         }
-        // fixed coupons that share no float payment date (lane = slot): a pass of their own below
-        const bool in = live && l < n_flt;
-        const bool fix_in = live && l < n_fix;
-        const bool fix_merged = fix_in && in && xtp == tp;
-        const bool own_fixed = fix_in && !fix_merged && xtp > 0.0 && sf * xpay != 0.0;
+#ifdef ADR_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        LAG_STAMP(0);   // waiting for the unit's inputs (and everything older in the memory queue)
+        const bool lead_row = LONG && !fresh;       // (wave-uniform: both groups' chains are padded to one length)
         int n_chunks;
         {
-            int m = live ? n_flt : 0;
+            int m = live ? max(n_flt, n_fix) : 0;
             m = max(m, __shfl_xor(m, 32, 64));
-            n_chunks = (__builtin_amdgcn_readfirstlane(m) + 15) >> 4;
+            m = __builtin_amdgcn_readfirstlane(m);
+            n_chunks = lead_row ? (m + 14) / 15 : (m <= 16 ? (m > 0 ? 1 : 0) : 1 + (m - 16 + 14) / 15);
         }
+        // the second chunk's coupons, requested now: their round trip hides behind the first chunk's work (a load issued
+        // later would also queue behind this wave's earlier result stores - vector memory operations retire in order)
+        double d_tp = 0.0, d_ts = 0.0, d_te = 0.0, d_al = 0.0, d_w = 1.0, d_xtp = 0.0, d_xpay = 0.0;
+        auto load_chunk = [&](int chunk) {
+            d_tp = d_ts = d_te = d_al = d_xtp = d_xpay = 0.0; d_w = 1.0;
+            if (live) {
+                const int64_t at = (unit * G + g) * kRowSlots + min(chunk_coupon(lead_row, chunk, l >> 1), kRowSlots - 1);
+                d_tp = tr.row_tp[at]; d_ts = tr.row_ts[at]; d_te = tr.row_te[at]; d_al = tr.row_alpha[at];
+                if (tr.row_w) d_w = tr.row_w[at];
+                d_xtp = tr.row_xtp[at]; d_xpay = tr.row_xpay[at];
+            }
+        };
+        if (n_chunks > 1) load_chunk(1);
+        unsigned long long fixed_b[3] = {0, 0, 0};   // fixed coupons that share no float payment date: per chunk, bit = the coupon's even lane
 
         // ---------------------------------------------------------------- shared pieces of the two walks
         int carry_row = zero_row;
@@ -459,16 +505,18 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
 
         // ---------------------------------------------------------------- the float coupons, sixteen at a time
         for (int chunk = 0; chunk < n_chunks; ++chunk) {
-            const int q = 16 * chunk + (l >> 1);              // this lane pair's coupon
-            const int src = gbase + q;                        // (q <= 31: the lane holding its slot)
-            const double tp_q = shfl_d(tp, src), te_q = shfl_d(te, src), ts_q = shfl_d(ts, src), al_q = shfl_d(al, src);
-            const double w_q = tr.row_w ? shfl_d(cw, src) : 1.0;
-            const double xtp_q = shfl_d(xtp, src), xpay_q = shfl_d(xpay, src);
-            const bool have = live && q < n_flt;
+            const int q = chunk_coupon(lead_row, chunk, l >> 1);      // this lane pair's coupon
+            const bool lead = (lead_row || chunk > 0) && (l >> 1) == 0;   // the lead pair: only the accrual start of coupon q counts
+            if (chunk > 0) {
+                if (chunk > 1) load_chunk(chunk);             // (a third chunk: rows of 32 coupons only)
+                c_tp = d_tp; c_ts = d_ts; c_te = d_te; c_al = d_al; c_w = d_w; c_xtp = d_xtp; c_xpay = d_xpay;
+            }
+            const double tp_q = c_tp, te_q = lead ? c_ts : c_te, ts_q = c_ts, al_q = c_al, w_q = c_w, xtp_q = c_xtp, xpay_q = c_xpay;
+            const bool have = live && q < n_flt && q < kRowSlots;
             const bool cin = have && tp_q >= 0.0, accr = al_q > 0.0;
-            // even lane: tp, then te from the same bracket when it holds; odd lane: ts
+            // even lane: tp, then te from the same bracket when it holds; odd lane: ts.  (A lead pair: the odd lane alone.)
             const double t1 = odd ? ts_q : tp_q;
-            const bool look1 = cin && (!odd || accr);
+            const bool look1 = cin && (odd ? accr : !lead);
             int cls1a = -2, cls1b = -2, cls2a = -2, cls2b = -2;
             double b1a = 0.0, b1b = 0.0, b2a = 0.0, b2b = 0.0, ell1 = 0.0, ell2 = 0.0;
             int j1 = 0;
@@ -480,7 +528,7 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
                 cls1b = b1b != 0.0 ? c.knot_class[lq.kb] : -2;
                 ell1 = fma(b1a, c.log_df[lq.ka], b1b * c.log_df[lq.kb]);
             }
-            const bool look2 = !odd && cin && accr;
+            const bool look2 = !odd && cin && accr && !lead;
             if (look2) {
                 const int j2 = curve_first_later_is(c, te_q, j1) ? j1 : curve_first_later(c, te_q);
                 const Lookup lq = curve_lookup_at(c, te_q, j2);
@@ -496,28 +544,34 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
             // (a payment time on the value-time knot snaps to it with weight 1 on a knot that carries no sensitivity: the
             // record's weights refer to the DATE's knots, so they are zero then)
             const double pa_raw = dpp_mov_d<kFromEven>(b1a), pb_raw = dpp_mov_d<kFromEven>(b1b);     // (DPP outside the conditional)
-            const double pa = pair_p != kNullPair ? pa_raw : 0.0, pb = pair_p != kNullPair ? pb_raw : 0.0;
+            const double sa_raw = dpp_mov_d<kFromOdd>(b1a), sb_raw = dpp_mov_d<kFromOdd>(b1b);
+            const double pa = lead ? sa_raw : (pair_p != kNullPair ? pa_raw : 0.0), pb = lead ? sb_raw : (pair_p != kNullPair ? pb_raw : 0.0);
             const double w_not = sl * N * w_q;
             // even lane: the ratio node; odd lane: the payment node (with the fixed coupon of the date)
             double om = 0.0;
             if (!odd) {
-                om = (cin && accr) ? w_not * exp(ell_s - ell2 + ell_p) : 0.0;
-            } else {
+                om = (cin && accr && !lead) ? w_not * exp(ell_s - ell2 + ell_p) : 0.0;
+            } else if (!lead) {
                 double a_q = cin ? w_not * (spread * al_q - (accr ? 1.0 : 0.0)) : 0.0;
                 if (have && q < n_fix && xtp_q == tp_q && xtp_q > 0.0) a_q = fma(sf, xpay_q, a_q);
                 om = a_q * exp(ell_p);
             }
             pv += om;
+            {   // a fixed coupon that found no float payment date of its own gets a pass below
+                const bool own = !odd && !lead && live && q < n_fix && q < kRowSlots && !(have && xtp_q == tp_q) && xtp_q > 0.0 && sf * xpay_q != 0.0;
+                const unsigned long long ob = __ballot(own);
+                if (chunk == 0) fixed_b[0] = ob; else if (chunk == 1) fixed_b[1] = ob; else fixed_b[2] = ob;
+            }
             // the date of the coupon: the payment time's knots; the accrual end's when the payment time carries no
             // sensitivity (the value-time knot, where the weighted coupons of DESIGN.md section 9 are "paid")
-            const bool fold_e = pair_e == pair_p, fold_e0 = pair_p == kNullPair && pair_e != kNullPair;
-            const int dpair = fold_e0 ? pair_e : pair_p;
+            const bool fold_e = !lead && pair_e == pair_p, fold_e0 = !lead && pair_p == kNullPair && pair_e != kNullPair;
+            const int dpair = lead ? pair_s : (fold_e0 ? pair_e : pair_p);       // (a lead pair's "date": the accrual start's knots)
             const bool e_folded = fold_e || fold_e0;
             const bool e_ok = e_folded || pair_e == kNullPair;
             // can the accrual start ride on the previous coupon's date record?  Same time as that coupon's accrual end (so
             // the same lookup), which was folded into its date
             const double prev_te = dpp_mov_d<kShr1>(dpp_mov_d<kShr1>(te_q));
-            const int prev_ok = dpp_mov_i<kShr1>(dpp_mov_i<kShr1>((cin && accr && e_folded) ? 1 : 0));
+            const int prev_ok = dpp_mov_i<kShr1>(dpp_mov_i<kShr1>((cin && accr && (e_folded || lead)) ? 1 : 0));
             const int prev_dpair = dpp_mov_i<kShr1>(dpp_mov_i<kShr1>(dpair));
             const bool s_null = pair_s == kNullPair;
 #ifdef ADR_LAG_NOTILE
@@ -533,6 +587,7 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
             double xa = pa, xb = pb;
             if (fold_e) { xa = pa - b2a; xb = pb - b2b; }
             if (fold_e0) { xa = -b2a; xb = -b2b; }
+            if (lead) { xa = 0.0; xb = 0.0; }          // (the record then hands v_P - v_D = s . (ua, ub) to the next one)
             const double om_r = irregular ? 0.0 : (odd ? 0.0 : om);
             // odd lane: the payment node's Greeks (none on the value-time knot)
             const double om_p = (odd && pair_p != kNullPair) ? om : 0.0;
@@ -545,7 +600,7 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
             const bool special = uses_vacc && has_mini && prev_dpair != dpair;
             const double om_p_pair = dpp_mov_d<kFromOdd>(om_p);
             const bool active = !odd && dpair != kNullPair && (om_r != 0.0 || om_p_pair != 0.0 || tile_next);
-            const int irregular_pair = dpp_mov_i<kFromEven>(irregular ? 1 : 0);
+            const unsigned long long irregular_b = __ballot(irregular);      // (bits at even lanes; nothing else of the build survives the walk)
 #ifdef ADR_LAG_DEBUG
             if (unit == 0 && g == 0 && out.gamma) {
                 double* d = out.gamma + 1024 + 16 * l;
@@ -554,55 +609,7 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
             }
 #endif
 
-            // ---- irregular ratio nodes of this chunk: three single-time parts each (accrual start +, accrual end -,
-            // payment time + and fire), ten coupons per round
-            unsigned long long todo = __ballot(irregular_pair != 0 && !odd);
-            while (todo) {
-                const unsigned mine_bits = static_cast<unsigned>((todo >> gbase) & kGroupMask);
-                const int rank = __builtin_popcount(mine_bits & ((1u << (l & ~1)) - 1u));       // irregular coupons of the group before this one
-                const double w_r = dpp_mov_d<kFromEven>(om);               // the ratio node's weight, for both lanes of the pair
-                const bool mine = irregular_pair != 0 && rank < 10 && ((todo >> (lane & ~1)) & 1ull);
-                // the odd lane has the accrual start; the even lane looks up the accrual end and the payment time again
-                // (the registers of the first lookups are long gone - this path is rare)
-                __builtin_amdgcn_wave_barrier();
-                if (mine) {
-                    double2* base = reinterpret_cast<double2*>(rec + (gbase + 3 * rank) * 4);
-                    if (odd) {
-                        base[0] = make_double2(w_r, b1a);
-                        base[1] = make_double2(b1b, __hiloint2double(0, pair1));
-                    } else {
-                        base[2] = make_double2(w_r, -b2a);
-                        base[3] = make_double2(-b2b, __hiloint2double(0, pair_e));
-                        const bool sp = (pair_has_mini(pair_s) || pair_has_mini(pair_e) || pair_has_mini(pair_p));
-                        base[4] = make_double2(w_r, pa);
-                        base[5] = make_double2(pb, __hiloint2double(kFire | (sp ? kSpecial : 0), pair_p));
-                    }
-                }
-                wave_lds_sync();
-                int cnt = min(__builtin_popcount(mine_bits), 10);
-                cnt = max(cnt, __shfl_xor(cnt, 32, 64));
-                const int n_rec = 3 * __builtin_amdgcn_readfirstlane(cnt);
-                // a group with fewer irregular coupons walks null records for the rest
-                __builtin_amdgcn_wave_barrier();
-                {
-                    const int own = 3 * min(__builtin_popcount(mine_bits), 10);
-                    if (l >= own && l < n_rec) {
-                        double2* wp = reinterpret_cast<double2*>(rec + lane * 4);
-                        wp[0] = make_double2(0.0, 0.0);
-                        wp[1] = make_double2(0.0, __hiloint2double((l % 3 == 2) ? kFire : 0, kNullPair));
-                    }
-                }
-                wave_lds_sync();
-                part_walk((1ull << n_rec) - 1ull);
-                // the coupons done: the first ten of each group
-                unsigned long long done = 0;
-                {
-                    const bool was = mine && !odd;
-                    done = __ballot(was);
-                }
-                todo &= ~done;
-            }
-
+            LAG_STAMP(1);   // chunk build: lookups, exponentials, pair logic
             // ---- date records: the even lane's half {w_r, x, classes | flags}, the odd lane's {w_p, p, -}
             __builtin_amdgcn_wave_barrier();
             {
@@ -620,20 +627,25 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
             unsigned long long rows = __ballot(active);
             rows |= rows >> 32;
             rows &= kGroupMask;
+#if defined(ADR_LAG_ABLATE) && ADR_LAG_ABLATE == 1
+            rows = 0;
+#endif
             if (rows) {
                 __builtin_amdgcn_s_setprio(ADR_WALK_PRIO);
                 int n = __builtin_ctzll(rows);
                 rows &= rows - 1;
                 const double2* rec_g = reinterpret_cast<const double2*>(rec + gbase * 4);
-                double2 a0 = rec_g[2 * n], a1 = rec_g[2 * n + 1], b0 = rec_g[2 * n + 2], b1 = rec_g[2 * n + 3];
+                double2 a0 = rec_g[2 * n], a1 = rec_g[2 * n + 1];
                 while (true) {
                     const bool has_next = rows != 0;
                     const int n_next = has_next ? __builtin_ctzll(rows) : n;
                     rows &= rows - 1;
-                    const double w_r = a0.x, x_a = a0.y, x_b = a1.x, w_p = b0.x, p_a = b0.y, p_b = b1.x;
+                    const double w_r = a0.x, x_a = a0.y, x_b = a1.x;
                     const int word = __double2loint(a1.y), flags = __double2hiint(a1.y);
                     const int ca = static_cast<int16_t>(word & 0xffff), cb = word >> 16;
-                    a0 = rec_g[2 * n_next]; a1 = rec_g[2 * n_next + 1]; b0 = rec_g[2 * n_next + 2]; b1 = rec_g[2 * n_next + 3];
+                    const double2 b0 = rec_g[2 * n + 2], b1 = rec_g[2 * n + 3];      // this record's payment half
+                    a0 = rec_g[2 * n_next]; a1 = rec_g[2 * n_next + 1];               // the next record's ratio half, one record ahead
+                    const double w_p = b0.x, p_a = b0.y, p_b = b1.x;
                     n = n_next;
                     __builtin_amdgcn_sched_barrier(0);
                     const int ra = ca >= 0 ? ca : zero_row, rb = cb >= 0 ? cb : zero_row;
@@ -657,7 +669,9 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
                     const double coef_a = fma(w_r, x_a, fma(w_p, p_a, w_nx * (p_a - x_a)));
                     const double coef_b = fma(w_r, x_b, fma(w_p, p_b, w_nx * (p_b - x_b)));
                     const double coa = convexity_coef(ra, rb, coef_a, coef_b);
+#if !defined(ADR_LAG_ABLATE) || ADR_LAG_ABLATE != 3
                     rank_one(std::true_type{}, w_r, v_r, coa, ra);
+#endif
                     const bool is_special = (flags & kSpecial) != 0;
                     if (__ballot(is_special)) {
                         const unsigned mask = is_special ? (pillar_mask(ca, cb) | pillar_mask(static_cast<int16_t>(prev_word & 0xffff), prev_word >> 16)) : 0u;
@@ -665,20 +679,96 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
                     }
                     prev_word = word;
                     if (any_mini) mini_convexity(ca, cb, coef_a, coef_b);
+#if !defined(ADR_LAG_ABLATE) || ADR_LAG_ABLATE != 3
                     if (__ballot(w_p != 0.0)) rank_one(std::false_type{}, w_p, v_p, 0.0, ra);
+#endif
                     if (!has_next) break;
                 }
                 __builtin_amdgcn_s_setprio(0);
             }
             vacc = 0.0;          // (a chunk's last record never feeds the next chunk: its first coupon is irregular)
+            LAG_STAMP(2);   // date walk
+
+            // ---- irregular ratio nodes of this chunk: three single-time parts each (accrual start +, accrual end -,
+            // payment time + and fire), ten coupons per round.  Rare: the coupon's times are fetched and looked up again
+            // (both lanes of the pair), so that nothing of the build has to live through the date walk
+            unsigned long long todo = irregular_b;
+            while (todo) {
+                const unsigned mine_bits = static_cast<unsigned>((todo >> gbase) & kGroupMask);
+                const int rank = __builtin_popcount(mine_bits & ((1u << (l & ~1)) - 1u));       // irregular coupons of the group before this one
+                const bool mine = rank < 10 && ((todo >> (lane & ~1)) & 1ull);
+                int pair_r = kNullPair, pair_e2 = kNullPair;
+                double ra_w = 0.0, rb_w = 0.0, ea_w = 0.0, eb_w = 0.0, ell_r = 0.0, ell_e2 = 0.0, w_full = 0.0;
+                if (mine) {
+                    const int64_t at = (unit * G + g) * kRowSlots + q;
+                    const double t_r = odd ? tr.row_ts[at] : tr.row_tp[at];
+                    const Lookup lq = curve_lookup(c, t_r);
+                    ra_w = lq.ba; rb_w = lq.bb;
+                    const int ka_c = c.knot_class[lq.ka], kb_c = rb_w != 0.0 ? c.knot_class[lq.kb] : -2;
+                    pair_r = (ka_c & 0xffff) | (kb_c << 16);
+                    ell_r = fma(ra_w, c.log_df[lq.ka], rb_w * c.log_df[lq.kb]);
+                    if (!odd) {
+                        const Lookup le = curve_lookup(c, tr.row_te[at]);
+                        ea_w = le.ba; eb_w = le.bb;
+                        const int ea_c = c.knot_class[le.ka], eb_c = eb_w != 0.0 ? c.knot_class[le.kb] : -2;
+                        pair_e2 = (ea_c & 0xffff) | (eb_c << 16);
+                        ell_e2 = fma(ea_w, c.log_df[le.ka], eb_w * c.log_df[le.kb]);
+                        w_full = sl * N * (tr.row_w ? tr.row_w[at] : 1.0);
+                    }
+                }
+                const double ell_s2 = dpp_mov_d<kFromOdd>(ell_r);
+                const int pair_s2 = dpp_mov_i<kFromOdd>(pair_r);
+                const double w_even = (mine && !odd) ? w_full * exp(ell_s2 - ell_e2 + ell_r) : 0.0;
+                const double w_r = dpp_mov_d<kFromEven>(w_even);             // the ratio node's weight, for both lanes of the pair
+                __builtin_amdgcn_wave_barrier();
+                if (mine) {
+                    double2* base = reinterpret_cast<double2*>(rec + (gbase + 3 * rank) * 4);
+                    if (odd) {
+                        base[0] = make_double2(w_r, ra_w);
+                        base[1] = make_double2(rb_w, __hiloint2double(0, pair_r));
+                    } else {
+                        base[2] = make_double2(w_r, -ea_w);
+                        base[3] = make_double2(-eb_w, __hiloint2double(0, pair_e2));
+                        const bool sp = (pair_has_mini(pair_s2) || pair_has_mini(pair_e2) || pair_has_mini(pair_r));
+                        base[4] = make_double2(w_r, ra_w);
+                        base[5] = make_double2(rb_w, __hiloint2double(kFire | (sp ? kSpecial : 0), pair_r));
+                    }
+                }
+                wave_lds_sync();
+                int cnt = min(__builtin_popcount(mine_bits), 10);
+                cnt = max(cnt, __shfl_xor(cnt, 32, 64));
+                const int n_rec = 3 * __builtin_amdgcn_readfirstlane(cnt);
+                // a group with fewer irregular coupons walks null records for the rest
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const int own = 3 * min(__builtin_popcount(mine_bits), 10);
+                    if (l >= own && l < n_rec) {
+                        double2* wp = reinterpret_cast<double2*>(rec + lane * 4);
+                        wp[0] = make_double2(0.0, 0.0);
+                        wp[1] = make_double2(0.0, __hiloint2double((l % 3 == 2) ? kFire : 0, kNullPair));
+                    }
+                }
+                wave_lds_sync();
+                part_walk((1ull << n_rec) - 1ull);
+                todo &= ~__ballot(mine && !odd);
+            }
 
         }
 
         // ---------------------------------------------------------------- fixed coupons on dates of their own
-        if (__ballot(own_fixed)) {
+        if (fixed_b[0] | fixed_b[1] | fixed_b[2]) {
+            // lane = slot l of the row: which chunk / lane pair had it
+            int f_chunk, f_pair;
+            if (lead_row) { f_chunk = l / 15; f_pair = l % 15 + 1; }
+            else if (l < 16) { f_chunk = 0; f_pair = l; }
+            else { f_chunk = 1 + (l - 16) / 15; f_pair = (l - 16) % 15 + 1; }
+            const unsigned long long fb = f_chunk == 0 ? fixed_b[0] : (f_chunk == 1 ? fixed_b[1] : fixed_b[2]);
+            const bool own_fixed = f_chunk < 3 && ((fb >> (gbase + 2 * f_pair)) & 1ull);
             int cls_a = -2, cls_b = -2;
             double ba = 0.0, bb = 0.0, om = 0.0;
             if (own_fixed) {
+                const int64_t at = (unit * G + g) * kRowSlots + l;
+                const double xtp = tr.row_xtp[at], xpay = tr.row_xpay[at];
                 const Lookup lq = curve_lookup(c, xtp);
                 ba = lq.ba; bb = lq.bb;
                 cls_a = c.knot_class[lq.ka];
@@ -700,30 +790,57 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
             if (rows) part_walk(rows);
         }
         if (__ballot(carry_row != zero_row)) lc_row_pass(carry_row, carry_w);
+        LAG_STAMP(3);   // irregular coupons, fixed coupons of their own
         if (LONG) {
             fresh = !more;
             if (more) {
-                load_unit(unit + wave_stride);
+                load_unit(unit + wave_stride, true);
                 pin_next();
                 continue;
             }
         }
 
         // ---------------------------------------------------------------- results
+        // Everything that LOADS comes first - the output map, the running totals' read-modify-writes, the side rows'
+        // table lookups, the next unit's inputs: vector memory operations retire in order, so a load issued behind this
+        // unit's 16 KB of matrix stores would wait for those to drain.
 #pragma unroll
         for (int off = 1; off < L; off <<= 1) pv += __shfl_xor(pv, off, 64);
         if (live && l == 0) {
             if (out.pv) out.pv[t] = pv;
-            tot_pv += pv;
+        }
+        int mm[8], beyond;
+        load_out_map(mm, beyond);
+        if (want_agg) {
+            scratch_run[0] += (live && l == 0) ? pv : 0.0;
+            scratch_run[64] += dacc;
+#pragma unroll
+            for (int i = 0; i < EPG; ++i) scratch_run[(2 + i) * 64] += acc[i] * 1e-8;      // (this lane's packed entries l + 32 i, its group's trade)
+        }
+        // side rows in register slots: value and whether element (m, l) has no packed entry
+        double side_val[kSideSlots];
+        bool side_ne[kSideSlots];
+#pragma unroll
+        for (int s_ = 0; s_ < kSideSlots; ++s_) {
+            const int m = side_pillar[s_];                       // (wave-uniform)
+            side_val[s_] = side[s_] * 1e-8;
+            side_ne[s_] = false;
+            if (m >= 0) {
+                side_ne[s_] = live && l < P && m < P && cv.out_map[m * kPillarPad + l] < 0;
+                if (want_agg) {
+                    if (side_ne[s_]) scratch_tot[m * 64] += side_val[s_];
+                    tot_rows |= 1u << m;
+                }
+            }
         }
         if (live && l < P && out.delta) __builtin_nontemporal_store(dacc * 1e-4, out.delta + static_cast<int64_t>(t) * P + l);
-        tot_delta += dacc;
         int group_trade[G];
 #pragma unroll
         for (int gg = 0; gg < G; ++gg) group_trade[gg] = __builtin_amdgcn_readfirstlane(__shfl(t, gg * L, 64));
         const int64_t my_gamma = static_cast<int64_t>(t) * (P * P);      // (this lane's own trade: the side-row stores)
 
-        load_unit(unit + wave_stride);          // before the (large) gamma stores: vector memory operations retire in order
+        load_unit(unit + wave_stride, false);   // before the (large) gamma stores
+        LAG_STAMP(4);   // results: loads, totals, pv / delta
 
         __builtin_amdgcn_s_setprio(ADR_OUT_PRIO);
 #pragma unroll
@@ -741,26 +858,14 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
 #pragma unroll
             for (int part = 0; part < kOutParts; ++part) {
                 constexpr int kBands = 8 / kOutParts;
-                double ts_[EPL], gv[2 * kBands];
-                if (part == 0) {
-#pragma unroll
-                    for (int s = 0; s < EPL; ++s) ts_[s] = slot[lane + 64 * s];
-                }
+                double gv[2 * kBands];
 #pragma unroll
                 for (int b = 0; b < kBands; ++b) {
                     gv[2 * b] = slot[mm[kBands * part + b] & 0xffff];
                     gv[2 * b + 1] = slot[mm[kBands * part + b] >> 16];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (part == 0) {
-#pragma unroll
-                    for (int s = 0; s < EPL; ++s) tot_gamma[s] += ts_[s];
-                }
-#ifdef ADR_LAG_DEBUG
-                if (false) {
-#else
                 if (STORE) {
-#endif
 #pragma unroll
                     for (int b = 0; b < kBands; ++b) {
                         const int band = kBands * part + b;
@@ -771,56 +876,63 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
             }
         }
         // ---- side rows of this unit's special nodes: elements (m, q) and (q, m) without a packed entry take the side row
-        // (stored after the matrices: same wave, same addresses, issue order), book totals go to the wave's scratch rows
-        {
-            unsigned used = ovf_rows;
+        // (stored after the matrices: same wave, same addresses, issue order)
 #pragma unroll
-            for (int s = 0; s < kSideSlots; ++s) if (side_pillar[s] >= 0) used |= 1u << side_pillar[s];
-            while (used) {
-                const int m = __builtin_ctz(used);
-                used &= used - 1;
-                double val = 0.0;
-#pragma unroll
-                for (int s = 0; s < kSideSlots; ++s) val += (side_pillar[s] == m) ? side[s] : 0.0;
-                if ((ovf_rows >> m) & 1u) {
-                    val += scratch_ovf[m * 64];
-                    scratch_ovf[m * 64] = 0.0;
+        for (int s_ = 0; s_ < kSideSlots; ++s_) {
+            const int m = side_pillar[s_];
+            if (m >= 0) {
+                if (STORE && out.gamma && side_ne[s_]) {
+                    out.gamma[my_gamma + m * P + l] = side_val[s_];
+                    out.gamma[my_gamma + l * P + m] = side_val[s_];
                 }
-                val *= 1e-8;
-                const bool no_entry = live && l < P && m < P && cv.out_map[m * kPillarPad + l] < 0;
-                if (no_entry) {
-#ifdef ADR_LAG_DEBUG
-                    if (false) {
-#else
-                    if (STORE && out.gamma) {
-#endif
-                        out.gamma[my_gamma + m * P + l] = val;
-                        out.gamma[my_gamma + l * P + m] = val;
-                    }
-                    if (want_agg) scratch_tot[m * 64] += val;
-                }
-                if (want_agg) tot_rows |= 1u << m;
             }
-#pragma unroll
-            for (int s = 0; s < kSideSlots; ++s) { side[s] = 0.0; side_pillar[s] = -1; }
-            ovf_rows = 0;
+            side[s_] = 0.0; side_pillar[s_] = -1;
+        }
+        // rows beyond the register slots (rare: more than four distinct short-end pillars in a unit's special nodes): from
+        // the wave's scratch, behind the stores
+        while (ovf_rows) {
+            const int m = __builtin_ctz(ovf_rows);
+            ovf_rows &= ovf_rows - 1;
+            const double val = scratch_ovf[m * 64] * 1e-8;
+            scratch_ovf[m * 64] = 0.0;
+            const bool no_entry = live && l < P && m < P && cv.out_map[m * kPillarPad + l] < 0;
+            if (no_entry) {
+                if (STORE && out.gamma) {
+                    out.gamma[my_gamma + m * P + l] = val;
+                    out.gamma[my_gamma + l * P + m] = val;
+                }
+                if (want_agg) scratch_tot[m * 64] += val;
+            }
+            if (want_agg) tot_rows |= 1u << m;
         }
         __builtin_amdgcn_s_setprio(0);
+        LAG_STAMP(5);   // results: expansion and stores
         pin_next();
     }
+#ifdef ADR_STAMPS
+    if (out.stamps && lane == 0) {
+        unsigned long long* dst = out.stamps + (static_cast<size_t>(blockIdx.x) * kWaves + wave) * 8;
+        for (int i = 0; i < 8; ++i) dst[i] = stamp_sum[i];
+    }
+#endif
 
     // ------------------------------------------------------------------------ block partial of the aggregate
     if (out.block_partials) {
         double blk_gamma[kGammaPerLane];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int s = 0; s < EPL; ++s) slot[lane + 64 * s] = tot_gamma[s];
+        for (int i = 0; i < EPG; ++i) {
+            double v = scratch_run[(2 + i) * 64];
+            v += __shfl_xor(v, 32, 64);                       // both groups' trades
+            if (g == 0) slot[l + L * i] = v;
+        }
         wave_lds_sync();
 #pragma unroll
         for (int e = 0; e < kGammaPerLane; ++e) {
             const int m = cv.out_map[(4 * bi + (e >> 2)) * kPillarPad + 4 * bj + (e & 3)];
             blk_gamma[e] = m >= 0 ? slot[m] : 0.0;
         }
+        double tot_pv = scratch_run[0], tot_delta = scratch_run[64];
         tot_pv += __shfl_xor(tot_pv, 32, 64);
         tot_delta += __shfl_xor(tot_delta, 32, 64);
         __syncthreads();
@@ -862,6 +974,10 @@ __global__ __launch_bounds__(kThreads) void price_lag_kernel(CurveDev cv, Trades
     }
 }
 
+#undef scratch_tot
+#undef scratch_ovf
+#undef scratch_run
+
 using KernelFn = void (*)(CurveDev, TradesDev, OutputsDev);
 
 template <bool STORE, bool LONG>
@@ -883,7 +999,7 @@ bool lag_kernel_takes(const CurveDev& cv) {
 int lag_kernel_threads() { return kThreads; }
 
 size_t lag_kernel_scratch_bytes(int n_blocks) {
-    return sizeof(double) * static_cast<size_t>(n_blocks) * kWaves * (2 * kPillarPad * 64);
+    return sizeof(double) * static_cast<size_t>(n_blocks) * kWaves * kScratchPerWave;
 }
 
 size_t lag_kernel_lds_bytes(const CurveDev& cv) {

@@ -524,3 +524,42 @@ def test_monthly_legs_of_up_to_360_coupons_vs_c_oracle(gpu_ctx):
     assert np.allclose(only_d["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
     dt.close()
     print(f"monthly legs: worst error {worst:.2e}")
+
+
+def test_date_record_payment_lag_kernel_vs_c_oracle(gpu_ctx, monkeypatch):
+    """kernels_lag.hip - two lanes per coupon, one 64-byte date record per coupon, side rows for the special nodes, three
+    waves per SIMD - is an opt-in (ADR_LAG_KERNEL=dates when the batch is uploaded; the older variant of kernels_fast.hip
+    is faster on the benchmark books): same numbers on a mixed payment-lag book with chained rows,
+    seasoned and forward-starting trades, spreads, all lags, and on the book aggregates."""
+    from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
+    from adrates_amd.utils import BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes
+    vd = F.README_VALUE_DT
+    rng = np.random.default_rng(77)
+    n = 8000
+    starts = [vd, vd.add_months(-7), vd.add_years(-2), vd.add_months(5)]
+    eff = [starts[i] for i in rng.choice(4, size=n, p=[0.55, 0.15, 0.1, 0.2])]
+    lfreq = [[FrequencyTypes.ANNUAL, FrequencyTypes.SEMI_ANNUAL, FrequencyTypes.QUARTERLY, FrequencyTypes.MONTHLY][i]
+             for i in rng.choice(4, size=n, p=[0.5, 0.25, 0.2, 0.05])]
+    terms = OISTerms(effective_dt=eff, tenor=[f"{int(m)}M" for m in rng.integers(1, 361, n)],
+                     coupon=rng.uniform(0.0, 0.08, n), notional=np.round(rng.uniform(1e5, 9e7, n), -4),
+                     pay_fixed=rng.random(n) < 0.5,
+                     fixed_freq_type=[[FrequencyTypes.ANNUAL, FrequencyTypes.QUARTERLY][i] for i in rng.choice(2, size=n, p=[0.7, 0.3])],
+                     fixed_dc_type=DayCountTypes.ACT_365F, floating_index=CurveTypes.GBP_OIS_SONIA, currency=CurrencyTypes.GBP,
+                     float_freq_type=lfreq, float_dc_type=[[DayCountTypes.ACT_365F, DayCountTypes.ACT_360][i] for i in rng.integers(0, 2, n)],
+                     float_spread=np.where(rng.random(n) < 0.3, rng.uniform(-0.002, 0.004, n), 0.0),
+                     payment_lag=rng.choice([0, 1, 2, 5, 10], size=n), bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
+    batch = compile_ois_terms(terms, vd)
+    monkeypatch.setenv("ADR_LAG_KERNEL", "dates")
+    for interp in (InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES):
+        curve = F.gbp_model(vd, interp).curves.GBP_OIS_SONIA
+        host, dc = _device_curve(gpu_ctx, curve)
+        dt = _native.DeviceTrades(gpu_ctx, batch)
+        got = _native.price(gpu_ctx, dc, dt, aggregate=True)
+        ref = port.price(interp.value, host.times, host.dfs, host.jac, host.hess, batch)
+        worst = assert_batch_parity(got, ref, batch.notional)
+        assert np.allclose(got["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+        assert np.allclose(got["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
+        only_agg = _native.price(gpu_ctx, dc, dt, per_trade=False, aggregate=True)
+        assert np.allclose(only_agg["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+        dt.close()
+        print(f"date-record kernel, {interp.name}: worst error {worst:.2e}")
