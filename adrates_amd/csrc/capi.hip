@@ -239,6 +239,8 @@ int adr_curve_layout_host(int K, int P, const double* times, const double* dfs, 
         info[8] = static_cast<int64_t>(g);
         info[9] = adr::general_lds_rows_fit(g, t.Ec, t.n_fringe) ? 1 : 0;
     }
+    info[10] = t.cpg;
+    info[11] = t.hub ? 1 : 0;
     return ADR_OK;
 }
 

@@ -117,10 +117,39 @@ std::string build_curve_tables(int K, int P, const double* times, const double* 
 // untouched) when the pairs do not fit.
 static bool hub_layout(int Pc, const std::vector<int>& core_pillars, int cpg, CurveTables& t) {
     if (Pc < 1 || Pc > kGroupLanes) return false;
+    // IDENTITY positions: entry e = lane + 32 * slot of a convexity row sits at position e of the (compact) row, so a lane
+    // reads its slots at one base address plus constants (no per-slot address arithmetic in the kernels).  The compact row
+    // holds the Ec real pairs at positions 0 .. Ec - 1, so the padding slots must be exactly the entries e >= Ec: the LAST
+    // slot of the last `n_short` lanes.  Hence: `n_full` lanes carry cpg pairs, the last `n_short` lanes cpg - 1, and every
+    // hub's pair count (its loop included) is cpg * (its full lanes) + (cpg - 1) * (its short lanes) - exactly.
+    const int Ec = Pc * (Pc + 1) / 2;
+    const int n_short = cpg * kGroupLanes - Ec, n_full = kGroupLanes - n_short;
+    if (n_short < 0 || n_full < 0) return false;
     std::vector<int> lanes_of(Pc, kGroupLanes / Pc);
     for (int h = 0; h < kGroupLanes % Pc; ++h) ++lanes_of[h];
+    // short lanes: one per hub, hubs with the most lanes first (keeps the pair counts - the out-degrees of the star
+    // decomposition - as even as the lane granularity allows), round robin beyond that
+    std::vector<int> short_of(Pc, 0);
+    {
+        std::vector<int> order(Pc);
+        for (int h = 0; h < Pc; ++h) order[h] = h;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lanes_of[a] > lanes_of[b]; });
+        int left = n_short;
+        for (int round = 0; left > 0 && round < kGroupLanes; ++round)
+            for (int k = 0; k < Pc && left > 0; ++k) {
+                const int h = order[k];
+                if (short_of[h] < lanes_of[h]) { ++short_of[h]; --left; }
+            }
+        if (left > 0) return false;
+    }
     std::vector<int> cap(Pc);
-    for (int h = 0; h < Pc; ++h) cap[h] = cpg * lanes_of[h] - 1;   // one slot is the loop (h, h)
+    int cap_sum = 0;
+    for (int h = 0; h < Pc; ++h) {
+        cap[h] = cpg * (lanes_of[h] - short_of[h]) + (cpg - 1) * short_of[h] - 1;   // one slot is the loop (h, h)
+        if (cap[h] < 0) return false;
+        cap_sum += cap[h];
+    }
+    if (cap_sum != Ec - Pc) return false;                          // (exact: every slot but the designated padding is a real pair)
     struct Edge { int a, b, at; };
     std::vector<Edge> edges;
     for (int a = 0; a < Pc; ++a)
@@ -161,46 +190,48 @@ static bool hub_layout(int Pc, const std::vector<int>& core_pillars, int cpg, Cu
         }
         if (!placed) return false;
     }
+    for (int h = 0; h < Pc; ++h)
+        if (load[h] != cap[h]) return false;
 
-    const int n_core_entries = cpg * kGroupLanes, Ec = Pc * (Pc + 1) / 2;
+    // lanes: every hub's full lanes first (lanes 0 .. n_full - 1), then the short lanes (their last slot is the padding)
+    const int n_core_entries = cpg * kGroupLanes;
     std::vector<uint8_t> pq(2 * static_cast<size_t>(n_core_entries));
     std::vector<char> real(n_core_entries, 0);
-    int lane = 0;
+    int lane_full = 0, lane_short = n_full;
     for (int h = 0; h < Pc; ++h) {
         std::vector<int> partners{h};                              // the loop first
         for (int ei : held[h]) partners.push_back(edges[ei].a == h ? edges[ei].b : edges[ei].a);
-        for (size_t k = 0; k < partners.size(); k += static_cast<size_t>(cpg), ++lane) {
-            if (lane >= kGroupLanes) return false;
+        size_t k = 0;
+        for (int j = 0; j < lanes_of[h]; ++j) {
+            const bool is_short = j >= lanes_of[h] - short_of[h];
+            const int lane = is_short ? lane_short++ : lane_full++;
+            const int n_here = is_short ? cpg - 1 : cpg;
             for (int i = 0; i < cpg; ++i) {
                 const int e = lane + kGroupLanes * i;
-                const bool on = k + static_cast<size_t>(i) < partners.size();
+                const bool on = i < n_here;
                 pq[2 * e] = static_cast<uint8_t>(core_pillars[h]);
                 pq[2 * e + 1] = static_cast<uint8_t>(core_pillars[on ? partners[k + static_cast<size_t>(i)] : h]);
                 real[e] = on;
             }
+            k += static_cast<size_t>(n_here);
         }
+        if (k != partners.size()) return false;
     }
-    for (; lane < kGroupLanes; ++lane)                             // idle lanes: padding on the first core pillar
-        for (int i = 0; i < cpg; ++i) {
-            const int e = lane + kGroupLanes * i;
-            pq[2 * e] = pq[2 * e + 1] = static_cast<uint8_t>(core_pillars[0]);
-        }
-    // compact row positions, slot-major, so that the lanes of one slot read (nearly) consecutive addresses
-    // A padding slot reads the position of the next real entry (the row's trailing zero at the very end): its
-    // accumulator is never output, and an address shared with a neighbouring lane costs no LDS bank conflict,
-    // where a common "zero" position would collide with whichever lane reads the same bank.
-    t.core_pos.assign(n_core_entries, static_cast<int16_t>(Ec));
+    if (lane_full != n_full || lane_short != kGroupLanes) return false;
+    // row positions: the identity (a padding slot - entry e >= Ec - reads the row's trailing zero or the head of the next
+    // row: its accumulator is never output)
+    t.core_pos.assign(n_core_entries, 0);
     t.lcc_pq.assign(2 * static_cast<size_t>(Ec), 0);
-    int pos = 0;
     for (int e = 0; e < n_core_entries; ++e) {
-        t.core_pos[e] = static_cast<int16_t>(pos);                 // pos <= Ec
+        t.core_pos[e] = static_cast<int16_t>(e);
         if (real[e]) {
-            t.lcc_pq[2 * pos] = pq[2 * e];
-            t.lcc_pq[2 * pos + 1] = pq[2 * e + 1];
-            ++pos;
+            if (e >= Ec) return false;
+            t.lcc_pq[2 * e] = pq[2 * e];
+            t.lcc_pq[2 * e + 1] = pq[2 * e + 1];
+        } else if (e < Ec) {
+            return false;
         }
     }
-    if (pos != Ec) return false;
     t.core_real.assign(real.begin(), real.end());
     t.ent_pq.assign(pq.begin(), pq.end());
     return true;

@@ -263,9 +263,6 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
         vq[i] = on ? cv.ent_pq[2 * e + 1] : 0;
     }
     const int hub_p = HUB ? up[0] : 0;            // == up[i] for every core slot i < CPG
-    int pos[CPG > 0 ? CPG : 1];                   // position of core entry l + L*i in a convexity row
-#pragma unroll
-    for (int i = 0; i < CPG; ++i) pos[i] = HUB ? cv.core_pos[l + L * i] : l + L * i;
 
     // Output map of this lane: it writes elements 2*lane, 2*lane + 1 of each 128-element band of a trade's
     // flat [P][P] matrix (4 rows when P = 32), so every store instruction covers 1 KB of consecutive addresses;
@@ -435,11 +432,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
         // rank-one update's batches as well, instead of carrying it: 5 % slower, 12 bytes of scratch.)
         auto lc_row_pass = [&](int row, double w) {
             double lr[CPG > 0 ? CPG : 1];
-            if (HUB) {
-                const double* src = c.lcc + __mul24(row, c.ec_stride);
-#pragma unroll
-                for (int i = 0; i < CPG; ++i) lr[i] = src[pos[i]];
-            } else {
+            {   // entry l + L*i of a row sits at position l + L*i (the hub layout too: curve_tables.cpp, hub_layout)
                 const double* src = c.lcc + __mul24(row, c.ec_stride) + l;
 #pragma unroll
                 for (int i = 0; i < CPG; ++i) lr[i] = src[L * i];
@@ -693,7 +686,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
 #if ADR_RANK_PRIO
                     __builtin_amdgcn_s_setprio(ADR_RANK_PRIO);
 #endif
-                    const double* rowa = c.lcc + __mul24(row, c.ec_stride) + (HUB ? 0 : l);
+                    const double* rowa = c.lcc + __mul24(row, c.ec_stride) + l;
                     // All operands of a batch of entries are fetched before any of them is used: the scheduling barrier
                     // keeps the compiler from pairing each LDS read with its FMA (which would expose one LDS round trip
                     // per entry).
@@ -710,7 +703,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                             if (!HUB) uu[i] = vbuf[up[i0 + i]];
                             vv[i] = vbuf[vq[i0 + i]];
                             // convexity rows: entry l + L*i of a row sits at row[l + L*i] (hub layout: row[pos[i]])
-                            if (WITH_ROW && i0 + i < CPG) la[i] = HUB ? rowa[pos[i0 + i]] : rowa[L * (i0 + i)];
+                            if (WITH_ROW && i0 + i < CPG) la[i] = rowa[L * (i0 + i)];
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

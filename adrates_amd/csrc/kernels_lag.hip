@@ -185,9 +185,6 @@ __global__ __launch_bounds__(ADR_LAG_BOUNDS) void price_lag_kernel(CurveDev cv, 
         vq[i] = e < cv.Eu ? cv.ent_pq[2 * e + 1] : 0;
     }
     const int hub_p = l < cv.Eu ? cv.ent_pq[2 * l] : 0;
-    int pos[CPG];
-#pragma unroll
-    for (int i = 0; i < CPG; ++i) pos[i] = cv.core_pos[l + L * i];
     constexpr int kZeroEntry = 64 * EPL;
     // Output map of this lane (elements 2 lane, 2 lane + 1 of each 128-element band, kernels_fast.hip): read from the
     // curve's table when a unit's results are written - eight registers the walks do not have to carry
@@ -321,9 +318,9 @@ __global__ __launch_bounds__(ADR_LAG_BOUNDS) void price_lag_kernel(CurveDev cv, 
         double carry_w = 0.0;
         auto lc_row_pass = [&](int row, double w) {
             double lr[CPG];
-            const double* src = c.lcc + __mul24(row, c.ec_stride);
+            const double* src = c.lcc + __mul24(row, c.ec_stride) + l;      // (hub layout: identity row positions)
 #pragma unroll
-            for (int i = 0; i < CPG; ++i) lr[i] = src[pos[i]];
+            for (int i = 0; i < CPG; ++i) lr[i] = src[L * i];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < CPG; ++i) acc[i] = fma(w, lr[i], acc[i]);
@@ -386,7 +383,7 @@ __global__ __launch_bounds__(ADR_LAG_BOUNDS) void price_lag_kernel(CurveDev cv, 
             vbuf[l] = vv_;
             wave_lds_sync();
             __builtin_amdgcn_s_setprio(ADR_RANK_PRIO);
-            const double* rowa = c.lcc + __mul24(row, c.ec_stride);
+            const double* rowa = c.lcc + __mul24(row, c.ec_stride) + l;
             constexpr int kBatch = ADR_FAST_BATCH;
             double hub_v = 0.0;
 #pragma unroll
@@ -397,7 +394,7 @@ __global__ __launch_bounds__(ADR_LAG_BOUNDS) void price_lag_kernel(CurveDev cv, 
                 for (int i = 0; i < kBatch; ++i) {
                     if (i0 + i >= EPG) continue;
                     vv[i] = vbuf[vq[i0 + i]];
-                    if (WITH_ROW && i0 + i < CPG) la[i] = rowa[pos[i0 + i]];
+                    if (WITH_ROW && i0 + i < CPG) la[i] = rowa[L * (i0 + i)];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -107,9 +107,10 @@ int adr_curve_tables_host(int K, int P, const double* times, const double* dfs,
 
 /*
  * Diagnostic twin of adr_curve_tables_host: how the fast kernels would lay this curve out in LDS.
- * info[10] = { packed layout usable (0/1), core pillars Pc, core pairs Ec, packed entries Eu,
+ * info[12] = { packed layout usable (0/1), core pillars Pc, core pairs Ec, packed entries Eu,
  *              entries per lane, core-table rows, short-end (mini) knots, LDS bytes of the gamma kernel,
- *              LDS bytes of the general kernel's variant with resident convexity rows (0: none), that variant fits (0/1) }.
+ *              LDS bytes of the general kernel's variant with resident convexity rows (0: none), that variant fits (0/1),
+ *              core slots per lane, hub layout found (0/1: the exact kernel variants; 0 = the universal ones) }.
  * Returns 0 or a negative status.  No GPU needed.
  */
 int adr_curve_layout_host(int K, int P, const double* times, const double* dfs,
