@@ -59,6 +59,9 @@
 #ifndef ADR_FAST_LINDF
 #define ADR_FAST_LINDF 0
 #endif
+#ifndef ADR_FAST_BOTH_ROWS
+#define ADR_FAST_BOTH_ROWS 2      // 0: carry the right knot's convexity weight; 1: both rows per node (plain kernels); 2: the payment-lag variant too
+#endif
 
 namespace adr {
 
@@ -253,6 +256,11 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
     // Exact variants (CPG < EPG) use the hub layout: the CPG core pairs of a lane share their first pillar,
     // whose v is read once per node; their convexity values sit at per-lane positions of the compact row.
     constexpr bool HUB = GAMMA && CPG < EPG;
+    // BOTH_ROWS: a node's two convexity rows are read in the rank-one update's batches.  The alternative - the right knot's
+    // weight carried to the next node, whose left knot it is on a grid without duplicate knots - never matches on the
+    // reference's grids off the knots (a time is bracketed by the LAST knot of a run on the left and the FIRST of a run on
+    // the right: different knots of one date), so every node paid a separate row pass for the flush.
+    constexpr bool BOTH_ROWS = GAMMA && (!LAG || ADR_FAST_BOTH_ROWS > 1) && ADR_FAST_LINDF == 0 && ADR_FAST_BOTH_ROWS != 0;
     static_assert(!HUB || PPL == 1, "exact variants: group lane l holds pillar l");
     int up[EPG], vq[EPG];                         // the two pillars of packed entry l + L*i (0, 0 if none)
 #pragma unroll
@@ -677,8 +685,9 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                 };
                 // rank-one update om_r * vv vv^T through the group's LDS slot, with the left row's convexity term
                 // (coefficient coa) folded into the same batches of LDS reads when WITH_ROW
-                auto rank_one_row = [&](auto with_row, double om_r, const double (&vv_)[PPL], double coa, int row) {
+                auto rank_one_rows = [&](auto with_row, auto two_rows, double om_r, const double (&vv_)[PPL], double coa, int row, double cob, int row_b) {
                     constexpr bool WITH_ROW = decltype(with_row)::value;
+                    constexpr bool TWO_ROWS = WITH_ROW && decltype(two_rows)::value;       // both knots' convexity rows in these batches (no carry)
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int k = 0; k < PPL; ++k) vbuf[l + L * k] = vv_[k];
@@ -687,6 +696,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                     __builtin_amdgcn_s_setprio(ADR_RANK_PRIO);
 #endif
                     const double* rowa = c.lcc + __mul24(row, c.ec_stride) + l;
+                    const double* rowb = c.lcc + __mul24(TWO_ROWS ? row_b : row, c.ec_stride) + l;
                     // All operands of a batch of entries are fetched before any of them is used: the scheduling barrier
                     // keeps the compiler from pairing each LDS read with its FMA (which would expose one LDS round trip
                     // per entry).
@@ -694,7 +704,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                     double hub_v = 0.0;
 #pragma unroll
                     for (int i0 = 0; i0 < EPG; i0 += kBatch) {
-                        double uu[kBatch], vv[kBatch], la[kBatch];
+                        double uu[kBatch], vv[kBatch], la[kBatch], lb[TWO_ROWS ? kBatch : 1];
                         if (HUB && i0 == 0) hub_v = vbuf[hub_p];
 #pragma unroll
                         for (int i = 0; i < kBatch; ++i) {
@@ -704,6 +714,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                             vv[i] = vbuf[vq[i0 + i]];
                             // convexity rows: entry l + L*i of a row sits at row[l + L*i] (hub layout: row[pos[i]])
                             if (WITH_ROW && i0 + i < CPG) la[i] = rowa[L * (i0 + i)];
+                            if (TWO_ROWS && i0 + i < CPG) lb[i] = rowb[L * (i0 + i)];
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -714,6 +725,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                             if (WITH_ROW && i0 + i < CPG) {
                                 const bool core = CPG < EPG || (i0 + i) < core_entries;   // compile-time true unless universal
                                 gsum = fma(core ? coa : 0.0, la[i], gsum);
+                                if (TWO_ROWS) gsum = fma(core ? cob : 0.0, lb[i], gsum);
                             }
                             acc[i0 + i] = gsum;
                         }
@@ -722,6 +734,9 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
 #if ADR_RANK_PRIO
                     __builtin_amdgcn_s_setprio(ADR_WALK_PRIO);
 #endif
+                };
+                auto rank_one_row = [&](auto with_row, double om_r, const double (&vv_)[PPL], double coa, int row) {
+                    rank_one_rows(with_row, std::false_type{}, om_r, vv_, coa, row, 0.0, 0);
                 };
                 auto rank_one = [&](auto with_row, double om_r, const double (&vv_)[PPL], double coa) {
                     rank_one_row(with_row, om_r, vv_, coa, ra);
@@ -768,9 +783,13 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                     stash_special(v1, om);
                     if (GAMMA) {
                         const double coef_a = fma(om, wa, fma(om_p, wpa, om_s * wsa)), coef_b = fma(om, wb, fma(om_p, wpb, om_s * wsb));
-                        const double coa = convexity_coef(coef_a, coef_b);
                         ADR_STAMP(6);   // (walk, date record) the three v, first-order sums, convexity coefficient
-                        rank_one(std::true_type{}, om, v1, coa);
+                        if (BOTH_ROWS) {
+                            rank_one_rows(std::true_type{}, std::true_type{}, om, v1, coef_a, ra, coef_b, rb);
+                        } else {
+                            const double coa = convexity_coef(coef_a, coef_b);
+                            rank_one(std::true_type{}, om, v1, coa);
+                        }
                         mini_convexity(coef_a, coef_b);
                         if (__ballot(om_p != 0.0)) rank_one(std::false_type{}, om_p, vp, 0.0);
                         ADR_STAMP(7);   // (walk, date record) the two rank-one updates
@@ -785,8 +804,13 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                         vacc[k] += vk;
                     }
                     if (GAMMA) {
-                        const double coa = convexity_coef(om_e * wa, om_e * wb);
-                        lc_row_pass(ra, coa);
+                        if (BOTH_ROWS) {
+                            lc_row_pass(ra, om_e * wa);
+                            if (__ballot(rb != zero_row)) lc_row_pass(rb, om_e * wb);
+                        } else {
+                            const double coa = convexity_coef(om_e * wa, om_e * wb);
+                            lc_row_pass(ra, coa);
+                        }
                         mini_convexity(om_e * wa, om_e * wb);
                     }
                 } else {
@@ -798,7 +822,13 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                         v[k] = fma(wb, ub[k], wa * ua[k]);
                         dacc[k] = fma(om_n, v[k], dacc[k]);
                     }
-                    if (GAMMA) {
+                    if (GAMMA && BOTH_ROWS) {
+                        ADR_STAMP(6);
+                        // (a branch for nodes on a single knot - one row - was measured: slower, it costs registers)
+                        rank_one_rows(std::true_type{}, std::true_type{}, om_n, v, om_n * wa, ra, om_n * wb, rb);
+                        ADR_STAMP(7);
+                        mini_convexity(om_n * wa, om_n * wb);
+                    } else if (GAMMA) {
                         const double coa = convexity_coef(om_n * wa, om_n * wb);
                         ADR_STAMP(6);   // (walk) v, first-order sums, convexity coefficient
                         if (!LAG && lindf) {
