@@ -59,6 +59,9 @@
 #ifndef ADR_FAST_LINDF
 #define ADR_FAST_LINDF 0
 #endif
+#ifndef ADR_FAST_LJ_PREFETCH
+#define ADR_FAST_LJ_PREFETCH 0    // 1: the next node's Jacobian entries are requested with the second batch of the rank-one update
+#endif
 #ifndef ADR_FAST_BOTH_ROWS
 #define ADR_FAST_BOTH_ROWS 2      // 0: carry the right knot's convexity weight; 1: both rows per node (plain kernels); 2: the payment-lag variant too
 #endif
@@ -591,6 +594,15 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
             any_row &= any_row - 1;
             const double2* rec_g = reinterpret_cast<const double2*>(rec + gbase * 4);
             double2 nx0 = rec_g[2 * n], nx1 = rec_g[2 * n + 1];
+            constexpr bool LJPRE = GAMMA && !LAG && PPL == 1 && ADR_FAST_LINDF == 0 && ADR_FAST_LJ_PREFETCH != 0;
+            double pre_ua = 0.0, pre_ub = 0.0;            // LJPRE: the Jacobian entries of the node about to be walked
+            auto request_rows = [&]() {                   // ... requested from the record in nx0 / nx1
+                const int n_ca = __double2loint(nx1.y), n_cb = __double2hiint(nx1.y);
+                const int n_ra = n_ca >= 0 ? n_ca : zero_row, n_rb = n_cb >= 0 ? n_cb : zero_row;
+                pre_ua = c.ljc[__mul24(n_ra, c.pc_pad) + col[0]];
+                pre_ub = c.ljc[__mul24(n_rb, c.pc_pad) + col[0]];
+            };
+            if (LJPRE) request_rows();
             while (true) {
                 const bool has_next = any_row != 0;
                 const int n_next = has_next ? __builtin_ctzll(any_row) : n;   // nothing left: read n again
@@ -617,7 +629,9 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                 // LJ at this lane's pillars for the record's two knots: core rows (the zero row for anything else),
                 // the short-end knots' one or two entries from their records
                 double ua[PPL], ub[PPL];
-                {
+                if (LJPRE) {
+                    ua[0] = pre_ua; ub[0] = pre_ub;
+                } else {
                     // (24-bit multiplies: full rate, v_mul_lo_u32 is quarter rate)
                     const double* lja = c.ljc + __mul24(ra, c.pc_pad);
                     const double* ljb = c.ljc + __mul24(rb, c.pc_pad);
@@ -706,6 +720,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                     for (int i0 = 0; i0 < EPG; i0 += kBatch) {
                         double uu[kBatch], vv[kBatch], la[kBatch], lb[TWO_ROWS ? kBatch : 1];
                         if (HUB && i0 == 0) hub_v = vbuf[hub_p];
+                        if (LJPRE && WITH_ROW && i0 + kBatch >= EPG) request_rows();      // (the last batch: the next record has long arrived)
 #pragma unroll
                         for (int i = 0; i < kBatch; ++i) {
                             if (i0 + i >= EPG) continue;

@@ -50,7 +50,8 @@ typedef enum adr_status {
  * (cavour/utils/global_types.py:76-84) accepted by simple_interpolate
  * (cavour/market/curves/interpolator_ad.py:227-235). */
 #define ADR_INTERP_FLAT_FWD_RATES 1
-#define ADR_INTERP_LINEAR_FWD_RATES 2   /* linear in the knot DFs: priced by the general kernel */
+#define ADR_INTERP_LINEAR_FWD_RATES 2   /* linear in the knot DFs: the fast / lite kernels built for it; payment-lag or weighted
+                                           coupons under this scheme go to the general kernel */
 #define ADR_INTERP_LINEAR_ZERO_RATES 4
 
 /* Request mask bits: RequestTypes.VALUE / DELTA / GAMMA (cavour/utils/global_types.py:69-74). */
@@ -60,9 +61,10 @@ typedef enum adr_status {
 
 /* Largest pillar count (the reference has none, cavour/market/position/engine.py:2388-2389).  Ladders live on chip
  * in tiles of 32 pillars: curves of up to 32 pillars take the fast kernels; beyond that the general kernel prices each
- * trade once per pair of tiles (3 launches for 33-64 pillars).  Odd pillar counts are served by the general kernel as
- * well (the fast kernel stores the [P][P] matrices as 16-byte pairs).  The device curve builder
- * (adr_curve_plan_create) takes at most 32 pillars. */
+ * trade once per pair of tiles - 3 launches for GAMMA on 33-64 pillars, 2 for DELTA, 1 for VALUE alone - at roughly a
+ * tenth of the 32-pillar throughput (profiles/r02_many_pillars_bench.json: 26 M against 350 M trades/s with GAMMA).
+ * Odd pillar counts are served by the general kernel as well (the fast kernel stores the [P][P] matrices as 16-byte
+ * pairs).  The device curve builder (adr_curve_plan_create) takes at most 32 pillars. */
 #define ADR_MAX_PILLARS 64
 
 int adr_version(void);
@@ -166,6 +168,12 @@ void adr_free_curve_set(adr_curve_set* set);
  *   fix_sign, flt_sign     +1 receive / -1 pay, per trade
  * Value time is 0 and both principals are 0, as for every OIS the reference builds
  * (cavour/trades/rates/ois.py:149, swap_float_leg.py:106).
+ * The arrays are validated and classified on the host (a thread per contiguous trade range), copied to the
+ * device once, and the kernels' padded row tables are gathered from them ON THE DEVICE (trades_build.hip):
+ * about 40 ms per million benchmark trades.  Blocks until the batch is usable; may be called from several
+ * host threads on one ctx (it touches no shared state of the ctx but its stream).
+ * Legs of up to 384 coupons take the fast paths (payment-lag legs with GAMMA: up to 128); environment variable
+ * ADR_LAG_KERNEL=dates lays the chained payment-lag rows out for the date-record kernel (kernels_lag.hip).
  */
 int adr_trades_upload(adr_ctx* ctx, int64_t n_trades,
                       const int64_t* fix_off, const int64_t* flt_off,
@@ -181,7 +189,8 @@ int adr_trades_upload(adr_ctx* ctx, int64_t n_trades,
  * discounted on one curve and projected on another - the foreign leg of a cross-currency swap, where the
  * reference calls _float_leg_jax with disc != index curve (engine.py:1640-1712): holding the XCCY curve fixed,
  * the sensitivities to the foreign OIS rates are those of sum_j w_j N D(ts_j)/D(te_j) with w_j = D_x(tp_j).
- * Trades with a weight != 1 are priced by the general kernel.
+ * Trades with a weight != 1 are priced like payment-lag trades: the payment-lag rows of the lite kernel (PV / DELTA),
+ * the payment-lag variant of the fast kernel (GAMMA, curves with the packed layout), the general kernel otherwise.
  */
 int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n_trades,
                                const int64_t* fix_off, const int64_t* flt_off,
@@ -217,10 +226,12 @@ int adr_price(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades,
  * caller.  This is the entry the throughput benchmark times.  The call neither
  * allocates nor synchronises, so a sequence of them (a scenario ladder, the pieces
  * of a cross-currency book) can be captured on `stream` into a HIP graph and replayed.
- * Stream rule: a call with agg_dev != NULL stages its per-block partial sums in scratch
+ * Stream rules: (1) a call with agg_dev != NULL stages its per-block partial sums in scratch
  * owned by the ctx, so all aggregate-producing calls of one ctx must be ordered on ONE
- * stream (or separated by a synchronisation); calls without agg_dev may run on any streams
- * concurrently.  Use one ctx per stream for concurrent aggregates.
+ * stream (or separated by a synchronisation); use one ctx per stream for concurrent aggregates.
+ * (2) A batch that holds payment-lag or weighted coupons owns a per-wave scratch used by GAMMA requests:
+ * calls with GAMMA on the SAME adr_trades must be stream-ordered.  Everything else - different batches on
+ * different streams, calls without agg_dev - may run concurrently on one ctx.
  */
 int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades,
                   uint32_t req_mask,
