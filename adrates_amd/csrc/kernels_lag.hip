@@ -450,9 +450,6 @@ __global__ __launch_bounds__(ADR_LAG_BOUNDS) void price_lag_kernel(CurveDev cv, 
         };
 
         auto pair_has_mini = [](int pair) { return min(static_cast<int>(static_cast<int16_t>(pair & 0xffff)), pair >> 16) <= -3; };
-#ifdef ADR_LAG_DEBUG
-        int n_dbg = 0;
-#endif
         double vacc = 0.0;                        // the ratio node under construction (its parts walked so far)
         int prev_word = kNullPair;                // classes of the record that left vacc
         unsigned part_mask = 0;                   // (part walk) short-end pillars of the parts so far
@@ -571,11 +568,7 @@ __global__ __launch_bounds__(ADR_LAG_BOUNDS) void price_lag_kernel(CurveDev cv, 
             const int prev_ok = dpp_mov_i<kShr1>(dpp_mov_i<kShr1>((cin && accr && (e_folded || lead)) ? 1 : 0));
             const int prev_dpair = dpp_mov_i<kShr1>(dpp_mov_i<kShr1>(dpair));
             const bool s_null = pair_s == kNullPair;
-#ifdef ADR_LAG_NOTILE
-            const bool tile_prev = false;
-#else
             const bool tile_prev = l >= 2 && prev_ok != 0 && ts_q == prev_te && prev_dpair != kNullPair;
-#endif
             const bool ratio_on = !odd && om != 0.0;
             const bool regular = !ratio_on || ((s_null || tile_prev) && e_ok);
             const bool irregular = ratio_on && !regular;
@@ -598,13 +591,6 @@ __global__ __launch_bounds__(ADR_LAG_BOUNDS) void price_lag_kernel(CurveDev cv, 
             const double om_p_pair = dpp_mov_d<kFromOdd>(om_p);
             const bool active = !odd && dpair != kNullPair && (om_r != 0.0 || om_p_pair != 0.0 || tile_next);
             const unsigned long long irregular_b = __ballot(irregular);      // (bits at even lanes; nothing else of the build survives the walk)
-#ifdef ADR_LAG_DEBUG
-            if (unit == 0 && g == 0 && out.gamma) {
-                double* d = out.gamma + 1024 + 16 * l;
-                d[0] = pair_s; d[1] = pair_e; d[2] = pair_p; d[3] = tile_prev; d[4] = uses_vacc; d[5] = next_uses; d[6] = regular; d[7] = s_null;
-                d[8] = prev_ok; d[9] = prev_te; d[10] = ts_q; d[11] = e_ok; d[12] = ratio_on; d[13] = om; d[14] = prev_dpair; d[15] = q;
-            }
-#endif
 
             LAG_STAMP(1);   // chunk build: lookups, exponentials, pair logic
             // ---- date records: the even lane's half {w_r, x, classes | flags}, the odd lane's {w_p, p, -}
@@ -624,9 +610,6 @@ __global__ __launch_bounds__(ADR_LAG_BOUNDS) void price_lag_kernel(CurveDev cv, 
             unsigned long long rows = __ballot(active);
             rows |= rows >> 32;
             rows &= kGroupMask;
-#if defined(ADR_LAG_ABLATE) && ADR_LAG_ABLATE == 1
-            rows = 0;
-#endif
             if (rows) {
                 __builtin_amdgcn_s_setprio(ADR_WALK_PRIO);
                 int n = __builtin_ctzll(rows);
@@ -651,13 +634,6 @@ __global__ __launch_bounds__(ADR_LAG_BOUNDS) void price_lag_kernel(CurveDev cv, 
                     const bool t_next = (flags & kTileNext) != 0;
                     const double v_d = fma(x_b, ub, x_a * ua), v_p = fma(p_b, ub, p_a * ua);
                     const double v_r = vacc + v_d;
-#ifdef ADR_LAG_DEBUG
-                    if (unit == 0 && lane == 26 && out.gamma) {       // lane 26 = pillar 15Y of group 0
-                        double* d = out.gamma + 16 * (n_dbg++);
-                        d[0] = w_r; d[1] = x_a; d[2] = x_b; d[3] = w_p; d[4] = p_a; d[5] = p_b; d[6] = ca; d[7] = cb; d[8] = flags;
-                        d[9] = vacc; d[10] = ua; d[11] = ub; d[12] = v_d; d[13] = v_p; d[14] = dacc; d[15] = a0.x;
-                    }
-#endif
                     vacc = t_next ? v_p - v_d : 0.0;
                     dacc = fma(w_r, v_r, fma(w_p, v_p, dacc));
                     // first-order weights on the date's two knots: the ratio node's date part, the payment node, and the
@@ -666,9 +642,7 @@ __global__ __launch_bounds__(ADR_LAG_BOUNDS) void price_lag_kernel(CurveDev cv, 
                     const double coef_a = fma(w_r, x_a, fma(w_p, p_a, w_nx * (p_a - x_a)));
                     const double coef_b = fma(w_r, x_b, fma(w_p, p_b, w_nx * (p_b - x_b)));
                     const double coa = convexity_coef(ra, rb, coef_a, coef_b);
-#if !defined(ADR_LAG_ABLATE) || ADR_LAG_ABLATE != 3
                     rank_one(std::true_type{}, w_r, v_r, coa, ra);
-#endif
                     const bool is_special = (flags & kSpecial) != 0;
                     if (__ballot(is_special)) {
                         const unsigned mask = is_special ? (pillar_mask(ca, cb) | pillar_mask(static_cast<int16_t>(prev_word & 0xffff), prev_word >> 16)) : 0u;
@@ -676,9 +650,7 @@ __global__ __launch_bounds__(ADR_LAG_BOUNDS) void price_lag_kernel(CurveDev cv, 
                     }
                     prev_word = word;
                     if (any_mini) mini_convexity(ca, cb, coef_a, coef_b);
-#if !defined(ADR_LAG_ABLATE) || ADR_LAG_ABLATE != 3
                     if (__ballot(w_p != 0.0)) rank_one(std::false_type{}, w_p, v_p, 0.0, ra);
-#endif
                     if (!has_next) break;
                 }
                 __builtin_amdgcn_s_setprio(0);

@@ -142,3 +142,19 @@ def test_readme_sized_curves_keep_their_lds_resident_variants(native_lib):
     assert 0 < info["general_lds_bytes"] <= 160 * 1024 and info["general_lds_rows"] == 1
     # every fringe pair sits in the lane of one of its own pillars: two slots of 32 entries behind the core slots
     assert info["packed_entries"] == 32 * 7
+
+
+def test_hub_layout_with_identity_row_positions_is_found_for_the_benchmark_curves():
+    """`curve_tables.cpp::hub_layout` (round 3): the star decomposition of the core pairs is constrained so that entry
+    lane + 32 * slot of a convexity row sits at that position of the compact row - 25 lanes of 5 pairs, 7 lanes of 4 for
+    the 17 core pillars of the README curve - and the exact kernel variants (hub layout) are what these curves get; the
+    LDS image still fits one CU."""
+    from adrates_amd import _native
+    from adrates_amd.trades.market_data import gbp_model, usd_model
+    for model, name in ((gbp_model(), "GBP_OIS_SONIA"), (usd_model(), "USD_OIS_SOFR")):
+        c = getattr(model.curves, name)
+        h = build_engine_curve(c.swap_rates, c.swap_times, c.year_fracs)
+        info = _native.curve_layout_host(h.times, h.dfs, h.jac, h.hess)
+        assert info["packed_ok"] == 1 and info["hub_layout"] == 1, info
+        assert info["core_pillars"] == 17 and info["core_pairs"] == 153 and info["core_slots_per_lane"] == 5
+        assert info["entries_per_lane"] == 7 and info["lds_bytes"] <= 160 * 1024
