@@ -300,6 +300,22 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     track(upload(comp16, &d_comp), d_comp);
     int16_t* d_lut = nullptr;
     track(upload(t.lut, &d_lut), d_lut);
+    // wide layout (33-64 pillars): the whole ladder in one launch when its LDS image fits, else one launch per tile pair
+    double *d_lj64 = nullptr, *d_lcw = nullptr;
+    int16_t* d_wblk = nullptr;
+    unsigned long long* d_lcwmask = nullptr;
+    const char* wide_env = std::getenv("ADR_WIDE_KERNEL");       // "0": keep the tiled route (A/B measurements, tests of that route)
+    const bool wide = t.wide_bpl > 0 && t.wide_bpl <= adr::kWideMaxBlocks && !(wide_env && wide_env[0] == '0') &&
+                      adr::wide_kernel_lds_bytes(t.K, t.Kc, t.wide_bpl, t.has_hess) <= kLdsBudget;
+    if (wide) {
+        track(upload(t.lj64, &d_lj64), d_lj64);
+        track(upload(t.wide_blk, &d_wblk), d_wblk);
+        if (t.has_hess) {
+            track(upload(t.lcw, &d_lcw), d_lcw);
+            std::vector<unsigned long long> m(t.lcw_mask.begin(), t.lcw_mask.end());
+            track(upload(m, &d_lcwmask), d_lcwmask);
+        }
+    }
     if (t.packed_ok) {
         track(upload(t.ljc, &d_ljc), d_ljc);
         track(upload(t.lcc, &d_lcc), d_lcc);
@@ -317,6 +333,8 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     c->dev.T = t.T; c->dev.tile_i = c->dev.tile_j = 0;
     c->dev.x = d_x; c->dev.log_df = d_log; c->dev.inv_x = d_invx; c->dev.lj = d_lj; c->dev.lc_lanes = d_lc; c->dev.lc_block_mask = d_lcmask;
     c->dev.first_of = d_first; c->dev.compact_of = d_comp; c->dev.lut = d_lut; c->dev.n_lut = static_cast<int>(t.lut.size() / 2);
+    c->dev.wide_bpl = wide ? t.wide_bpl : 0;
+    c->dev.lj64 = d_lj64; c->dev.wide_blk = d_wblk; c->dev.lcw = d_lcw; c->dev.lcw_mask = d_lcwmask;
     // the fast kernels store the [P][P] matrices as 16-byte pairs of the flat array: P must be even
     // LINEAR_FWD_RATES is linear in the knot DFs, not in their logs: only the general kernel carries the extra
     // Hessian term (kernels_general.hip, `Lookup`)
@@ -436,6 +454,22 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     track(upload(comp16, &d_comp), d_comp);
     int16_t* d_lut = nullptr;
     track(upload(t.lut, &d_lut), d_lut);
+    // wide layout (33-64 pillars): the whole ladder in one launch when its LDS image fits, else one launch per tile pair
+    double *d_lj64 = nullptr, *d_lcw = nullptr;
+    int16_t* d_wblk = nullptr;
+    unsigned long long* d_lcwmask = nullptr;
+    const char* wide_env = std::getenv("ADR_WIDE_KERNEL");       // "0": keep the tiled route (A/B measurements, tests of that route)
+    const bool wide = t.wide_bpl > 0 && t.wide_bpl <= adr::kWideMaxBlocks && !(wide_env && wide_env[0] == '0') &&
+                      adr::wide_kernel_lds_bytes(t.K, t.Kc, t.wide_bpl, t.has_hess) <= kLdsBudget;
+    if (wide) {
+        track(upload(t.lj64, &d_lj64), d_lj64);
+        track(upload(t.wide_blk, &d_wblk), d_wblk);
+        if (t.has_hess) {
+            track(upload(t.lcw, &d_lcw), d_lcw);
+            std::vector<unsigned long long> m(t.lcw_mask.begin(), t.lcw_mask.end());
+            track(upload(m, &d_lcwmask), d_lcwmask);
+        }
+    }
     if (t.packed_ok) {
         track(upload(core_pillars, &d_core), d_core);
         track(upload(t.knot_class, &d_class), d_class);
@@ -1028,8 +1062,24 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     o.delta = (req_mask & ADR_REQ_DELTA) ? delta_dev : nullptr;
     o.gamma = want_gamma ? gamma_dev : nullptr;
 
+    if (curve->dev.T > 1 && curve->dev.wide_bpl > 0) {
+        // More than 32 pillars: the wide variants of the general kernel price every trade once - a wavefront of 64 lanes
+        // holds the whole delta ladder, the lanes share the 4x4 blocks of the upper triangle of the gamma matrix.
+        const size_t lds = adr::wide_kernel_lds_bytes(curve->dev.K, curve->dev.Kc, curve->dev.wide_bpl, want_gamma);
+        const int waves = adr::wide_kernel_threads() / 64;
+        const int64_t need = (n + waves - 1) / waves;
+        const int blocks = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * adr::wide_kernel_blocks_per_cu(lds)));
+        if (static_cast<size_t>(blocks) * adr::kAggWide > static_cast<size_t>(ctx->max_blocks) * adr::kAggStride)
+            return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
+        adr::TradesDev all = trades->dev;
+        all.list = nullptr; all.n_list = n;
+        o.block_partials = agg_dev ? ctx->partials : nullptr;
+        ADR_HIP(adr::launch_price_wide(curve->dev, all, o, want_delta, want_gamma, blocks, stream));
+        if (agg_dev) ADR_HIP(adr::launch_reduce_wide(ctx->partials, blocks, P, want_delta, want_gamma, agg_dev, stream));
+        return ADR_OK;
+    }
     if (curve->dev.T > 1) {
-        // More than 32 pillars: the general kernel prices every trade once per pair of pillar tiles (tile_i <= tile_j);
+        // ... or, when the wide tables do not fit the LDS: once per pair of pillar tiles (tile_i <= tile_j);
         // each launch writes its tile of the ladders, its partials are reduced into its tile of the aggregate.
         const int T = curve->dev.T;
         const int threads = adr::kGeneralThreads;

@@ -105,6 +105,43 @@ std::string build_curve_tables(int K, int P, const double* times, const double* 
                 out.lc_block_mask[pair * Kc + c] = mask;
             }
     }
+    if (T > 1) {   // wide layout: the whole ladder in one launch
+        const int nb = (P + 3) / 4, U = nb * (nb + 1) / 2;
+        const int bpl = out.wide_bpl = (U + 63) / 64;
+        out.lj64.assign(static_cast<size_t>(Kc) * kWidePad, 0.0);
+        for (int c = 0; c < Kc; ++c)
+            for (int p = 0; p < P; ++p)
+                out.lj64[static_cast<size_t>(c) * kWidePad + p] = out.lj[(static_cast<size_t>(p / kPillarPad) * Kc + c) * kPillarPad + p % kPillarPad];
+        out.wide_blk.assign(static_cast<size_t>(bpl) * 64, -1);
+        {
+            int u = 0;
+            for (int bi = 0; bi < nb; ++bi)
+                for (int bj = bi; bj < nb; ++bj, ++u) out.wide_blk[static_cast<size_t>(u / 64) * 64 + u % 64] = static_cast<int16_t>(bi | (bj << 8));
+        }
+        if (out.has_hess) {
+            out.lcw.assign(static_cast<size_t>(Kc) * bpl * 64 * 16, 0.0);
+            out.lcw_mask.assign(static_cast<size_t>(Kc) * bpl, 0);
+            for (int c = 0; c < Kc; ++c) {
+                const double* lck = &out.lc[static_cast<size_t>(c) * P * P];
+                for (int s = 0; s < bpl; ++s)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int blk = out.wide_blk[static_cast<size_t>(s) * 64 + lane];
+                        if (blk < 0) continue;
+                        const int bi = blk & 0xff, bj = blk >> 8;
+                        double* dst = &out.lcw[((static_cast<size_t>(c) * bpl + s) * 64 + lane) * 16];
+                        bool nz = false;
+                        for (int i = 0; i < 4; ++i)
+                            for (int j = 0; j < 4; ++j) {
+                                const int r = 4 * bi + i, q = 4 * bj + j;
+                                const double x = (r < P && q < P) ? lck[r * P + q] : 0.0;
+                                dst[4 * i + j] = x;
+                                nz = nz || x != 0.0;
+                            }
+                        if (nz) out.lcw_mask[static_cast<size_t>(c) * bpl + s] |= 1ull << lane;
+                    }
+            }
+        }
+    }
     out.packed_ok = build_packed_layout(out);
     return std::string();
 }

@@ -21,7 +21,10 @@
 namespace adr {
 
 constexpr int kPillarPad = 32;                                  // ladders are padded to this on chip (one pillar tile)
-constexpr int kMaxPillars = 64;                                 // more than 32 pillars: tiles of 32, general kernel only
+constexpr int kMaxPillars = 64;                                 // more than 32 pillars: the wide kernel (one launch), or tiles of 32
+constexpr int kWidePad = 64;                                    // wide kernel: ladders padded to one wavefront of pillars
+constexpr int kWideMaxBlocks = 3;                               // ... 4x4 gamma blocks per lane: 136 upper blocks of a 64 x 64 matrix
+constexpr int kAggWide = 1 + kWidePad + kWidePad * kWidePad;    // ... padded [pv, delta, gamma] record of a block partial
 inline int pillar_tiles(int P) { return (P + kPillarPad - 1) / kPillarPad; }
 inline int tile_pair(int ti, int tj) { return tj * (tj + 1) / 2 + ti; }       // ti <= tj
 constexpr int kGammaPerLane = kPillarPad * kPillarPad / 64;     // 16 gamma entries per lane (4x4 block)
@@ -63,6 +66,14 @@ struct CurveTables {
     std::vector<double> lc_lanes;      // [pairs][Kc][64][16] lane-major 32x32 tiles read by the general gamma kernel; tile pair
                                        //                     (ti <= tj) at index tile_pair(ti, tj), pair 0 = the only one for P <= 32
     std::vector<uint64_t> lc_block_mask;  // [pairs][Kc] bit l: lane l's 4x4 block of that tile of LC_k has a non-zero entry
+
+    // ---- wide layout (33-64 pillars, kernels_general.hip WIDE variants): one wavefront = 64 pillars, the upper triangle
+    // of the gamma matrix in 4x4 blocks dealt to the lanes, block u of the row-major upper triangle to lane u % 64, slot u / 64
+    int wide_bpl = 0;                  // blocks per lane (1..kWideMaxBlocks); 0: no wide tables (P <= 32)
+    std::vector<double> lj64;          // [Kc][64] zero padded
+    std::vector<int16_t> wide_blk;     // [wide_bpl][64] block row | block column << 8 of the lane's block in that slot, -1: none
+    std::vector<double> lcw;           // [Kc][wide_bpl][64][16] LC_k on the lanes' blocks (entry 4 i + j = row 4 bi + i, column 4 bj + j)
+    std::vector<uint64_t> lcw_mask;    // [Kc][wide_bpl] bit l: lane l's block in that slot has a structural non-zero of LC_k
 
     // ---- packed layout of the fast kernels (see build_packed_layout) ----
     int Pc = 0;                        // pillars in the core set

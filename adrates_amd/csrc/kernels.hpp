@@ -169,6 +169,12 @@ struct CurveDev {
     const double* lj;            // [T][Kc][32]
     const double* lc_lanes;      // [pairs][Kc][64][16], null without gamma
     const unsigned long long* lc_block_mask;  // [pairs][Kc] lanes whose 4x4 block of that tile of LC_k is not structurally zero
+    // wide kernel (33-64 pillars, one launch for the whole ladder): valid when wide_bpl > 0
+    int wide_bpl;                // 4x4 gamma blocks per lane (1..3), 0: no wide tables
+    const double* lj64;          // [Kc][64]
+    const int16_t* wide_blk;     // [wide_bpl][64] block row | block column << 8, -1: the lane has no block in that slot
+    const double* lcw;           // [Kc][wide_bpl][64][16], null without gamma
+    const unsigned long long* lcw_mask;   // [Kc][wide_bpl]
     // fast kernels: packed layout (curve_tables.hpp), valid when packed_ok
     int packed_ok, Pc, pc_pad, Ec, Eu, epg, cpg, hub, Kcore, n_mini;
     int fringe_start;            // first packed entry of the fringe pairs (entries fringe_start .. Eu - 1)
@@ -235,6 +241,15 @@ size_t fast_kernel_lag_scratch_bytes(int n_blocks);
 hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes);
 hipError_t launch_price_general(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                                 bool want_gamma, int n_blocks, hipStream_t stream);
+// wide variants of the general kernel: curves of 33-64 pillars, every trade, all three schemes, one launch
+size_t wide_kernel_lds_bytes(int K, int Kc, int bpl, bool gamma);
+int wide_kernel_threads();
+int wide_kernel_blocks_per_cu(size_t lds_bytes);
+hipError_t launch_price_wide(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
+                             bool want_gamma, int n_blocks, hipStream_t stream);
+// block partials of the wide kernel ([n_blocks][kAggWide]) -> agg[1 + P + P*P], fixed order
+hipError_t launch_reduce_wide(const double* partials, int n_blocks, int P, bool has_delta, bool has_gamma, double* agg,
+                              hipStream_t stream);
 hipError_t launch_price_fast(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                              bool want_gamma, int n_blocks, hipStream_t stream);
 hipError_t launch_curve_df(const CurveDev& cv, int64_t n, const double* t_dev, double* df_dev, int n_cu, hipStream_t stream);

@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "kernels.hpp"
 
 namespace adr {
@@ -70,6 +72,7 @@ struct CurveLds {
     const int16_t* compact_of;  // [K]
     int K;
     int method;
+    int wblk[kWideMaxBlocks];   // WIDE: this lane's 4x4 block per slot (block row | block column << 8), -1: none
 };
 
 // One discount-factor lookup.  FLAT_FWD / LINEAR_ZERO: D(t) = exp(ba*L[ka] + bb*L[kb]); ka/kb are rows of the
@@ -149,16 +152,17 @@ __device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
 }
 
 // Per-wave accumulators of one trade (and, separately, of the wave's running portfolio sums).
-template <bool GAMMA>
+template <bool GAMMA, int WIDE = 0>
 struct Ladders {
+    static constexpr int kGammaRegs = GAMMA ? kGammaPerLane * (WIDE > 0 ? WIDE : 1) : 1;
     double pv;                 // lane-partial, reduced at the end of the trade
-    double delta;              // lane p (and p + 32, duplicated) holds pillar p
-    double gamma[GAMMA ? kGammaPerLane : 1];
+    double delta;              // lane p (and p + 32, duplicated) holds pillar p; WIDE: lane p holds pillar p of 64
+    double gamma[kGammaRegs];  // WIDE: 16 entries per block slot
     double conv[GAMMA ? kConvSlices : 1];   // LDS path: sum_k coef_k * LC_k on the packed core pairs, entry lane + 64 s
     __device__ void clear() {
         pv = 0.0; delta = 0.0;
 #pragma unroll
-        for (int e = 0; e < (GAMMA ? kGammaPerLane : 1); ++e) gamma[e] = 0.0;
+        for (int e = 0; e < kGammaRegs; ++e) gamma[e] = 0.0;
 #pragma unroll
         for (int e = 0; e < (GAMMA ? kConvSlices : 1); ++e) conv[e] = 0.0;
     }
@@ -278,40 +282,116 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
     }
 }
 
+// WIDE variants (curves of 33-64 pillars): lane p builds v for pillar p of 64 from the 64-wide Jacobian table, and a lane
+// holds up to BPL 4x4 blocks of the upper triangle of the whole P x P matrix (curve_tables.hpp, wide layout) - the rank-one
+// term from the wave's v hand-off buffer, the convexity term from lane-major tiles in L2 under a per-knot lane mask, as
+// above; one launch covers the whole ladder instead of one launch per pair of 32-pillar tiles.
+template <int NK, bool DELTA, bool GAMMA, bool CF, int BPL>
+__device__ __forceinline__ void add_nodes_wide(unsigned long long mask, const int (&k)[NK], const double (&b)[NK],
+                                               double omega, const CurveLds& c, const double* __restrict__ lcw,
+                                               const unsigned long long* lcw_mask, double* vbuf, int lane,
+                                               Ladders<GAMMA, BPL>& acc, const double (&cf)[NK]) {
+    while (mask) {
+        const int n = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const double om = readlane_d(omega, n);
+        int kk[NK];
+        double bb[NK], cc[NK];
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            kk[i] = readlane_i(k[i], n);
+            bb[i] = readlane_d(b[i], n);
+        }
+#pragma unroll
+        for (int i = 0; i < NK; ++i) cc[i] = (CF && GAMMA) ? readlane_d(cf[i], n) : om * bb[i];
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) v = fma(bb[i], c.lj[kk[i] * kWidePad + lane], v);
+        if (DELTA) acc.delta = fma(om, v, acc.delta);
+        if constexpr (GAMMA) {
+            __builtin_amdgcn_wave_barrier();
+            vbuf[lane] = v;
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < BPL; ++s) {
+                const int blk = c.wblk[s];
+                if (blk < 0) continue;
+                const int bi = blk & 0xff, bj = blk >> 8;
+                double vr[4], vc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { vr[i] = om * vbuf[4 * bi + i]; vc[i] = vbuf[4 * bj + i]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx)
+                        acc.gamma[s * 16 + i * 4 + jx] = fma(vr[i], vc[jx], acc.gamma[s * 16 + i * 4 + jx]);
+#pragma unroll
+                for (int i = 0; i < NK; ++i) {
+                    const double coef = cc[i];
+                    if (coef != 0.0 && ((lcw_mask[kk[i] * BPL + s] >> lane) & 1ull)) {
+                        const double2* tile = reinterpret_cast<const double2*>(
+                            lcw + ((static_cast<size_t>(kk[i]) * BPL + s) * 64 + lane) * 16);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const double2 tv = tile[e];
+                            acc.gamma[s * 16 + 2 * e] = fma(coef, tv.x, acc.gamma[s * 16 + 2 * e]);
+                            acc.gamma[s * 16 + 2 * e + 1] = fma(coef, tv.y, acc.gamma[s * 16 + 2 * e + 1]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NK, bool DELTA, bool GAMMA, bool CF, bool LDSLC, int WIDE>
+__device__ __forceinline__ void add_nodes_any(unsigned long long mask, const int (&k)[NK], const double (&b)[NK],
+                                              double omega, const CurveLds& c, const double* __restrict__ lc_lanes,
+                                              const unsigned long long* lc_block_mask, double* vbuf, int lane,
+                                              Ladders<GAMMA, WIDE>& acc, const double (&cf)[NK], const ConvLds& conv) {
+    if constexpr (WIDE > 0) add_nodes_wide<NK, DELTA, GAMMA, CF, WIDE>(mask, k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf);
+    else add_nodes<NK, DELTA, GAMMA, CF, LDSLC>(mask, k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf, conv);
+}
+
 // LINEAR_FWD_RATES: the rank-one term a discount factor that is linear in its two knot DFs adds to the Hessian,
 // weight * (LJ[ka] - LJ[kb]) (LJ[ka] - LJ[kb])^T with weight = (term value) * (+1 numerator / -1 denominator) * kappa
 // (see `Lookup`).  It has no first-order and no convexity part, so it runs as a node without DELTA and with zero
 // convexity coefficients.
-template <bool GAMMA, bool LDSLC = false>
+template <bool GAMMA, bool LDSLC = false, int WIDE = 0>
 __device__ __forceinline__ void add_df_correction(bool on, int ka, int kb, double weight, const CurveLds& c,
                                                   const double* __restrict__ lc_lanes,
                                                   const unsigned long long* lc_block_mask, double* vbuf, int lane,
-                                                  Ladders<GAMMA>& acc) {
+                                                  Ladders<GAMMA, WIDE>& acc) {
     if constexpr (GAMMA) {
         const int k2[2] = {ka, kb};     // untagged is fine: the convexity coefficients are zero
         const double b2[2] = {1.0, -1.0}, none[2] = {0.0, 0.0};
         const double om = on ? weight : 0.0;
-        add_nodes<2, false, true, true, LDSLC>(__ballot(om != 0.0), k2, b2, om, c, lc_lanes, lc_block_mask, vbuf, lane, acc, none);
+        add_nodes_any<2, false, true, true, LDSLC, WIDE>(__ballot(om != 0.0), k2, b2, om, c, lc_lanes, lc_block_mask, vbuf, lane, acc, none, ConvLds{});
     }
 }
 
 // LINDF: the curve interpolates with LINEAR_FWD_RATES (a compile-time switch: the state of the corrections would
 // otherwise cost the log-linear instantiations registers - measured +9 % on the gamma paths)
 // LDSLC: the convexity rows are LDS-resident (`ConvLds`): one 512-thread block per CU instead of two of 256.
-template <bool DELTA, bool GAMMA, bool LINDF, bool LDSLC>
+template <bool DELTA, bool GAMMA, bool LINDF, bool LDSLC, int WIDE = 0>
 // Two waves per SIMD either way (two blocks of 4 waves, the curve tables being about 75 KB, or one block of 8 waves next
 // to 112 KB of convexity rows): the register budget is pinned to that (without the bound the gamma instantiation
 // drifts to 256 VGPRs + AGPRs and one wave per SIMD).
 __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_general_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
+    static_assert(!(WIDE > 0 && LDSLC), "the wide variants stream their convexity tiles from L2");
     constexpr int kBlockThreads = LDSLC ? kThreadsLds : kThreadsL2;
     constexpr int kWavesPerBlock = kBlockThreads / 64;
+    constexpr int kLjPad = WIDE > 0 ? kWidePad : kPillarPad;      // row width of the Jacobian table in LDS
+    constexpr int kMaskWords = WIDE > 0 ? WIDE : 1;              // 64-bit lane masks per knot
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS carve-up: doubles first (16-byte aligned base), then the int16 index tables
     double* s_x = reinterpret_cast<double*>(smem_raw);
     double* s_log = s_x + cv.K;
     double* s_invx = s_log + cv.Kc;
-    const bool diag = cv.tile_i == cv.tile_j;
-    const int n_lj = cv.Kc * kPillarPad;                 // one pillar tile of LJ
+    const bool diag = WIDE > 0 || cv.tile_i == cv.tile_j;
+    const int n_lj = cv.Kc * kLjPad;                     // one pillar tile of LJ (WIDE: all 64 columns)
     double* s_lj = s_invx + cv.Kc;
     double* s_vbuf = s_lj + static_cast<size_t>(n_lj) * (diag ? 1 : 2);
     // per-knot masks of the structurally non-zero LC blocks: read before every tile, so LDS-resident (a global
@@ -320,7 +400,7 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
     // LDS path: packed convexity rows, the short-end records and the per-wave staging of the flat sums
     const int ec_stride = cv.Ec + 1;
     const int n_lcc = (LDSLC && GAMMA) ? (cv.Kcore + 1) * ec_stride : 0;
-    double* s_lcc = reinterpret_cast<double*>(s_lcmask + ((GAMMA && !LDSLC) ? cv.Kc : 0));
+    double* s_lcc = reinterpret_cast<double*>(s_lcmask + ((GAMMA && !LDSLC) ? cv.Kc * kMaskWords : 0));
     double* s_stage = s_lcc + n_lcc;
     MiniKnot* s_mini = reinterpret_cast<MiniKnot*>(s_stage + ((LDSLC && GAMMA) ? kWavesPerBlock * kConvStage : 0));
     int16_t* s_first = reinterpret_cast<int16_t*>(s_mini + ((LDSLC && GAMMA) ? cv.n_mini : 0));
@@ -336,9 +416,11 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
     for (int i = threadIdx.x; i < cv.Kc; i += kBlockThreads) {
         s_log[i] = cv.log_df[i];
         s_invx[i] = cv.inv_x[i];
-        if (GAMMA && !LDSLC) s_lcmask[i] = cv.lc_block_mask[i];
+        if (GAMMA && !LDSLC && WIDE == 0) s_lcmask[i] = cv.lc_block_mask[i];
         if (LDSLC) s_class[i] = cv.knot_class[i];
     }
+    if constexpr (GAMMA && WIDE > 0)
+        for (int i = threadIdx.x; i < cv.Kc * WIDE; i += kBlockThreads) s_lcmask[i] = cv.lcw_mask[i];
     for (int i = threadIdx.x; i < n_lcc; i += kBlockThreads) s_lcc[i] = cv.lcc[i];
     if (LDSLC && GAMMA) {
         const double* src = reinterpret_cast<const double*>(cv.mini);
@@ -346,7 +428,9 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
         for (int i = threadIdx.x; i < cv.n_mini * 8; i += kBlockThreads) dst[i] = src[i];
     }
     for (int i = threadIdx.x; i < 2 * cv.n_lut; i += kBlockThreads) s_lut[i] = cv.lut[i];
-    {
+    if constexpr (WIDE > 0) {
+        for (int i = threadIdx.x; i < n_lj; i += kBlockThreads) s_lj[i] = cv.lj64[i];
+    } else {
         const double* row_tile = cv.lj + static_cast<size_t>(cv.tile_i) * n_lj;
         const double* col_tile = cv.lj + static_cast<size_t>(cv.tile_j) * n_lj;
         for (int i = threadIdx.x; i < n_lj; i += kBlockThreads) s_lj[i] = row_tile[i];
@@ -369,9 +453,11 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
     c.col0 = diag ? 0 : 32;
     c.diag = diag;
     const int row0 = kPillarPad * cv.tile_i, col0g = kPillarPad * cv.tile_j;    // first pillar of the row / column tile
-    const bool first_tile = cv.tile_i == 0 && cv.tile_j == 0;
+    const bool first_tile = WIDE > 0 || (cv.tile_i == 0 && cv.tile_j == 0);
     const bool one_tile = cv.T == 1;
-    const double* __restrict__ lc_lanes = cv.lc_lanes;
+    const double* __restrict__ lc_lanes = WIDE > 0 ? cv.lcw : cv.lc_lanes;
+#pragma unroll
+    for (int s_ = 0; s_ < kWideMaxBlocks; ++s_) c.wblk[s_] = (WIDE > 0 && GAMMA && s_ < WIDE) ? cv.wide_blk[s_ * 64 + lane] : -1;
     const unsigned long long* lc_block_mask = s_lcmask;
     ConvLds conv;
     conv.lcc = s_lcc; conv.mini = s_mini; conv.ec_stride = ec_stride; conv.flat_of = cv.lcc_pos;
@@ -391,7 +477,7 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
         }
     }
 
-    Ladders<GAMMA> total;   // this wave's share of the portfolio aggregate
+    Ladders<GAMMA, WIDE> total;   // this wave's share of the portfolio aggregate
     total.clear();
 
     const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
@@ -409,7 +495,7 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
         const double* x_tp = tr.fix_tp + h.fix_begin;
         const double* x_pay = tr.fix_pay + h.fix_begin;
 
-        Ladders<GAMMA> acc;
+        Ladders<GAMMA, WIDE> acc;
         acc.clear();
 
         // ---------------------------------------------------------------- float coupons (+ merged fixed)
@@ -469,8 +555,8 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
                 { int kt_[2];
 #pragma unroll
                   for (int i_ = 0; i_ < 2; ++i_) kt_[i_] = tag(k[i_]);
-                  add_nodes<2, DELTA, GAMMA, false, LDSLC>(__ballot(own_start), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b, conv); }
-                if constexpr (linear_df) add_df_correction<GAMMA, LDSLC>(own_start, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+                  add_nodes_any<2, DELTA, GAMMA, false, LDSLC, WIDE>(__ballot(own_start), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b, conv); }
+                if constexpr (linear_df) add_df_correction<GAMMA, LDSLC, WIDE>(own_start, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
             }
             const bool own_ratio = valid && ratio;
             if (__ballot(own_ratio)) {   // payment lag: N D(ts) D(tp) / D(te) keeps all three lookups
@@ -547,7 +633,7 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
                 { int kt_[6];
 #pragma unroll
                   for (int i_ = 0; i_ < 6; ++i_) kt_[i_] = tag(k[i_]);
-                  add_nodes<6, DELTA, GAMMA, true, LDSLC>(__ballot(own_ratio && !pay_flat), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf, conv); }
+                  add_nodes_any<6, DELTA, GAMMA, true, LDSLC, WIDE>(__ballot(own_ratio && !pay_flat), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf, conv); }
                 const unsigned long long flat_mask = __ballot(own_ratio && pay_flat);
                 if (flat_mask) {
                     int k4[4]; double b4[4], cf4[4];
@@ -556,19 +642,19 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
                     { int kt_[4];
 #pragma unroll
                       for (int i_ = 0; i_ < 4; ++i_) kt_[i_] = tag(k4[i_]);
-                      add_nodes<4, DELTA, GAMMA, true, LDSLC>(flat_mask, kt_, b4, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf4, conv); }
+                      add_nodes_any<4, DELTA, GAMMA, true, LDSLC, WIDE>(flat_mask, kt_, b4, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf4, conv); }
                 }
                 if constexpr (linear_df) {
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
-                        add_df_correction<GAMMA, LDSLC>(own_ratio, kc[2 * q], kc[2 * q + 1], omega * kap[q], c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+                        add_df_correction<GAMMA, LDSLC, WIDE>(own_ratio, kc[2 * q], kc[2 * q + 1], omega * kap[q], c, lc_lanes, lc_block_mask, vbuf, lane, acc);
                 }
             }
             { int kt_[2];
 #pragma unroll
               for (int i_ = 0; i_ < 2; ++i_) kt_[i_] = tag(kp[i_]);
-              add_nodes<2, DELTA, GAMMA, true, LDSLC>(__ballot(pay_node), kt_, bp, omega_p, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cfp, conv); }
-            if constexpr (linear_df) add_df_correction<GAMMA, LDSLC>(pay_node, kp[0], kp[1], omega_p * qpay.kappa, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+              add_nodes_any<2, DELTA, GAMMA, true, LDSLC, WIDE>(__ballot(pay_node), kt_, bp, omega_p, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cfp, conv); }
+            if constexpr (linear_df) add_df_correction<GAMMA, LDSLC, WIDE>(pay_node, kp[0], kp[1], omega_p * qpay.kappa, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
         }
         // ---------------------------------------------------------------- fixed coupons not merged above
         for (int base = 0; base < n_fix; base += 64) {
@@ -594,14 +680,74 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
             { int kt_[2];
 #pragma unroll
               for (int i_ = 0; i_ < 2; ++i_) kt_[i_] = tag(k[i_]);
-              add_nodes<2, DELTA, GAMMA, false, LDSLC>(__ballot(on), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b, conv); }
-            if constexpr (linear_df) add_df_correction<GAMMA, LDSLC>(on, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+              add_nodes_any<2, DELTA, GAMMA, false, LDSLC, WIDE>(__ballot(on), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b, conv); }
+            if constexpr (linear_df) add_df_correction<GAMMA, LDSLC, WIDE>(on, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
         }
 
         // ---------------------------------------------------------------- results of this trade
         // (more than 32 pillars: this launch holds the tile pair (tile_i, tile_j) of the ladders - the PV comes from the
         // launch of tile (0, 0), the delta tiles from the diagonal launches, off-diagonal gamma tiles are written twice)
         const double pv = wave_sum(acc.pv);
+        if constexpr (WIDE > 0) {
+            // wide variants: the whole ladder of the trade - pv, lane p = pillar p of the delta ladder, the lanes' 4x4 blocks
+            // of the upper triangle and their mirrors
+            if (lane == 0) {
+                if (out.pv) out.pv[t] = pv;
+                total.pv += pv;
+            }
+            if (DELTA) {
+                const double d = acc.delta * 1e-4;
+                if (lane < P && out.delta) out.delta[t * P + lane] = d;
+                total.delta += d;
+            }
+            if constexpr (GAMMA) {
+                double* g = out.gamma ? out.gamma + t * static_cast<int64_t>(P) * P : nullptr;
+                const bool vec = (P & 3) == 0;          // rows of a block are 32-byte aligned runs inside the matrix
+#pragma unroll
+                for (int s_ = 0; s_ < WIDE; ++s_) {
+                    const int blk = c.wblk[s_];
+                    if (blk < 0) continue;
+                    const int bi = blk & 0xff, bj = blk >> 8;
+                    double gv[16];
+#pragma unroll
+                    for (int e_ = 0; e_ < 16; ++e_) {
+                        gv[e_] = acc.gamma[s_ * 16 + e_] * 1e-8;
+                        total.gamma[s_ * 16 + e_] += gv[e_];
+                    }
+                    if (!g) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * bi + i;
+                        if (r >= P) continue;
+                        if (vec) {
+                            double2* dst = reinterpret_cast<double2*>(g + r * P + 4 * bj);
+                            dst[0] = make_double2(gv[4 * i], gv[4 * i + 1]);
+                            dst[1] = make_double2(gv[4 * i + 2], gv[4 * i + 3]);
+                        } else {
+#pragma unroll
+                            for (int jx = 0; jx < 4; ++jx)
+                                if (4 * bj + jx < P) g[r * P + 4 * bj + jx] = gv[4 * i + jx];
+                        }
+                    }
+                    if (bi < bj) {
+#pragma unroll
+                        for (int jx = 0; jx < 4; ++jx) {
+                            const int r = 4 * bj + jx;
+                            if (r >= P) continue;
+                            if (vec) {
+                                double2* dst = reinterpret_cast<double2*>(g + r * P + 4 * bi);
+                                dst[0] = make_double2(gv[jx], gv[4 + jx]);
+                                dst[1] = make_double2(gv[8 + jx], gv[12 + jx]);
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (4 * bi + i < P) g[r * P + 4 * bi + i] = gv[4 * i + jx];
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
         if (lane == 0 && first_tile) {
             if (out.pv) out.pv[t] = pv;
             total.pv += pv;
@@ -670,9 +816,42 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
                 }
             }
         }
+    }   // WIDE == 0
     }
 
     // ------------------------------------------------------------------------ block partial of the aggregate
+    if constexpr (WIDE > 0) {
+        if (out.block_partials) {
+            // one padded record [pv, delta[64], gamma[64][64]] per block: the waves add their totals in turn (fixed order)
+            __syncthreads();   // every wave is done with the curve tables; reuse the LDS for the reduction
+            double* red = reinterpret_cast<double*>(smem_raw);   // [kAggWide]
+            for (int i = threadIdx.x; i < kAggWide; i += kBlockThreads) red[i] = 0.0;
+            __syncthreads();
+            for (int w = 0; w < kWavesPerBlock; ++w) {
+                if (wave == w) {
+                    if (lane == 0) red[0] += total.pv;
+                    if (DELTA) red[1 + lane] += total.delta;
+                    if constexpr (GAMMA) {
+#pragma unroll
+                        for (int s_ = 0; s_ < WIDE; ++s_) {
+                            const int blk = c.wblk[s_];
+                            if (blk < 0) continue;
+                            const int bi = blk & 0xff, bj = blk >> 8;
+#pragma unroll
+                            for (int e_ = 0; e_ < 16; ++e_) {
+                                const int r = 4 * bi + (e_ >> 2), q = 4 * bj + (e_ & 3);
+                                red[1 + kWidePad + r * kWidePad + q] += total.gamma[s_ * 16 + e_];
+                                if (bi < bj) red[1 + kWidePad + q * kWidePad + r] += total.gamma[s_ * 16 + e_];
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            double* dst = out.block_partials + static_cast<size_t>(blockIdx.x) * kAggWide;
+            for (int i = threadIdx.x; i < kAggWide; i += kBlockThreads) dst[i] = red[i];
+        }
+    } else
     if (out.block_partials) {
         __syncthreads();   // every wave is done with the curve tables; reuse the LDS for the reduction
         double* red = reinterpret_cast<double*>(smem_raw);   // [waves][kAggStride]
@@ -770,7 +949,96 @@ hipError_t launch_price_general(const CurveDev& cv, const TradesDev& tr, const O
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ wide variants
+namespace {
+
+// Fixed-order sum of the wide kernel's block partials -> agg[1 + P + P*P]: one wavefront per output, lanes stride over the
+// blocks, then a fixed butterfly.
+__global__ __launch_bounds__(256) void reduce_wide_kernel(const double* partials, int n_blocks, int P, int has_delta,
+                                                           int has_gamma, double* agg) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);       // index into agg
+    if (o >= 1 + P + P * P) return;
+    int i = 0;                                                               // index into a padded record
+    bool live = true;
+    if (o >= 1 + P) { const int r = (o - 1 - P) / P, q = (o - 1 - P) % P; i = 1 + kWidePad + r * kWidePad + q; live = has_gamma != 0; }
+    else if (o >= 1) { i = o; live = has_delta != 0; }
+    double s = 0.0;
+    if (live)
+        for (int b = lane; b < n_blocks; b += 64) s += partials[static_cast<size_t>(b) * kAggWide + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) agg[o] = s;
+}
+
+template <bool LINDF>
+void collect_wide(std::vector<const void*>& fns) {
+    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, LINDF, false, 1>));
+    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, LINDF, false, 2>));
+    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, LINDF, false, 3>));
+    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, false, LINDF, false, 1>));
+    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<false, false, LINDF, false, 1>));
+}
+
+}  // namespace
+
+size_t wide_kernel_lds_bytes(int K, int Kc, int bpl, bool gamma) {
+    constexpr int kWavesPerBlock = kThreadsL2 / 64;
+    size_t bytes = sizeof(double) * (static_cast<size_t>(K) + 2 * Kc + static_cast<size_t>(Kc) * kWidePad + kWavesPerBlock * 64) +
+                   (gamma ? sizeof(unsigned long long) * static_cast<size_t>(Kc) * bpl : 0) +
+                   sizeof(int16_t) * (2 * static_cast<size_t>(K) + 2 * kLutMax);
+    const size_t reduce = sizeof(double) * kAggWide;
+    if (bytes < reduce) bytes = reduce;
+    return (bytes + 15) & ~static_cast<size_t>(15);
+}
+
+int wide_kernel_threads() { return kThreadsL2; }
+
+// blocks of 4 waves a CU holds: the register budget allows two waves per SIMD (launch bounds), the LDS image the rest
+int wide_kernel_blocks_per_cu(size_t lds_bytes) {
+    const size_t by_lds = lds_bytes ? (160 * 1024) / lds_bytes : 2;
+    return static_cast<int>(by_lds < 1 ? 1 : (by_lds > 2 ? 2 : by_lds));
+}
+
+hipError_t launch_price_wide(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
+                             bool want_gamma, int n_blocks, hipStream_t stream) {
+    const bool lin = cv.method == 2;
+    const size_t lds = wide_kernel_lds_bytes(cv.K, cv.Kc, cv.wide_bpl, want_gamma);
+    dim3 grid(n_blocks), block(kThreadsL2);
+    using Fn = void (*)(CurveDev, TradesDev, OutputsDev);
+    Fn fn = nullptr;
+    if (want_gamma) {
+        switch (cv.wide_bpl) {
+            case 1: fn = lin ? &price_general_kernel<true, true, true, false, 1> : &price_general_kernel<true, true, false, false, 1>; break;
+            case 2: fn = lin ? &price_general_kernel<true, true, true, false, 2> : &price_general_kernel<true, true, false, false, 2>; break;
+            case 3: fn = lin ? &price_general_kernel<true, true, true, false, 3> : &price_general_kernel<true, true, false, false, 3>; break;
+            default: return hipErrorInvalidValue;
+        }
+    } else if (want_delta) {
+        fn = lin ? &price_general_kernel<true, false, true, false, 1> : &price_general_kernel<true, false, false, false, 1>;
+    } else {
+        fn = lin ? &price_general_kernel<false, false, true, false, 1> : &price_general_kernel<false, false, false, false, 1>;
+    }
+    hipLaunchKernelGGL(fn, grid, block, lds, stream, cv, tr, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_wide(const double* partials, int n_blocks, int P, bool has_delta, bool has_gamma, double* agg,
+                              hipStream_t stream) {
+    const int n_out = 1 + P + P * P;
+    hipLaunchKernelGGL(reduce_wide_kernel, dim3((n_out + 3) / 4), dim3(256), 0, stream, partials, n_blocks, P,
+                       has_delta ? 1 : 0, has_gamma ? 1 : 0, agg);
+    return hipGetLastError();
+}
+
 hipError_t set_general_kernel_lds_limit(size_t bytes) {
+    std::vector<const void*> wide;
+    collect_wide<false>(wide);
+    collect_wide<true>(wide);
+    for (const void* f : wide) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        if (e != hipSuccess) return e;
+    }
     const void* fns[] = {reinterpret_cast<const void*>(&price_general_kernel<true, true, false, false>),
                          reinterpret_cast<const void*>(&price_general_kernel<true, false, false, false>),
                          reinterpret_cast<const void*>(&price_general_kernel<false, false, false, false>),

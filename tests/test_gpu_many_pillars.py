@@ -1,7 +1,8 @@
 """Curves with more than 32 pillars, and with an odd pillar count (the reference has no pillar limit,
-cavour/market/position/engine.py:2388-2389).  Ladders live on chip in tiles of 32 pillars: a 40-pillar curve is priced
-by the general kernel once per pair of tiles (include/adrates.h, ADR_MAX_PILLARS); a 17-pillar curve takes the
-general kernel for gamma (the fast kernel stores matrices as 16-byte pairs) and the lite kernel for delta."""
+cavour/market/position/engine.py:2388-2389).  33-64 pillars: the wide variants of the general kernel (one wavefront = 64
+pillars, the whole ladder in one launch; include/adrates.h, ADR_MAX_PILLARS), or - when the wide tables do not fit the
+LDS, or with ADR_WIDE_KERNEL=0 at upload - the general kernel once per pair of 32-pillar tiles; a 17-pillar curve takes
+the general kernel for gamma (the fast kernel stores matrices as 16-byte pairs) and the lite kernel for delta."""
 import numpy as np
 import pytest
 
@@ -31,6 +32,16 @@ def forty_pillar_quotes():
     base_t = np.array([_years(t) for t in F.TENORS])
     tenors = sorted(list(F.TENORS) + EXTRA, key=_years)
     px = [float(np.interp(_years(t), base_t, F.GBP_PX)) if t in EXTRA else F.GBP_PX[F.TENORS.index(t)] for t in tenors]
+    return px, tenors
+
+
+def many_pillar_quotes(P):
+    """The 32 README quotes plus annual pillars up to 49Y until there are P of them (quoted off the neighbours)."""
+    base_t = np.array([_years(t) for t in F.TENORS])
+    extra = [f"{y}Y" for y in range(1, 50) if f"{y}Y" not in F.TENORS]
+    tenors = sorted(list(F.TENORS) + extra, key=_years)[:P]
+    assert len(tenors) == P
+    px = [float(np.interp(_years(t), base_t, F.GBP_PX)) if t not in F.TENORS else F.GBP_PX[F.TENORS.index(t)] for t in tenors]
     return px, tenors
 
 
@@ -74,6 +85,59 @@ def test_forty_pillar_curve_vs_c_oracle(gpu_ctx, interp):
     assert np.all(only_v["agg_delta"] == 0.0) and np.all(only_v["agg_gamma"] == 0.0)
     dt.close()
     print(f"40 pillars, {interp.name}: worst error {worst:.2e}")
+
+
+@pytest.mark.parametrize("P,interp", [(47, InterpTypes.LINEAR_ZERO_RATES), (47, InterpTypes.LINEAR_FWD_RATES),
+                                      (64, InterpTypes.FLAT_FWD_RATES), (64, InterpTypes.LINEAR_FWD_RATES),
+                                      (33, InterpTypes.LINEAR_ZERO_RATES)])
+def test_wide_kernel_block_counts_vs_c_oracle(gpu_ctx, P, interp):
+    """One, two and three 4x4 blocks per lane (33 / 47 / 64 pillars; 47 and 33 are odd: scalar stores), payment lag and
+    spreads in the batch, every request mask, the aggregate."""
+    vd = F.README_VALUE_DT
+    px, tenors = many_pillar_quotes(P)
+    curve = F.gbp_model(vd, interp, px=px, tenors=tenors).curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    assert dc.n_pillars == P
+    batch = _mixed_batch(vd, 2003, seed=P)
+    dt = _native.DeviceTrades(gpu_ctx, batch)
+    ref = port.price(interp.value, host.times, host.dfs, host.jac, host.hess, batch)
+    got = _native.price(gpu_ctx, dc, dt, aggregate=True)
+    assert got["delta"].shape == (2003, P) and got["gamma"].shape == (2003, P, P)
+    worst = assert_batch_parity(got, ref, batch.notional)
+    asym = np.max(np.abs(got["gamma"] - np.swapaxes(got["gamma"], 1, 2)), axis=(1, 2))
+    assert np.all(asym <= 1e-12 * np.max(np.abs(got["gamma"]), axis=(1, 2)) + 1e-14)
+    assert np.allclose(got["agg_pv"], ref["pv"].sum(), rtol=1e-10, atol=1e-3)
+    assert np.allclose(got["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
+    assert np.allclose(got["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+    only_d = _native.price(gpu_ctx, dc, dt, want_gamma=False, aggregate=True)
+    assert_batch_parity(only_d, dict(pv=ref["pv"], delta=ref["delta"]), batch.notional)
+    assert np.allclose(only_d["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6) and np.all(only_d["agg_gamma"] == 0.0)
+    only_v = _native.price(gpu_ctx, dc, dt, want_delta=False, want_gamma=False, aggregate=True)
+    assert_batch_parity(only_v, dict(pv=ref["pv"]), batch.notional)
+    assert np.all(only_v["agg_delta"] == 0.0) and np.all(only_v["agg_gamma"] == 0.0)
+    dt.close()
+    print(f"{P} pillars, {interp.name}: worst error {worst:.2e}")
+
+
+def test_tiled_route_still_serves_wide_curves(gpu_ctx, monkeypatch):
+    """ADR_WIDE_KERNEL=0 at upload: the general kernel once per pair of 32-pillar tiles - the route of curves whose wide
+    tables do not fit the LDS.  Same numbers as the wide route, to rounding."""
+    vd = F.README_VALUE_DT
+    px, tenors = forty_pillar_quotes()
+    curve = F.gbp_model(vd, px=px, tenors=tenors).curves.GBP_OIS_SONIA
+    batch = _mixed_batch(vd, 1501, seed=5)
+    dt = _native.DeviceTrades(gpu_ctx, batch)
+    host, dc_wide = _device_curve(gpu_ctx, curve)
+    wide = _native.price(gpu_ctx, dc_wide, dt, aggregate=True)
+    monkeypatch.setenv("ADR_WIDE_KERNEL", "0")
+    _, dc_tiled = _device_curve(gpu_ctx, curve)
+    monkeypatch.delenv("ADR_WIDE_KERNEL")
+    tiled = _native.price(gpu_ctx, dc_tiled, dt, aggregate=True)
+    ref = port.price(4, host.times, host.dfs, host.jac, host.hess, batch)
+    assert_batch_parity(tiled, ref, batch.notional)
+    assert_batch_parity(wide, ref, batch.notional)
+    assert np.allclose(tiled["agg_gamma"], wide["agg_gamma"], rtol=1e-12, atol=1e-9)
+    dt.close()
 
 
 def test_forty_pillar_curve_through_the_public_api(gpu_ctx):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Throughput on a 40-pillar curve (ladders in tiles of 32 pillars, general kernel once per tile pair) and on the
-32-pillar curve forced off the packed layout paths for comparison: 100 000 benchmark trades, PV + delta + gamma."""
+"""Throughput on curves of more than 32 pillars - 40 and 64 pillars on the wide variants of the general kernel (one launch),
+the 40-pillar curve again on the tiled route (ADR_WIDE_KERNEL=0 at upload: one launch per pair of 32-pillar tiles) - and on
+the 32-pillar curve for comparison: 100 000 benchmark trades, PV + delta + gamma and PV + delta."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -18,9 +19,14 @@ ctx = _native.Context(0)
 batch = synthetic.synthesize(vd, n)
 dt = _native.DeviceTrades(ctx, batch)
 dev = torch.device("cuda", 0)
-for label, model in (("40 pillars", gbp_model(vd, px=px, tenors=tenors)), ("32 pillars", gbp_model(vd))):
+extra64 = [f"{y}Y" for y in range(1, 50) if f"{y}Y" not in TENORS]
+tenors64 = sorted(list(TENORS) + extra64, key=years)[:64]
+px64 = [float(np.interp(years(t), base_t, GBP_PX)) if t not in TENORS else GBP_PX[TENORS.index(t)] for t in tenors64]
+for label, model, wide in (("40 pillars", gbp_model(vd, px=px, tenors=tenors), "1"), ("40 pillars, tiled route", gbp_model(vd, px=px, tenors=tenors), "0"),
+                           ("64 pillars", gbp_model(vd, px=px64, tenors=tenors64), "1"), ("32 pillars", gbp_model(vd), "1")):
     curve = model.curves.GBP_OIS_SONIA
     host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    os.environ["ADR_WIDE_KERNEL"] = wide
     dc = _native.DeviceCurve(ctx, 4, host.times, host.dfs, host.jac, host.hess)
     P = dc.n_pillars
     pv = torch.empty(n, dtype=torch.float64, device=dev); de = torch.empty((n, P), dtype=torch.float64, device=dev)
@@ -35,4 +41,6 @@ for label, model in (("40 pillars", gbp_model(vd, px=px, tenors=tenors)), ("32 p
             _native.price_dev(ctx, dc, dt, mask, pv.data_ptr(), de.data_ptr(), ga.data_ptr() if mask & 4 else 0, ag.data_ptr())
         ctx.sync(); b.record(); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / 10
-        print(json.dumps({"curve": label, "pillars": P, "trades": n, "mask": mask, "ms": ms, "trades_per_s": n / ms * 1e3}))
+        out_bytes = 8 * (1 + P + (P * P if mask & 4 else 0)) * n
+        print(json.dumps({"curve": label, "pillars": P, "trades": n, "mask": mask, "ms": ms, "trades_per_s": n / ms * 1e3,
+                          "output_GBps": out_bytes / ms / 1e6}))
