@@ -360,11 +360,12 @@ def curve_layout_host(times, dfs, jac, hess=None):
     times, dfs, jac = _f64(times), _f64(dfs), _f64(jac)
     K, P = jac.shape
     hess_c = None if hess is None else _f64(hess)
-    info = np.zeros(12, dtype=np.int64)
+    info = np.zeros(16, dtype=np.int64)
     _check(load().adr_curve_layout_host(K, P, _ptr(times), _ptr(dfs), _ptr(jac), _ptr(hess_c), _ptr(info, _i64p)),
            "adr_curve_layout_host")
     keys = ("packed_ok", "core_pillars", "core_pairs", "packed_entries", "entries_per_lane", "core_rows",
-            "mini_knots", "lds_bytes", "general_lds_bytes", "general_lds_rows", "core_slots_per_lane", "hub_layout")
+            "mini_knots", "lds_bytes", "general_lds_bytes", "general_lds_rows", "core_slots_per_lane", "hub_layout",
+            "wide_chunks", "wide_lds_bytes", "wide_max_knot_chunks", "reserved")
     return dict(zip(keys, (int(v) for v in info)))
 
 

@@ -241,6 +241,11 @@ int adr_curve_layout_host(int K, int P, const double* times, const double* dfs, 
     }
     info[10] = t.cpg;
     info[11] = t.hub ? 1 : 0;
+    info[12] = t.wide_nch;
+    info[13] = t.wide_nch > 0 ? static_cast<int64_t>(adr::wide_kernel_lds_bytes(t.K, t.Kc, t.wide_nch, t.has_hess)) : 0;
+    info[14] = 0;
+    for (uint32_t m : t.wide_knot_chunks) info[14] = std::max<int64_t>(info[14], __builtin_popcount(m));
+    info[15] = 0;
     return ADR_OK;
 }
 
@@ -301,19 +306,21 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     int16_t* d_lut = nullptr;
     track(upload(t.lut, &d_lut), d_lut);
     // wide layout (33-64 pillars): the whole ladder in one launch when its LDS image fits, else one launch per tile pair
-    double *d_lj64 = nullptr, *d_lcw = nullptr;
-    int16_t* d_wblk = nullptr;
-    unsigned long long* d_lcwmask = nullptr;
+    double *d_lj64 = nullptr, *d_lcflat = nullptr;
+    uint32_t *d_went = nullptr, *d_wchunks = nullptr, *d_wsmap = nullptr;
+    int32_t *d_wpos = nullptr, *d_worder = nullptr;
     const char* wide_env = std::getenv("ADR_WIDE_KERNEL");       // "0": keep the tiled route (A/B measurements, tests of that route)
-    const bool wide = t.wide_bpl > 0 && t.wide_bpl <= adr::kWideMaxBlocks && !(wide_env && wide_env[0] == '0') &&
-                      adr::wide_kernel_lds_bytes(t.K, t.Kc, t.wide_bpl, t.has_hess) <= kLdsBudget;
+    const bool wide = t.wide_nch > 0 && t.wide_nch <= adr::kWideMaxChunks && !(wide_env && wide_env[0] == '0') &&
+                      adr::wide_kernel_lds_bytes(t.K, t.Kc, t.wide_nch, t.has_hess) <= kLdsBudget;
     if (wide) {
         track(upload(t.lj64, &d_lj64), d_lj64);
-        track(upload(t.wide_blk, &d_wblk), d_wblk);
+        track(upload(t.wide_ent, &d_went), d_went);
+        track(upload(t.wide_store_map, &d_wsmap), d_wsmap);
+        track(upload(t.wide_pos, &d_wpos), d_wpos);
+        track(upload(t.wide_order, &d_worder), d_worder);
         if (t.has_hess) {
-            track(upload(t.lcw, &d_lcw), d_lcw);
-            std::vector<unsigned long long> m(t.lcw_mask.begin(), t.lcw_mask.end());
-            track(upload(m, &d_lcwmask), d_lcwmask);
+            track(upload(t.lcflat, &d_lcflat), d_lcflat);
+            track(upload(t.wide_knot_chunks, &d_wchunks), d_wchunks);
         }
     }
     if (t.packed_ok) {
@@ -333,8 +340,8 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     c->dev.T = t.T; c->dev.tile_i = c->dev.tile_j = 0;
     c->dev.x = d_x; c->dev.log_df = d_log; c->dev.inv_x = d_invx; c->dev.lj = d_lj; c->dev.lc_lanes = d_lc; c->dev.lc_block_mask = d_lcmask;
     c->dev.first_of = d_first; c->dev.compact_of = d_comp; c->dev.lut = d_lut; c->dev.n_lut = static_cast<int>(t.lut.size() / 2);
-    c->dev.wide_bpl = wide ? t.wide_bpl : 0;
-    c->dev.lj64 = d_lj64; c->dev.wide_blk = d_wblk; c->dev.lcw = d_lcw; c->dev.lcw_mask = d_lcwmask;
+    c->dev.wide_nch = wide ? t.wide_nch : 0;
+    c->dev.lj64 = d_lj64; c->dev.wide_ent = d_went; c->dev.lcflat = d_lcflat; c->dev.wide_knot_chunks = d_wchunks; c->dev.wide_store_map = d_wsmap; c->dev.wide_pos = d_wpos; c->dev.wide_order = d_worder;
     // the fast kernels store the [P][P] matrices as 16-byte pairs of the flat array: P must be even
     // LINEAR_FWD_RATES is linear in the knot DFs, not in their logs: only the general kernel carries the extra
     // Hessian term (kernels_general.hip, `Lookup`)
@@ -454,22 +461,6 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     track(upload(comp16, &d_comp), d_comp);
     int16_t* d_lut = nullptr;
     track(upload(t.lut, &d_lut), d_lut);
-    // wide layout (33-64 pillars): the whole ladder in one launch when its LDS image fits, else one launch per tile pair
-    double *d_lj64 = nullptr, *d_lcw = nullptr;
-    int16_t* d_wblk = nullptr;
-    unsigned long long* d_lcwmask = nullptr;
-    const char* wide_env = std::getenv("ADR_WIDE_KERNEL");       // "0": keep the tiled route (A/B measurements, tests of that route)
-    const bool wide = t.wide_bpl > 0 && t.wide_bpl <= adr::kWideMaxBlocks && !(wide_env && wide_env[0] == '0') &&
-                      adr::wide_kernel_lds_bytes(t.K, t.Kc, t.wide_bpl, t.has_hess) <= kLdsBudget;
-    if (wide) {
-        track(upload(t.lj64, &d_lj64), d_lj64);
-        track(upload(t.wide_blk, &d_wblk), d_wblk);
-        if (t.has_hess) {
-            track(upload(t.lcw, &d_lcw), d_lcw);
-            std::vector<unsigned long long> m(t.lcw_mask.begin(), t.lcw_mask.end());
-            track(upload(m, &d_lcwmask), d_lcwmask);
-        }
-    }
     if (t.packed_ok) {
         track(upload(core_pillars, &d_core), d_core);
         track(upload(t.knot_class, &d_class), d_class);
@@ -1062,13 +1053,13 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     o.delta = (req_mask & ADR_REQ_DELTA) ? delta_dev : nullptr;
     o.gamma = want_gamma ? gamma_dev : nullptr;
 
-    if (curve->dev.T > 1 && curve->dev.wide_bpl > 0) {
+    if (curve->dev.T > 1 && curve->dev.wide_nch > 0) {
         // More than 32 pillars: the wide variants of the general kernel price every trade once - a wavefront of 64 lanes
         // holds the whole delta ladder, the lanes share the 4x4 blocks of the upper triangle of the gamma matrix.
-        const size_t lds = adr::wide_kernel_lds_bytes(curve->dev.K, curve->dev.Kc, curve->dev.wide_bpl, want_gamma);
-        const int waves = adr::wide_kernel_threads() / 64;
+        const size_t lds = adr::wide_kernel_lds_bytes(curve->dev.K, curve->dev.Kc, curve->dev.wide_nch, want_gamma);
+        const int threads = adr::wide_kernel_threads(curve->dev.wide_nch, want_gamma), waves = threads / 64;
         const int64_t need = (n + waves - 1) / waves;
-        const int blocks = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * adr::wide_kernel_blocks_per_cu(lds)));
+        const int blocks = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * adr::wide_kernel_blocks_per_cu(lds, threads)));
         if (static_cast<size_t>(blocks) * adr::kAggWide > static_cast<size_t>(ctx->max_blocks) * adr::kAggStride)
             return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
         adr::TradesDev all = trades->dev;

@@ -106,39 +106,68 @@ std::string build_curve_tables(int K, int P, const double* times, const double* 
             }
     }
     if (T > 1) {   // wide layout: the whole ladder in one launch
-        const int nb = (P + 3) / 4, U = nb * (nb + 1) / 2;
-        const int bpl = out.wide_bpl = (U + 63) / 64;
+        const int nch = out.wide_nch = wide_chunks(P), row = nch * kWideChunk;
         out.lj64.assign(static_cast<size_t>(Kc) * kWidePad, 0.0);
         for (int c = 0; c < Kc; ++c)
             for (int p = 0; p < P; ++p)
                 out.lj64[static_cast<size_t>(c) * kWidePad + p] = out.lj[(static_cast<size_t>(p / kPillarPad) * Kc + c) * kPillarPad + p % kPillarPad];
-        out.wide_blk.assign(static_cast<size_t>(bpl) * 64, -1);
+        // pillar order: the pillars most knots depend on first (stable: equal counts keep the pillar order)
+        std::vector<int> uses(P, 0);
+        for (int c = 0; c < Kc; ++c)
+            for (int p = 0; p < P; ++p) {
+                bool nz = out.lj64[static_cast<size_t>(c) * kWidePad + p] != 0.0;
+                if (!nz && out.has_hess)
+                    for (int q = 0; q < P && !nz; ++q) nz = out.lc[(static_cast<size_t>(c) * P + p) * P + q] != 0.0;
+                if (nz) ++uses[p];
+            }
+        out.wide_order.resize(P);
+        for (int p = 0; p < P; ++p) out.wide_order[p] = p;
+        std::stable_sort(out.wide_order.begin(), out.wide_order.end(), [&](int x, int y) { return uses[x] > uses[y]; });
+        out.wide_pos.assign(kWidePad, 0);
+        for (int aq = 0; aq < P; ++aq) out.wide_pos[out.wide_order[aq]] = aq;
+        for (int p = P; p < kWidePad; ++p) out.wide_pos[p] = p;              // lanes beyond the pillars keep their own (zero) slot
+        // columns of the packed triangle, each padded to an even length: a lane's two entries are rows a, a + 1 of ONE column
+        std::vector<int> col_off(P + 1, 0);
+        for (int bq = 0; bq < P; ++bq) col_off[bq + 1] = col_off[bq] + 2 * ((bq + 2) / 2);
+        const int E = col_off[P];                                             // <= row (wide_chunks)
+        std::vector<int> ea(row, 0), eb(row, 0);
+        std::vector<char> live(row, 0);
+        for (int bq = 0; bq < P; ++bq)
+            for (int aq = 0; aq < col_off[bq + 1] - col_off[bq]; ++aq) {
+                ea[col_off[bq] + aq] = aq; eb[col_off[bq] + aq] = bq;
+                live[col_off[bq] + aq] = aq <= bq;
+            }
+        out.wide_ent.assign(static_cast<size_t>(nch) * 64, 0u);
+        for (int ch = 0; ch < nch; ++ch)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int e0 = ch * kWideChunk + 2 * lane;
+                if (e0 >= E) continue;
+                out.wide_ent[static_cast<size_t>(ch) * 64 + lane] = static_cast<uint32_t>(ea[e0]) | (static_cast<uint32_t>(eb[e0]) << 8) |
+                                                                    (live[e0] ? 1u << 16 : 0u) | (live[e0 + 1] ? 1u << 17 : 0u);
+            }
         {
-            int u = 0;
-            for (int bi = 0; bi < nb; ++bi)
-                for (int bj = bi; bj < nb; ++bj, ++u) out.wide_blk[static_cast<size_t>(u / 64) * 64 + u % 64] = static_cast<int16_t>(bi | (bj << 8));
+            const int bands = (P * P + 127) / 128;
+            out.wide_store_map.assign(static_cast<size_t>(bands) * 64, 0xffffffffu);
+            auto entry_of = [&](int f) -> uint32_t {
+                if (f >= P * P) return 0xffffu;
+                const int pr = out.wide_pos[f / P], pq = out.wide_pos[f % P];
+                return static_cast<uint32_t>(col_off[std::max(pr, pq)] + std::min(pr, pq));
+            };
+            for (int band = 0; band < bands; ++band)
+                for (int lane = 0; lane < 64; ++lane)
+                    out.wide_store_map[static_cast<size_t>(band) * 64 + lane] = entry_of(band * 128 + 2 * lane) | (entry_of(band * 128 + 2 * lane + 1) << 16);
         }
         if (out.has_hess) {
-            out.lcw.assign(static_cast<size_t>(Kc) * bpl * 64 * 16, 0.0);
-            out.lcw_mask.assign(static_cast<size_t>(Kc) * bpl, 0);
+            out.lcflat.assign(static_cast<size_t>(Kc) * row, 0.0);
+            out.wide_knot_chunks.assign(Kc, 0u);
             for (int c = 0; c < Kc; ++c) {
                 const double* lck = &out.lc[static_cast<size_t>(c) * P * P];
-                for (int s = 0; s < bpl; ++s)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int blk = out.wide_blk[static_cast<size_t>(s) * 64 + lane];
-                        if (blk < 0) continue;
-                        const int bi = blk & 0xff, bj = blk >> 8;
-                        double* dst = &out.lcw[((static_cast<size_t>(c) * bpl + s) * 64 + lane) * 16];
-                        bool nz = false;
-                        for (int i = 0; i < 4; ++i)
-                            for (int j = 0; j < 4; ++j) {
-                                const int r = 4 * bi + i, q = 4 * bj + j;
-                                const double x = (r < P && q < P) ? lck[r * P + q] : 0.0;
-                                dst[4 * i + j] = x;
-                                nz = nz || x != 0.0;
-                            }
-                        if (nz) out.lcw_mask[static_cast<size_t>(c) * bpl + s] |= 1ull << lane;
-                    }
+                for (int e = 0; e < E; ++e) {
+                    if (!live[e]) continue;
+                    const double x = lck[out.wide_order[ea[e]] * P + out.wide_order[eb[e]]];
+                    out.lcflat[static_cast<size_t>(c) * row + e] = x;
+                    if (x != 0.0) out.wide_knot_chunks[c] |= 1u << (e / kWideChunk);
+                }
             }
         }
     }

@@ -23,8 +23,17 @@ namespace adr {
 constexpr int kPillarPad = 32;                                  // ladders are padded to this on chip (one pillar tile)
 constexpr int kMaxPillars = 64;                                 // more than 32 pillars: the wide kernel (one launch), or tiles of 32
 constexpr int kWidePad = 64;                                    // wide kernel: ladders padded to one wavefront of pillars
-constexpr int kWideMaxBlocks = 3;                               // ... 4x4 gamma blocks per lane: 136 upper blocks of a 64 x 64 matrix
+constexpr int kWideChunk = 128;                                 // ... packed gamma entries per chunk: two per lane
+constexpr int kWideMaxChunks = 17;                              // ... 64 * 65 / 2 = 2080 packed entries
 constexpr int kAggWide = 1 + kWidePad + kWidePad * kWidePad;    // ... padded [pv, delta, gamma] record of a block partial
+// chunks per row of the packed triangle (columns padded to an even length), rounded up to the kernel variants
+// (7: up to 41 pillars, 10: up to 49, 17: up to 64)
+inline int wide_chunks(int P) {
+    int e = 0;
+    for (int b = 0; b < P; ++b) e += 2 * ((b + 2) / 2);
+    const int n = (e + kWideChunk - 1) / kWideChunk;
+    return n <= 7 ? 7 : (n <= 10 ? 10 : kWideMaxChunks);
+}
 inline int pillar_tiles(int P) { return (P + kPillarPad - 1) / kPillarPad; }
 inline int tile_pair(int ti, int tj) { return tj * (tj + 1) / 2 + ti; }       // ti <= tj
 constexpr int kGammaPerLane = kPillarPad * kPillarPad / 64;     // 16 gamma entries per lane (4x4 block)
@@ -67,13 +76,21 @@ struct CurveTables {
                                        //                     (ti <= tj) at index tile_pair(ti, tj), pair 0 = the only one for P <= 32
     std::vector<uint64_t> lc_block_mask;  // [pairs][Kc] bit l: lane l's 4x4 block of that tile of LC_k has a non-zero entry
 
-    // ---- wide layout (33-64 pillars, kernels_general.hip WIDE variants): one wavefront = 64 pillars, the upper triangle
-    // of the gamma matrix in 4x4 blocks dealt to the lanes, block u of the row-major upper triangle to lane u % 64, slot u / 64
-    int wide_bpl = 0;                  // blocks per lane (1..kWideMaxBlocks); 0: no wide tables (P <= 32)
+    // ---- wide layout (33-64 pillars, kernels_general.hip WIDE variants): one wavefront = 64 pillars for v and the delta
+    // ladder; the gamma matrix as its packed upper triangle in POSITION space - position a of `wide_order` = the pillars
+    // sorted by how many knots depend on them, most first -, column by column (column b: rows a = 0 .. b, padded to an even
+    // length): the pairs a knot's convexity touches sit at the front of the array, and a knot's row is read in the few
+    // 128-entry chunks its `wide_knot_chunks` bit mask names.  Lane l of the wavefront holds entries 128 c + 2 l and
+    // 128 c + 2 l + 1 of chunk c: rows a (even) and a + 1 of one column.
+    int wide_nch = 0;                  // chunks of 128 packed entries: ceil(P (P + 1) / 2 / 128); 0: no wide tables (P <= 32)
+    std::vector<int32_t> wide_order;   // [P] pillar at position a
     std::vector<double> lj64;          // [Kc][64] zero padded
-    std::vector<int16_t> wide_blk;     // [wide_bpl][64] block row | block column << 8 of the lane's block in that slot, -1: none
-    std::vector<double> lcw;           // [Kc][wide_bpl][64][16] LC_k on the lanes' blocks (entry 4 i + j = row 4 bi + i, column 4 bj + j)
-    std::vector<uint64_t> lcw_mask;    // [Kc][wide_bpl] bit l: lane l's block in that slot has a structural non-zero of LC_k
+    std::vector<int32_t> wide_pos;     // [64] position of pillar p (inverse of wide_order; identity beyond P)
+    std::vector<uint32_t> wide_ent;    // [wide_nch][64] the lane's pair: row a | column b << 8 | (entry 0 inside the triangle) << 16 | (entry 1) << 17
+    std::vector<double> lcflat;        // [Kc][wide_nch * 128] LC_k on the packed entries, zero beyond the triangle
+    std::vector<uint32_t> wide_knot_chunks;   // [Kc] bit c: chunk c of the knot's row has a structural non-zero
+    std::vector<uint32_t> wide_store_map;     // [ceil(P * P / 128)][64] packed entry of element 128 band + 2 lane | the next one's << 16
+                                              //                         of the row-major P x P matrix, 0xffff beyond it
 
     // ---- packed layout of the fast kernels (see build_packed_layout) ----
     int Pc = 0;                        // pillars in the core set

@@ -169,12 +169,15 @@ struct CurveDev {
     const double* lj;            // [T][Kc][32]
     const double* lc_lanes;      // [pairs][Kc][64][16], null without gamma
     const unsigned long long* lc_block_mask;  // [pairs][Kc] lanes whose 4x4 block of that tile of LC_k is not structurally zero
-    // wide kernel (33-64 pillars, one launch for the whole ladder): valid when wide_bpl > 0
-    int wide_bpl;                // 4x4 gamma blocks per lane (1..3), 0: no wide tables
+    // wide kernel (33-64 pillars, one launch for the whole ladder; curve_tables.hpp, wide layout): valid when wide_nch > 0
+    int wide_nch;                // chunks of 128 packed gamma entries (two per lane), 0: no wide tables
     const double* lj64;          // [Kc][64]
-    const int16_t* wide_blk;     // [wide_bpl][64] block row | block column << 8, -1: the lane has no block in that slot
-    const double* lcw;           // [Kc][wide_bpl][64][16], null without gamma
-    const unsigned long long* lcw_mask;   // [Kc][wide_bpl]
+    const uint32_t* wide_ent;    // [wide_nch][64] the lane's pair of entries: row | column << 8 | inside-the-triangle bits
+    const int32_t* wide_pos;     // [64] position of pillar p in the packing's pillar order
+    const int32_t* wide_order;   // [P] its inverse
+    const double* lcflat;        // [Kc][wide_nch * 128], null without gamma
+    const uint32_t* wide_knot_chunks;   // [Kc] chunks of the knot's row with a structural non-zero
+    const uint32_t* wide_store_map;     // [bands][64] packed entries of elements 128 band + 2 lane, + 1 of the P x P matrix
     // fast kernels: packed layout (curve_tables.hpp), valid when packed_ok
     int packed_ok, Pc, pc_pad, Ec, Eu, epg, cpg, hub, Kcore, n_mini;
     int fringe_start;            // first packed entry of the fringe pairs (entries fringe_start .. Eu - 1)
@@ -242,9 +245,9 @@ hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes);
 hipError_t launch_price_general(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                                 bool want_gamma, int n_blocks, hipStream_t stream);
 // wide variants of the general kernel: curves of 33-64 pillars, every trade, all three schemes, one launch
-size_t wide_kernel_lds_bytes(int K, int Kc, int bpl, bool gamma);
-int wide_kernel_threads();
-int wide_kernel_blocks_per_cu(size_t lds_bytes);
+size_t wide_kernel_lds_bytes(int K, int Kc, int nch, bool gamma);
+int wide_kernel_threads(int nch, bool gamma);
+int wide_kernel_blocks_per_cu(size_t lds_bytes, int threads);
 hipError_t launch_price_wide(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                              bool want_gamma, int n_blocks, hipStream_t stream);
 // block partials of the wide kernel ([n_blocks][kAggWide]) -> agg[1 + P + P*P], fixed order

@@ -41,6 +41,13 @@ constexpr int kThreadsL2 = kGeneralThreads;      // convexity tiles streamed fro
 constexpr int kThreadsLds = kGeneralLdsThreads;  // convexity rows resident in LDS: 1 block of 8 waves per CU
 constexpr int kConvSlices = 3;                   // 64-entry slices of a packed convexity row (at most 192 core pairs)
 constexpr int kConvStage = 64 * kConvSlices;     // doubles per wave for handing the flat convexity sums to the blocks
+// Wide variants with GAMMA stage a trade's packed ladder in LDS (7 / 10 / 17 KB per wave) on its way to the row-major
+// matrix: 8 waves per block next to the tables for up to 50 pillars (two waves per SIMD), 4 waves beyond (one per SIMD,
+// which may then use the whole register file).
+__host__ __device__ constexpr int general_block_threads(bool ldslc, int wide) {
+    return ldslc ? kThreadsLds : (wide > 0 && wide <= 10 ? 512 : kThreadsL2);
+}
+__host__ __device__ constexpr int wide_bands(int nch) { return nch <= 7 ? 14 : (nch <= 10 ? 20 : 32); }   // 41^2, 50^2, 64^2 elements
 
 __device__ __forceinline__ int readlane_i(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
 
@@ -72,7 +79,10 @@ struct CurveLds {
     const int16_t* compact_of;  // [K]
     int K;
     int method;
-    int wblk[kWideMaxBlocks];   // WIDE: this lane's 4x4 block per slot (block row | block column << 8), -1: none
+    unsigned went[kWideMaxChunks];   // WIDE: this lane's pair of packed gamma entries per chunk: row a (even) | column b << 8 |
+                                     //       (entry 0 inside the triangle) << 16 | (entry 1: row a + 1) << 17, in position space
+    int wrow;                        // WIDE: doubles per row of the packed convexity table
+    int wpos;                        // WIDE: position of this lane's pillar in the packing's pillar order
 };
 
 // One discount-factor lookup.  FLAT_FWD / LINEAR_ZERO: D(t) = exp(ba*L[ka] + bb*L[kb]); ka/kb are rows of the
@@ -154,10 +164,10 @@ __device__ __forceinline__ Lookup curve_lookup(const CurveLds& c, double t) {
 // Per-wave accumulators of one trade (and, separately, of the wave's running portfolio sums).
 template <bool GAMMA, int WIDE = 0>
 struct Ladders {
-    static constexpr int kGammaRegs = GAMMA ? kGammaPerLane * (WIDE > 0 ? WIDE : 1) : 1;
+    static constexpr int kGammaRegs = GAMMA ? (WIDE > 0 ? 2 * WIDE : kGammaPerLane) : 1;
     double pv;                 // lane-partial, reduced at the end of the trade
     double delta;              // lane p (and p + 32, duplicated) holds pillar p; WIDE: lane p holds pillar p of 64
-    double gamma[kGammaRegs];  // WIDE: 16 entries per block slot
+    double gamma[kGammaRegs];  // WIDE: packed entries 128 c + 2 lane, 128 c + 2 lane + 1 of chunk c at [2 c], [2 c + 1]
     double conv[GAMMA ? kConvSlices : 1];   // LDS path: sum_k coef_k * LC_k on the packed core pairs, entry lane + 64 s
     __device__ void clear() {
         pv = 0.0; delta = 0.0;
@@ -282,15 +292,20 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
     }
 }
 
-// WIDE variants (curves of 33-64 pillars): lane p builds v for pillar p of 64 from the 64-wide Jacobian table, and a lane
-// holds up to BPL 4x4 blocks of the upper triangle of the whole P x P matrix (curve_tables.hpp, wide layout) - the rank-one
-// term from the wave's v hand-off buffer, the convexity term from lane-major tiles in L2 under a per-knot lane mask, as
-// above; one launch covers the whole ladder instead of one launch per pair of 32-pillar tiles.
-template <int NK, bool DELTA, bool GAMMA, bool CF, int BPL>
+// WIDE variants (curves of 33-64 pillars; curve_tables.hpp, wide layout): lane p builds v for pillar p of 64 from the 64-wide
+// Jacobian table; the gamma matrix is held as its packed upper triangle, two entries per lane and 128-entry chunk.  The
+// rank-one term reads omega v of the lane's two rows (one 16-byte read) and v of its column from the wave's hand-off buffers,
+// which hold v in the packing's pillar order; the convexity term adds
+// coef * (row of LC_k in the same packed order) straight into the same registers - 16 bytes per lane and chunk from L2,
+// and only the chunks the knot's bit mask names (the pillar order of the packing puts a knot's pairs at the front of the
+// row: typically one to three chunks of 1 KB per knot instead of a 128-byte tile for each of the wave's 64 lanes).
+// One launch covers the whole ladder instead of one launch per pair of 32-pillar tiles.
+template <int NK, bool DELTA, bool GAMMA, bool CF, int NCH>
 __device__ __forceinline__ void add_nodes_wide(unsigned long long mask, const int (&k)[NK], const double (&b)[NK],
-                                               double omega, const CurveLds& c, const double* __restrict__ lcw,
-                                               const unsigned long long* lcw_mask, double* vbuf, int lane,
-                                               Ladders<GAMMA, BPL>& acc, const double (&cf)[NK]) {
+                                               double omega, const CurveLds& c, const double* __restrict__ lcflat,
+                                               const unsigned* knot_chunks, double* vbuf, int lane,
+                                               Ladders<GAMMA, NCH>& acc, const double (&cf)[NK]) {
+    static_assert(NK % 2 == 0, "knots are walked in pairs");
     while (mask) {
         const int n = __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -310,35 +325,50 @@ __device__ __forceinline__ void add_nodes_wide(unsigned long long mask, const in
         if (DELTA) acc.delta = fma(om, v, acc.delta);
         if constexpr (GAMMA) {
             __builtin_amdgcn_wave_barrier();
-            vbuf[lane] = v;
+            vbuf[c.wpos] = v;                       // in position space: the rows of a column are consecutive
+            vbuf[kWidePad + c.wpos] = om * v;
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
+            // Convexity rows of the node's knots, a pair of knots at a time: every chunk either knot has entries in
+            // (wave-uniform bit masks) is requested for both, all requests of the pair ahead of the rank-one update (first
+            // pair) and of their FMAs.  No register is initialised for a chunk that is not read.
 #pragma unroll
-            for (int s = 0; s < BPL; ++s) {
-                const int blk = c.wblk[s];
-                if (blk < 0) continue;
-                const int bi = blk & 0xff, bj = blk >> 8;
-                double vr[4], vc[4];
+            for (int i0 = 0; i0 < NK; i0 += 2) {
+                unsigned m = (cc[i0] != 0.0 ? knot_chunks[kk[i0]] : 0u) | (cc[i0 + 1] != 0.0 ? knot_chunks[kk[i0 + 1]] : 0u);
+                m = __builtin_amdgcn_readfirstlane(m);
+                const double2* ra = reinterpret_cast<const double2*>(lcflat + static_cast<size_t>(kk[i0]) * c.wrow) + lane;
+                const double2* rb = reinterpret_cast<const double2*>(lcflat + static_cast<size_t>(kk[i0 + 1]) * c.wrow) + lane;
+#ifndef ADR_WIDE_BATCH
+#define ADR_WIDE_BATCH 4
+#endif
+                constexpr int BATCH = ADR_WIDE_BATCH;   // chunks in flight: 8 registers of row data each
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { vr[i] = om * vbuf[4 * bi + i]; vc[i] = vbuf[4 * bj + i]; }
+                for (int c0 = 0; c0 < NCH; c0 += BATCH) {
+                    double2 la[BATCH], lb[BATCH];
+                    const bool any = ((m >> c0) & ((1u << BATCH) - 1u)) != 0;      // wave-uniform
+                    if (any) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                        for (int q = 0; q < BATCH; ++q)
+                            if (c0 + q < NCH && ((m >> (c0 + q)) & 1u)) { la[q] = ra[(c0 + q) * 64]; lb[q] = rb[(c0 + q) * 64]; }
+                    }
+                    if (i0 == 0 && c0 == 0) {       // the rank-one term, under the first requests
 #pragma unroll
-                    for (int jx = 0; jx < 4; ++jx)
-                        acc.gamma[s * 16 + i * 4 + jx] = fma(vr[i], vc[jx], acc.gamma[s * 16 + i * 4 + jx]);
-#pragma unroll
-                for (int i = 0; i < NK; ++i) {
-                    const double coef = cc[i];
-                    if (coef != 0.0 && ((lcw_mask[kk[i] * BPL + s] >> lane) & 1ull)) {
-                        const double2* tile = reinterpret_cast<const double2*>(
-                            lcw + ((static_cast<size_t>(kk[i]) * BPL + s) * 64 + lane) * 16);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const double2 tv = tile[e];
-                            acc.gamma[s * 16 + 2 * e] = fma(coef, tv.x, acc.gamma[s * 16 + 2 * e]);
-                            acc.gamma[s * 16 + 2 * e + 1] = fma(coef, tv.y, acc.gamma[s * 16 + 2 * e + 1]);
+                        for (int ch = 0; ch < NCH; ++ch) {
+                            const unsigned w = c.went[ch];
+                            const double2 wa = *reinterpret_cast<const double2*>(vbuf + kWidePad + (w & 0xff));   // omega v at rows a, a + 1
+                            const double vb = vbuf[(w >> 8) & 0xff];
+                            acc.gamma[2 * ch] = fma(wa.x, vb, acc.gamma[2 * ch]);
+                            acc.gamma[2 * ch + 1] = fma(wa.y, vb, acc.gamma[2 * ch + 1]);
                         }
+                    }
+                    if (any) {
+#pragma unroll
+                        for (int q = 0; q < BATCH; ++q)
+                            if (c0 + q < NCH && ((m >> (c0 + q)) & 1u)) {
+                                acc.gamma[2 * (c0 + q)] = fma(cc[i0], la[q].x, fma(cc[i0 + 1], lb[q].x, acc.gamma[2 * (c0 + q)]));
+                                acc.gamma[2 * (c0 + q) + 1] = fma(cc[i0], la[q].y, fma(cc[i0 + 1], lb[q].y, acc.gamma[2 * (c0 + q) + 1]));
+                            }
                     }
                 }
             }
@@ -351,7 +381,7 @@ __device__ __forceinline__ void add_nodes_any(unsigned long long mask, const int
                                               double omega, const CurveLds& c, const double* __restrict__ lc_lanes,
                                               const unsigned long long* lc_block_mask, double* vbuf, int lane,
                                               Ladders<GAMMA, WIDE>& acc, const double (&cf)[NK], const ConvLds& conv) {
-    if constexpr (WIDE > 0) add_nodes_wide<NK, DELTA, GAMMA, CF, WIDE>(mask, k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf);
+    if constexpr (WIDE > 0) add_nodes_wide<NK, DELTA, GAMMA, CF, WIDE>(mask, k, b, omega, c, lc_lanes, reinterpret_cast<const unsigned*>(lc_block_mask), vbuf, lane, acc, cf);
     else add_nodes<NK, DELTA, GAMMA, CF, LDSLC>(mask, k, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf, conv);
 }
 
@@ -379,28 +409,33 @@ template <bool DELTA, bool GAMMA, bool LINDF, bool LDSLC, int WIDE = 0>
 // Two waves per SIMD either way (two blocks of 4 waves, the curve tables being about 75 KB, or one block of 8 waves next
 // to 112 KB of convexity rows): the register budget is pinned to that (without the bound the gamma instantiation
 // drifts to 256 VGPRs + AGPRs and one wave per SIMD).
-__global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_general_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
-    static_assert(!(WIDE > 0 && LDSLC), "the wide variants stream their convexity tiles from L2");
-    constexpr int kBlockThreads = LDSLC ? kThreadsLds : kThreadsL2;
+__global__ __launch_bounds__(general_block_threads(LDSLC, WIDE), (WIDE > 10) ? 1 : 2) void price_general_kernel(CurveDev cv, TradesDev tr, OutputsDev out) {
+    static_assert(!(WIDE > 0 && LDSLC), "the wide variants stream their convexity rows from L2");
+    constexpr int kBlockThreads = general_block_threads(LDSLC, WIDE);
+    constexpr int kWideBands = wide_bands(WIDE);                  // 128-element bands of the P x P output matrix
     constexpr int kWavesPerBlock = kBlockThreads / 64;
     constexpr int kLjPad = WIDE > 0 ? kWidePad : kPillarPad;      // row width of the Jacobian table in LDS
-    constexpr int kMaskWords = WIDE > 0 ? WIDE : 1;              // 64-bit lane masks per knot
+    constexpr int kVbuf = WIDE > 0 ? 2 * kWidePad : 64;           // doubles of hand-off buffer per wave (WIDE: v and omega v)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS carve-up: doubles first (16-byte aligned base), then the int16 index tables
-    double* s_x = reinterpret_cast<double*>(smem_raw);
+    // (WIDE with GAMMA: the waves' staging areas for the packed ladder come first - 16-byte aligned)
+    double* s_wstage = reinterpret_cast<double*>(smem_raw);
+    double* s_wvbuf = s_wstage + ((WIDE > 0 && GAMMA) ? kWavesPerBlock * WIDE * kWideChunk : 0);      // WIDE: the v hand-off buffers next
+    double* s_x = s_wvbuf + (WIDE > 0 ? kWavesPerBlock * kVbuf : 0);
     double* s_log = s_x + cv.K;
     double* s_invx = s_log + cv.Kc;
     const bool diag = WIDE > 0 || cv.tile_i == cv.tile_j;
     const int n_lj = cv.Kc * kLjPad;                     // one pillar tile of LJ (WIDE: all 64 columns)
     double* s_lj = s_invx + cv.Kc;
-    double* s_vbuf = s_lj + static_cast<size_t>(n_lj) * (diag ? 1 : 2);
+    double* s_vbuf = WIDE > 0 ? s_wvbuf : s_lj + static_cast<size_t>(n_lj) * (diag ? 1 : 2);
+    double* s_after_lj = s_lj + static_cast<size_t>(n_lj) * ((diag || WIDE > 0) ? 1 : 2);
     // per-knot masks of the structurally non-zero LC blocks: read before every tile, so LDS-resident (a global
     // read here would put a second L2 round trip in front of each tile)
-    unsigned long long* s_lcmask = reinterpret_cast<unsigned long long*>(s_vbuf + kWavesPerBlock * 64);
+    unsigned long long* s_lcmask = reinterpret_cast<unsigned long long*>(WIDE > 0 ? s_after_lj : s_vbuf + kWavesPerBlock * kVbuf);   // WIDE: 32-bit chunk masks
     // LDS path: packed convexity rows, the short-end records and the per-wave staging of the flat sums
     const int ec_stride = cv.Ec + 1;
     const int n_lcc = (LDSLC && GAMMA) ? (cv.Kcore + 1) * ec_stride : 0;
-    double* s_lcc = reinterpret_cast<double*>(s_lcmask + ((GAMMA && !LDSLC) ? cv.Kc * kMaskWords : 0));
+    double* s_lcc = reinterpret_cast<double*>(s_lcmask + ((GAMMA && !LDSLC) ? (WIDE > 0 ? (cv.Kc + 1) / 2 : cv.Kc) : 0));
     double* s_stage = s_lcc + n_lcc;
     MiniKnot* s_mini = reinterpret_cast<MiniKnot*>(s_stage + ((LDSLC && GAMMA) ? kWavesPerBlock * kConvStage : 0));
     int16_t* s_first = reinterpret_cast<int16_t*>(s_mini + ((LDSLC && GAMMA) ? cv.n_mini : 0));
@@ -420,7 +455,7 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
         if (LDSLC) s_class[i] = cv.knot_class[i];
     }
     if constexpr (GAMMA && WIDE > 0)
-        for (int i = threadIdx.x; i < cv.Kc * WIDE; i += kBlockThreads) s_lcmask[i] = cv.lcw_mask[i];
+        for (int i = threadIdx.x; i < cv.Kc; i += kBlockThreads) reinterpret_cast<unsigned*>(s_lcmask)[i] = cv.wide_knot_chunks[i];
     for (int i = threadIdx.x; i < n_lcc; i += kBlockThreads) s_lcc[i] = cv.lcc[i];
     if (LDSLC && GAMMA) {
         const double* src = reinterpret_cast<const double*>(cv.mini);
@@ -447,7 +482,7 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar loads of the header
     const int knot0 = c.compact_of[0];                                    // the value-time knot (t = 0)
     constexpr bool linear_df = LINDF;                                     // LINEAR_FWD_RATES: see `Lookup`
-    double* vbuf = s_vbuf + wave * 64;
+    double* vbuf = s_vbuf + wave * kVbuf;
     const int P = cv.P;
     c.lj_off = (lane >= 32 && !diag) ? n_lj : 0;
     c.col0 = diag ? 0 : 32;
@@ -455,9 +490,42 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
     const int row0 = kPillarPad * cv.tile_i, col0g = kPillarPad * cv.tile_j;    // first pillar of the row / column tile
     const bool first_tile = WIDE > 0 || (cv.tile_i == 0 && cv.tile_j == 0);
     const bool one_tile = cv.T == 1;
-    const double* __restrict__ lc_lanes = WIDE > 0 ? cv.lcw : cv.lc_lanes;
+    const double* __restrict__ lc_lanes = WIDE > 0 ? cv.lcflat : cv.lc_lanes;
 #pragma unroll
-    for (int s_ = 0; s_ < kWideMaxBlocks; ++s_) c.wblk[s_] = (WIDE > 0 && GAMMA && s_ < WIDE) ? cv.wide_blk[s_ * 64 + lane] : -1;
+    for (int s_ = 0; s_ < kWideMaxChunks; ++s_) c.went[s_] = (WIDE > 0 && GAMMA && s_ < WIDE) ? cv.wide_ent[s_ * 64 + lane] : 0u;
+    c.wrow = WIDE * kWideChunk;
+    c.wpos = WIDE > 0 ? cv.wide_pos[lane] : lane;
+    // WIDE: packed entries feeding elements 128 band + 2 lane, + 1 of the row-major P x P matrix (0xffff beyond P * P)
+    unsigned wmap[(WIDE > 0 && GAMMA) ? kWideBands : 1];
+    if constexpr (WIDE > 0 && GAMMA) {
+#pragma unroll
+        for (int band = 0; band < kWideBands; ++band) wmap[band] = band * 128 < P * P ? cv.wide_store_map[band * 64 + lane] : 0xffffffffu;
+    }
+    double* wstage = s_wstage + wave * (WIDE * kWideChunk);
+    double* pending_gamma = nullptr;     // WIDE: matrix of the trade whose packed ladder waits in the staging area (wave-uniform)
+    auto flush_gamma = [&]() {
+        if constexpr (WIDE > 0 && GAMMA) {
+            double* g = pending_gamma;
+            if (!g) return;
+            pending_gamma = nullptr;
+            const bool vec = (P & 1) == 0;      // P even: every pair of elements is a 16-byte aligned pair of the matrix
+#pragma unroll
+            for (int band = 0; band < kWideBands; ++band) {
+                if (band * 128 >= P * P) continue;                     // wave-uniform
+                const unsigned w = wmap[band];
+                const unsigned e0 = w & 0xffffu, e1 = w >> 16;
+                const double x0 = e0 != 0xffffu ? wstage[e0] : 0.0;
+                const double x1 = e1 != 0xffffu ? wstage[e1] : 0.0;
+                double* dst = g + band * 128 + 2 * lane;
+                if (vec) {
+                    if (e0 != 0xffffu) *reinterpret_cast<double2*>(dst) = make_double2(x0, x1);
+                } else {
+                    if (e0 != 0xffffu) dst[0] = x0;
+                    if (e1 != 0xffffu) dst[1] = x1;
+                }
+            }
+        }
+    };
     const unsigned long long* lc_block_mask = s_lcmask;
     ConvLds conv;
     conv.lcc = s_lcc; conv.mini = s_mini; conv.ec_stride = ec_stride; conv.flat_of = cv.lcc_pos;
@@ -525,6 +593,7 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
             // own start node S_j unless it coincides with the previous payment node
             bool own_start = valid && linear;
             if (own_start && j > 0 && f_tp[j - 1] == ts) own_start = false;
+            if (base == 0) flush_gamma();   // WIDE: the previous trade's gamma stores, behind this trade's input loads
 
             // payment node; its ladder work comes after the ratio nodes, which take over its convexity entries
             int kp[2]; double bp[2], cfp[2]; double omega_p = 0.0;
@@ -701,51 +770,24 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
                 total.delta += d;
             }
             if constexpr (GAMMA) {
-                double* g = out.gamma ? out.gamma + t * static_cast<int64_t>(P) * P : nullptr;
-                const bool vec = (P & 3) == 0;          // rows of a block are 32-byte aligned runs inside the matrix
+                // the packed ladder goes through the wave's staging area to the row-major matrix: 1 KB-contiguous stores
+                // (8-byte scattered stores of the entries to their two mirrored positions cost 0.6 ms per 100 k trades at
+                // 40 pillars and 3 ms at 64: one write request per element).  The stores themselves are issued at the start
+                // of the wave's NEXT trade, behind that trade's input loads (flush_gamma): vector memory operations retire in
+                // order, so loads queued behind 13-32 KB of stores would wait for them to drain.
+                flush_gamma();                     // (a trade without float coupons has not flushed its predecessor yet)
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int s_ = 0; s_ < WIDE; ++s_) {
-                    const int blk = c.wblk[s_];
-                    if (blk < 0) continue;
-                    const int bi = blk & 0xff, bj = blk >> 8;
-                    double gv[16];
-#pragma unroll
-                    for (int e_ = 0; e_ < 16; ++e_) {
-                        gv[e_] = acc.gamma[s_ * 16 + e_] * 1e-8;
-                        total.gamma[s_ * 16 + e_] += gv[e_];
-                    }
-                    if (!g) continue;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = 4 * bi + i;
-                        if (r >= P) continue;
-                        if (vec) {
-                            double2* dst = reinterpret_cast<double2*>(g + r * P + 4 * bj);
-                            dst[0] = make_double2(gv[4 * i], gv[4 * i + 1]);
-                            dst[1] = make_double2(gv[4 * i + 2], gv[4 * i + 3]);
-                        } else {
-#pragma unroll
-                            for (int jx = 0; jx < 4; ++jx)
-                                if (4 * bj + jx < P) g[r * P + 4 * bj + jx] = gv[4 * i + jx];
-                        }
-                    }
-                    if (bi < bj) {
-#pragma unroll
-                        for (int jx = 0; jx < 4; ++jx) {
-                            const int r = 4 * bj + jx;
-                            if (r >= P) continue;
-                            if (vec) {
-                                double2* dst = reinterpret_cast<double2*>(g + r * P + 4 * bi);
-                                dst[0] = make_double2(gv[jx], gv[4 + jx]);
-                                dst[1] = make_double2(gv[8 + jx], gv[12 + jx]);
-                            } else {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    if (4 * bi + i < P) g[r * P + 4 * bi + i] = gv[4 * i + jx];
-                            }
-                        }
-                    }
+                for (int ch = 0; ch < WIDE; ++ch) {
+                    const double g0 = acc.gamma[2 * ch] * 1e-8, g1 = acc.gamma[2 * ch + 1] * 1e-8;
+                    total.gamma[2 * ch] += (c.went[ch] & 0x10000u) ? g0 : 0.0;
+                    total.gamma[2 * ch + 1] += (c.went[ch] & 0x20000u) ? g1 : 0.0;
+                    if (out.gamma) *reinterpret_cast<double2*>(wstage + ch * kWideChunk + 2 * lane) = make_double2(g0, g1);
                 }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+                pending_gamma = out.gamma ? out.gamma + t * static_cast<int64_t>(P) * P : nullptr;
             }
         } else {
         if (lane == 0 && first_tile) {
@@ -819,6 +861,7 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
     }   // WIDE == 0
     }
 
+    flush_gamma();
     // ------------------------------------------------------------------------ block partial of the aggregate
     if constexpr (WIDE > 0) {
         if (out.block_partials) {
@@ -833,15 +876,15 @@ __global__ __launch_bounds__(LDSLC ? kThreadsLds : kThreadsL2, 2) void price_gen
                     if (DELTA) red[1 + lane] += total.delta;
                     if constexpr (GAMMA) {
 #pragma unroll
-                        for (int s_ = 0; s_ < WIDE; ++s_) {
-                            const int blk = c.wblk[s_];
-                            if (blk < 0) continue;
-                            const int bi = blk & 0xff, bj = blk >> 8;
+                        for (int ch = 0; ch < WIDE; ++ch) {
+                            const unsigned w = c.went[ch];
+                            const int aq = w & 0xff, bq = (w >> 8) & 0xff;
 #pragma unroll
-                            for (int e_ = 0; e_ < 16; ++e_) {
-                                const int r = 4 * bi + (e_ >> 2), q = 4 * bj + (e_ & 3);
-                                red[1 + kWidePad + r * kWidePad + q] += total.gamma[s_ * 16 + e_];
-                                if (bi < bj) red[1 + kWidePad + q * kWidePad + r] += total.gamma[s_ * 16 + e_];
+                            for (int q = 0; q < 2; ++q) {
+                                if (!(w & (0x10000u << q))) continue;
+                                const int i = cv.wide_order[aq + q], j = cv.wide_order[bq];
+                                red[1 + kWidePad + i * kWidePad + j] += total.gamma[2 * ch + q];
+                                if (i != j) red[1 + kWidePad + j * kWidePad + i] += total.gamma[2 * ch + q];
                             }
                         }
                     }
@@ -973,51 +1016,53 @@ __global__ __launch_bounds__(256) void reduce_wide_kernel(const double* partials
 
 template <bool LINDF>
 void collect_wide(std::vector<const void*>& fns) {
-    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, LINDF, false, 1>));
-    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, LINDF, false, 2>));
-    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, LINDF, false, 3>));
-    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, false, LINDF, false, 1>));
-    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<false, false, LINDF, false, 1>));
+    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, LINDF, false, 7>));
+    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, LINDF, false, 10>));
+    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, LINDF, false, 17>));
+    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, false, LINDF, false, 7>));
+    fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<false, false, LINDF, false, 7>));
 }
 
 }  // namespace
 
-size_t wide_kernel_lds_bytes(int K, int Kc, int bpl, bool gamma) {
-    constexpr int kWavesPerBlock = kThreadsL2 / 64;
-    size_t bytes = sizeof(double) * (static_cast<size_t>(K) + 2 * Kc + static_cast<size_t>(Kc) * kWidePad + kWavesPerBlock * 64) +
-                   (gamma ? sizeof(unsigned long long) * static_cast<size_t>(Kc) * bpl : 0) +
+size_t wide_kernel_lds_bytes(int K, int Kc, int nch, bool gamma) {
+    const int kWavesPerBlock = general_block_threads(false, gamma ? nch : 7) / 64;
+    size_t bytes = sizeof(double) * (static_cast<size_t>(K) + 2 * Kc + static_cast<size_t>(Kc) * kWidePad + kWavesPerBlock * 2 * kWidePad +
+                                     (gamma ? static_cast<size_t>(kWavesPerBlock) * nch * kWideChunk : 0)) +
+                   (gamma ? sizeof(unsigned long long) * static_cast<size_t>((Kc + 1) / 2) : 0) +
                    sizeof(int16_t) * (2 * static_cast<size_t>(K) + 2 * kLutMax);
     const size_t reduce = sizeof(double) * kAggWide;
     if (bytes < reduce) bytes = reduce;
     return (bytes + 15) & ~static_cast<size_t>(15);
 }
 
-int wide_kernel_threads() { return kThreadsL2; }
+int wide_kernel_threads(int nch, bool gamma) { return general_block_threads(false, gamma ? nch : 7); }
 
-// blocks of 4 waves a CU holds: the register budget allows two waves per SIMD (launch bounds), the LDS image the rest
-int wide_kernel_blocks_per_cu(size_t lds_bytes) {
-    const size_t by_lds = lds_bytes ? (160 * 1024) / lds_bytes : 2;
-    return static_cast<int>(by_lds < 1 ? 1 : (by_lds > 2 ? 2 : by_lds));
+// blocks a CU holds: the register budget allows two waves per SIMD (launch bounds), the LDS image the rest
+int wide_kernel_blocks_per_cu(size_t lds_bytes, int threads) {
+    const size_t by_lds = lds_bytes ? (160 * 1024) / lds_bytes : 1, by_regs = static_cast<size_t>(512 / threads);
+    const size_t n = by_lds < by_regs ? by_lds : by_regs;
+    return static_cast<int>(n < 1 ? 1 : n);
 }
 
 hipError_t launch_price_wide(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                              bool want_gamma, int n_blocks, hipStream_t stream) {
     const bool lin = cv.method == 2;
-    const size_t lds = wide_kernel_lds_bytes(cv.K, cv.Kc, cv.wide_bpl, want_gamma);
-    dim3 grid(n_blocks), block(kThreadsL2);
+    const size_t lds = wide_kernel_lds_bytes(cv.K, cv.Kc, cv.wide_nch, want_gamma);
+    dim3 grid(n_blocks), block(wide_kernel_threads(cv.wide_nch, want_gamma));
     using Fn = void (*)(CurveDev, TradesDev, OutputsDev);
     Fn fn = nullptr;
     if (want_gamma) {
-        switch (cv.wide_bpl) {
-            case 1: fn = lin ? &price_general_kernel<true, true, true, false, 1> : &price_general_kernel<true, true, false, false, 1>; break;
-            case 2: fn = lin ? &price_general_kernel<true, true, true, false, 2> : &price_general_kernel<true, true, false, false, 2>; break;
-            case 3: fn = lin ? &price_general_kernel<true, true, true, false, 3> : &price_general_kernel<true, true, false, false, 3>; break;
+        switch (cv.wide_nch) {
+            case 7: fn = lin ? &price_general_kernel<true, true, true, false, 7> : &price_general_kernel<true, true, false, false, 7>; break;
+            case 10: fn = lin ? &price_general_kernel<true, true, true, false, 10> : &price_general_kernel<true, true, false, false, 10>; break;
+            case 17: fn = lin ? &price_general_kernel<true, true, true, false, 17> : &price_general_kernel<true, true, false, false, 17>; break;
             default: return hipErrorInvalidValue;
         }
     } else if (want_delta) {
-        fn = lin ? &price_general_kernel<true, false, true, false, 1> : &price_general_kernel<true, false, false, false, 1>;
+        fn = lin ? &price_general_kernel<true, false, true, false, 7> : &price_general_kernel<true, false, false, false, 7>;
     } else {
-        fn = lin ? &price_general_kernel<false, false, true, false, 1> : &price_general_kernel<false, false, false, false, 1>;
+        fn = lin ? &price_general_kernel<false, false, true, false, 7> : &price_general_kernel<false, false, false, false, 7>;
     }
     hipLaunchKernelGGL(fn, grid, block, lds, stream, cv, tr, out);
     return hipGetLastError();

@@ -59,12 +59,15 @@ typedef enum adr_status {
 #define ADR_REQ_DELTA 2u
 #define ADR_REQ_GAMMA 4u
 
-/* Largest pillar count (the reference has none, cavour/market/position/engine.py:2388-2389).  Ladders live on chip
- * in tiles of 32 pillars: curves of up to 32 pillars take the fast kernels; beyond that the general kernel prices each
- * trade once per pair of tiles - 3 launches for GAMMA on 33-64 pillars, 2 for DELTA, 1 for VALUE alone - at roughly a
- * tenth of the 32-pillar throughput (profiles/r02_many_pillars_bench.json: 26 M against 350 M trades/s with GAMMA).
- * Odd pillar counts are served by the general kernel as well (the fast kernel stores the [P][P] matrices as 16-byte
- * pairs).  The device curve builder (adr_curve_plan_create) takes at most 32 pillars. */
+/* Largest pillar count (the reference has none, cavour/market/position/engine.py:2388-2389).  Curves of up to 32
+ * pillars take the fast kernels.  Curves of 33-64 pillars take the WIDE variants of the general kernel: one wavefront holds
+ * the whole delta ladder (lane = pillar), the gamma matrix is accumulated as its packed upper triangle and written once -
+ * one launch per request, every trade type and all three schemes; 40 pillars: 86 M trades/s with GAMMA, 340 M with DELTA
+ * (profiles/r03_many_pillars_bench.json; 26 M / 244 M on the tiled route it replaces), 64 pillars: 42 M / 333 M.  A curve
+ * whose wide tables exceed the LDS of a CU (several hundred reachable knots), or a curve uploaded with ADR_WIDE_KERNEL=0
+ * in the environment, is priced by the general kernel once per pair of 32-pillar tiles instead: 3 launches for GAMMA, 2
+ * for DELTA, 1 for VALUE alone.  Odd pillar counts are served by the general kernel as well (the fast kernel stores the
+ * [P][P] matrices as 16-byte pairs).  The device curve builder (adr_curve_plan_create) takes at most 32 pillars. */
 #define ADR_MAX_PILLARS 64
 
 int adr_version(void);
@@ -109,10 +112,12 @@ int adr_curve_tables_host(int K, int P, const double* times, const double* dfs,
 
 /*
  * Diagnostic twin of adr_curve_tables_host: how the fast kernels would lay this curve out in LDS.
- * info[12] = { packed layout usable (0/1), core pillars Pc, core pairs Ec, packed entries Eu,
+ * info[16] = { packed layout usable (0/1), core pillars Pc, core pairs Ec, packed entries Eu,
  *              entries per lane, core-table rows, short-end (mini) knots, LDS bytes of the gamma kernel,
  *              LDS bytes of the general kernel's variant with resident convexity rows (0: none), that variant fits (0/1),
- *              core slots per lane, hub layout found (0/1: the exact kernel variants; 0 = the universal ones) }.
+ *              core slots per lane, hub layout found (0/1: the exact kernel variants; 0 = the universal ones),
+ *              wide layout (33-64 pillars): 128-entry chunks per row of the packed triangle (7 / 10 / 17; 0: none),
+ *              LDS bytes of the wide gamma kernel, the most chunks any knot's convexity row is read in, reserved }.
  * Returns 0 or a negative status.  No GPU needed.
  */
 int adr_curve_layout_host(int K, int P, const double* times, const double* dfs,

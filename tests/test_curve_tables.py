@@ -158,3 +158,32 @@ def test_hub_layout_with_identity_row_positions_is_found_for_the_benchmark_curve
         assert info["packed_ok"] == 1 and info["hub_layout"] == 1, info
         assert info["core_pillars"] == 17 and info["core_pairs"] == 153 and info["core_slots_per_lane"] == 5
         assert info["entries_per_lane"] == 7 and info["lds_bytes"] <= 160 * 1024
+
+
+def test_wide_layout_of_curves_with_more_than_32_pillars():
+    """33-64 pillars: the wide layout (curve_tables.hpp) - the packed upper triangle of the gamma matrix in 7 / 10 / 17
+    chunks of 128 entries, the kernel's LDS image inside a CU's 160 KB, and a knot's convexity row confined to a few chunks
+    by the pillar order of the packing (CPU; the GPU parity tests are tests/test_gpu_many_pillars.py)."""
+    from tests import _fixtures as F
+
+    def years(t):
+        return int(t[:-1]) / {"D": 365.0, "W": 52.0, "M": 12.0, "Y": 1.0}[t[-1]]
+
+    base_t = np.array([years(t) for t in F.TENORS])
+    extra = [f"{y}Y" for y in range(1, 50) if f"{y}Y" not in F.TENORS]
+    for P, chunks in ((33, 7), (40, 7), (41, 7), (42, 10), (49, 10), (50, 17), (64, 17)):
+        tenors = sorted(list(F.TENORS) + extra, key=years)[:P]
+        px = [float(np.interp(years(t), base_t, F.GBP_PX)) if t not in F.TENORS else F.GBP_PX[F.TENORS.index(t)] for t in tenors]
+        curve = F.gbp_model(F.README_VALUE_DT, px=px, tenors=tenors).curves.GBP_OIS_SONIA
+        h = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+        info = _native.curve_layout_host(h.times, h.dfs, h.jac, h.hess)
+        assert info["packed_ok"] == 0                                   # the fast kernels' layout is for one pillar tile
+        assert info["wide_chunks"] == chunks, (P, info)
+        assert 0 < info["wide_lds_bytes"] <= 160 * 1024, (P, info)
+        # the padded triangle fits the chunks: sum over columns b of 2 * ceil((b + 1) / 2) entries
+        assert sum(2 * ((b + 2) // 2) for b in range(P)) <= 128 * chunks
+        # annual pillars sorted by use: a knot's pairs sit in a prefix of the packed array
+        assert 1 <= info["wide_max_knot_chunks"] <= max(3, chunks * 2 // 3), (P, info)
+    info32 = _native.curve_layout_host(*(lambda h: (h.times, h.dfs, h.jac, h.hess))(
+        build_engine_curve(*(lambda c: (c.swap_rates, c.swap_times, c.year_fracs))(F.gbp_model().curves.GBP_OIS_SONIA))))
+    assert info32["wide_chunks"] == 0 and info32["packed_ok"] == 1
