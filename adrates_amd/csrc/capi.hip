@@ -410,8 +410,8 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
         interp_method != ADR_INTERP_LINEAR_FWD_RATES)
         return fail(ADR_ERR_UNSUPPORTED, "adr_curve_plan_create: only FLAT_FWD_RATES (1), LINEAR_FWD_RATES (2) and "
                                          "LINEAR_ZERO_RATES (4) are implemented");
-    if (P > adr::kPillarPad)
-        return fail(ADR_ERR_UNSUPPORTED, "adr_curve_plan_create: the device curve builder takes at most 32 pillars");
+    if (P > ADR_MAX_PILLARS)
+        return fail(ADR_ERR_UNSUPPORTED, "adr_curve_plan_create: more than ADR_MAX_PILLARS (64) pillars");
     if (!acc || !pillar || !prev_idx) return fail(ADR_ERR_INVALID, "adr_curve_plan_create: null scan arrays");
     for (int k = 0; k < K; ++k) {
         if (pillar[k] < 0 || pillar[k] >= P) return fail(ADR_ERR_INVALID, "adr_curve_plan_create: pillar index out of range");
@@ -425,8 +425,12 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     adr::CurveTables& t = plan->base;
     const std::string err = adr::build_curve_tables(K, P, times, base_dfs, base_jac, base_hess, t);
     if (!err.empty()) { delete plan; return fail(ADR_ERR_INVALID, "adr_curve_plan_create: " + err); }
-    const size_t lds = adr::general_kernel_lds_bytes(t.K, t.Kc);
-    if (lds > kLdsBudget || adr::bootstrap_kernel_lds_bytes(K, P) > kLdsBudget) {
+    // more than 32 pillars: the built curves carry the wide layout's tables only (no tiled route for them)
+    const bool wide = t.T > 1;
+    const size_t lds = wide ? adr::wide_kernel_lds_bytes(t.K, t.Kc, t.wide_nch, plan->has_hess) : adr::general_kernel_lds_bytes(t.K, t.Kc);
+    // the PV01 gradients of the scan ([K][P] doubles) stay in LDS when they fit, else they go through a scratch buffer
+    const bool dpv_global = adr::bootstrap_kernel_lds_bytes(K, P, false) > kLdsBudget;
+    if (lds > kLdsBudget || adr::bootstrap_kernel_lds_bytes(K, P, dpv_global) > kLdsBudget) {
         delete plan;
         return fail(ADR_ERR_UNSUPPORTED, "adr_curve_plan_create: curve tables exceed the 160 KiB LDS of a CU");
     }
@@ -461,6 +465,17 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     track(upload(comp16, &d_comp), d_comp);
     int16_t* d_lut = nullptr;
     track(upload(t.lut, &d_lut), d_lut);
+    uint32_t *d_went = nullptr, *d_wchunks = nullptr, *d_wsmap = nullptr;
+    int32_t *d_wpos = nullptr, *d_worder = nullptr;
+    uint8_t* d_wpq = nullptr;
+    if (wide) {
+        track(upload(t.wide_ent, &d_went), d_went);
+        track(upload(t.wide_store_map, &d_wsmap), d_wsmap);
+        track(upload(t.wide_pos, &d_wpos), d_wpos);
+        track(upload(t.wide_order, &d_worder), d_worder);
+        track(upload(t.wide_pq, &d_wpq), d_wpq);
+        if (plan->has_hess) track(upload(t.wide_knot_chunks, &d_wchunks), d_wchunks);
+    }
     if (t.packed_ok) {
         track(upload(core_pillars, &d_core), d_core);
         track(upload(t.knot_class, &d_class), d_class);
@@ -479,9 +494,12 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     d.packed_ok = (t.packed_ok && t.P % 2 == 0) ? 1 : 0;   // as in adr_curve_upload
     d.Pc = t.Pc; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Kcore = t.Kcore; d.n_mini = t.n_mini;
     d.knot_class = d_class; d.core_pillars = d_core; d.lcc_pq = d_lccpq;
+    d.wide_nch = wide ? t.wide_nch : 0; d.wide_pq = d_wpq; d.dpv_global = dpv_global ? 1 : 0;
 
     adr::CurveDev& c = plan->shared;
-    c.K = t.K; c.Kc = t.Kc; c.P = t.P; c.method = interp_method; c.T = 1; c.tile_i = c.tile_j = 0;
+    c.K = t.K; c.Kc = t.Kc; c.P = t.P; c.method = interp_method; c.T = t.T; c.tile_i = c.tile_j = 0;
+    c.wide_nch = d.wide_nch; c.wide_ent = d_went; c.wide_store_map = d_wsmap; c.wide_pos = d_wpos; c.wide_order = d_worder;
+    c.wide_knot_chunks = d_wchunks;
     c.x = d_x; c.inv_x = d_invx; c.first_of = d_first; c.compact_of = d_comp; c.lc_block_mask = d_lcmask;
     c.lut = d_lut; c.n_lut = static_cast<int>(t.lut.size() / 2);
     c.packed_ok = d.packed_ok;
@@ -542,8 +560,15 @@ int adr_curve_set_build(adr_ctx* ctx, const adr_curve_plan* plan, int n_scen, co
     set->hess = hs ? static_cast<double*>(alloc(sizeof(double) * S * K * P * P, false)) : nullptr;
     adr::CurvePackOut po{};
     po.log_df = static_cast<double*>(alloc(sizeof(double) * S * Kc, false));
-    po.lj = static_cast<double*>(alloc(sizeof(double) * S * Kc * adr::kPillarPad, false));
-    po.lc_lanes = hs ? static_cast<double*>(alloc(sizeof(double) * S * Kc * 64 * adr::kGammaPerLane, false)) : nullptr;
+    const bool wide = plan->dev.wide_nch > 0;
+    const size_t wrow = static_cast<size_t>(plan->dev.wide_nch) * adr::kWideChunk;
+    if (wide) {
+        po.lj64 = static_cast<double*>(alloc(sizeof(double) * S * Kc * adr::kWidePad, false));
+        po.lcflat = hs ? static_cast<double*>(alloc(sizeof(double) * S * Kc * wrow, true)) : nullptr;
+    } else {
+        po.lj = static_cast<double*>(alloc(sizeof(double) * S * Kc * adr::kPillarPad, false));
+        po.lc_lanes = hs ? static_cast<double*>(alloc(sizeof(double) * S * Kc * 64 * adr::kGammaPerLane, false)) : nullptr;
+    }
     const size_t ljc_n = static_cast<size_t>(t.Kcore + 1) * t.pc_pad, lcc_n = static_cast<size_t>(t.Kcore + 1) * (t.Ec + 1);
     if (packed) {
         po.ljc = static_cast<double*>(alloc(sizeof(double) * S * ljc_n, true));
@@ -551,17 +576,19 @@ int adr_curve_set_build(adr_ctx* ctx, const adr_curve_plan* plan, int n_scen, co
         po.mini = static_cast<adr::MiniKnot*>(alloc(sizeof(adr::MiniKnot) * S * std::max(1, t.n_mini), false));
     }
     // scratch of the scan's second-derivative state; released once the build has run
-    double* d_scratch = nullptr;
+    double *d_scratch = nullptr, *d_dpv = nullptr;
     if (hs && e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_scratch), sizeof(double) * S * K * P * P);
+    if (plan->dev.dpv_global && e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_dpv), sizeof(double) * S * K * P);
     if (e == hipSuccess) e = hipMemcpyAsync(d_rates, rates, sizeof(double) * S * P, hipMemcpyHostToDevice, ctx->stream);
     if (packed && t.n_mini > 0)
         for (size_t s = 0; s < S && e == hipSuccess; ++s)   // pillar / entry fields of the short-end records
             e = hipMemcpyAsync(po.mini + s * t.n_mini, t.mini.data(), sizeof(adr::MiniKnot) * t.n_mini,
                                hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
-        e = adr::launch_curve_build(plan->dev, n_scen, d_rates, set->dfs, set->jac, set->hess, d_scratch, po, ctx->stream);
+        e = adr::launch_curve_build(plan->dev, n_scen, d_rates, set->dfs, set->jac, set->hess, d_scratch, d_dpv, po, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (d_scratch) hipFree(d_scratch);
+    if (d_dpv) hipFree(d_dpv);
     if (e != hipSuccess) { adr_free_curve_set(set); return fail_hip(e, "adr_curve_set_build"); }
 
     set->curves.resize(S);
@@ -570,8 +597,13 @@ int adr_curve_set_build(adr_ctx* ctx, const adr_curve_plan* plan, int n_scen, co
         c.ctx = ctx;
         c.dev = plan->shared;
         c.dev.log_df = po.log_df + s * Kc;
-        c.dev.lj = po.lj + s * Kc * adr::kPillarPad;
-        c.dev.lc_lanes = hs ? po.lc_lanes + s * Kc * 64 * adr::kGammaPerLane : nullptr;
+        if (wide) {
+            c.dev.lj64 = po.lj64 + s * Kc * adr::kWidePad;
+            c.dev.lcflat = hs ? po.lcflat + s * Kc * wrow : nullptr;
+        } else {
+            c.dev.lj = po.lj + s * Kc * adr::kPillarPad;
+            c.dev.lc_lanes = hs ? po.lc_lanes + s * Kc * 64 * adr::kGammaPerLane : nullptr;
+        }
         if (packed) {
             c.dev.ljc = po.ljc + s * ljc_n;
             c.dev.lcc = hs ? po.lcc + s * lcc_n : nullptr;
@@ -1034,7 +1066,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         return fail(ADR_ERR_INVALID, "adr_price: curve/trades were uploaded through another ctx");
     const bool want_gamma = (req_mask & ADR_REQ_GAMMA) != 0;
     const bool want_delta = want_gamma || (req_mask & ADR_REQ_DELTA) != 0;
-    if (want_gamma && !curve->dev.lc_lanes)
+    if (want_gamma && !curve->dev.lc_lanes && !curve->dev.lcflat)
         return fail(ADR_ERR_INVALID, "adr_price: GAMMA requested but the curve was uploaded without hess");
     hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
     const int P = curve->dev.P;

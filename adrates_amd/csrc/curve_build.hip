@@ -16,10 +16,12 @@
 // libm `log`).
 //
 // bootstrap_kernel: one 256-thread block per scenario walks the K knots in order (a knot's predecessor is
-// an earlier knot); PV01 and its gradient stay in LDS, the K x P x P second-derivative state goes through
-// a scratch buffer in HBM/L2 (8 KB per knot); thread t owns entries t, t+256, ... of the P x P matrices.
+// an earlier knot); PV01 and its gradient stay in LDS (or, when K x P doubles exceed it - a 64-pillar grid has
+// 1 242 knots -, go through a second scratch buffer), the K x P x P second-derivative state goes through
+// a scratch buffer in HBM/L2 (8 KB per knot at 32 pillars); thread t owns entries t, t+256, ... of the P x P matrices.
 // pack_kernel: one block per (reachable knot, scenario) converts to log space and scatters into the dense
-// tables of the general kernel and the packed LDS tables of the fast kernel.
+// tables of the general kernel and the packed LDS tables of the fast kernel - or, for 33-64 pillars, into the
+// wide layout's tables (64-wide Jacobian rows, convexity rows on the packed triangle).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,16 +35,18 @@ constexpr int kBuildThreads = 256;
 
 __global__ __launch_bounds__(kBuildThreads) void bootstrap_kernel(CurveBuildPlanDev plan, const double* rates,
                                                                  double* dfs_out, double* jac_out, double* hess_out,
-                                                                 double* d2pv_scratch) {
+                                                                 double* d2pv_scratch, double* dpv_scratch) {
 #pragma clang fp contract(off)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int K = plan.K, P = plan.P, PP = P * P;
-    double* s_pv = reinterpret_cast<double*>(smem_raw);   // [K]
-    double* s_dpv = s_pv + K;                              // [K][P]
-    double* s_dd = s_dpv + static_cast<size_t>(K) * P;     // [32] gradient of the current knot
-    double* s_cross = s_dd + kPillarPad;                   // [32]
-
     const int scen = blockIdx.x;
+    double* s_pv = reinterpret_cast<double*>(smem_raw);   // [K]
+    double* s_dd = s_pv + K;                               // [64] gradient of the current knot
+    double* s_cross = s_dd + kWidePad;                     // [64]
+    // [K][P] PV01 gradients: in LDS, or in this scenario's slice of the scratch (same-block writes and reads around the
+    // barriers below, as for the second-derivative state)
+    double* s_dpv = plan.dpv_global ? dpv_scratch + static_cast<size_t>(scen) * K * P : s_cross + kWidePad;
+
     const double* r_s = rates + static_cast<size_t>(scen) * P;
     double* dfs = dfs_out + static_cast<size_t>(scen) * K;
     double* jac = jac_out + static_cast<size_t>(scen) * K * P;
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(kBuildThreads) void pack_kernel(CurveBuildPlanDev p
                                                             const double* jac_in, const double* hess_in,
                                                             CurvePackOut out) {
 #pragma clang fp contract(off)
-    __shared__ double s_lj[kPillarPad];
+    __shared__ double s_lj[kWidePad];
     const int K = plan.K, P = plan.P, PP = P * P, Kc = plan.Kc;
     const int c = blockIdx.x, scen = blockIdx.y, t = threadIdx.x;
     const int k = plan.knot_index[c];
@@ -99,12 +103,25 @@ __global__ __launch_bounds__(kBuildThreads) void pack_kernel(CurveBuildPlanDev p
     const double* jrow = jac_in + (static_cast<size_t>(scen) * K + k) * P;
     const double* hk = hess_in ? hess_in + (static_cast<size_t>(scen) * K + k) * PP : nullptr;
 
-    if (t < kPillarPad) s_lj[t] = t < P ? jrow[t] / d : 0.0;
+    if (t < kWidePad) s_lj[t] = t < P ? jrow[t] / d : 0.0;
     __syncthreads();
 
     double* log_df = out.log_df + static_cast<size_t>(scen) * Kc;
-    double* lj = out.lj + (static_cast<size_t>(scen) * Kc + c) * kPillarPad;
     if (t == 0) log_df[c] = log(d);
+    if (plan.wide_nch > 0) {      // 33-64 pillars: the wide layout only
+        double* lj64 = out.lj64 + (static_cast<size_t>(scen) * Kc + c) * kWidePad;
+        if (t < kWidePad) lj64[t] = s_lj[t];
+        if (hk) {
+            const int row = plan.wide_nch * kWideChunk;
+            double* dst = out.lcflat + (static_cast<size_t>(scen) * Kc + c) * row;
+            for (int e = t; e < row; e += kBuildThreads) {
+                const int p = plan.wide_pq[2 * e], q = plan.wide_pq[2 * e + 1];
+                if (p != 255) dst[e] = hk[p * P + q] / d - s_lj[p] * s_lj[q];
+            }
+        }
+        return;
+    }
+    double* lj = out.lj + (static_cast<size_t>(scen) * Kc + c) * kPillarPad;
     if (t < kPillarPad) lj[t] = s_lj[t];
 
     const int cls = plan.knot_class ? plan.knot_class[c] : -2;
@@ -146,20 +163,20 @@ __global__ __launch_bounds__(kBuildThreads) void pack_kernel(CurveBuildPlanDev p
 
 }  // namespace
 
-size_t bootstrap_kernel_lds_bytes(int K, int P) {
-    return sizeof(double) * (static_cast<size_t>(K) * (P + 1) + 2 * kPillarPad);
+size_t bootstrap_kernel_lds_bytes(int K, int P, bool dpv_global) {
+    return sizeof(double) * (static_cast<size_t>(K) * (dpv_global ? 1 : P + 1) + 2 * kWidePad);
 }
 
 hipError_t launch_curve_build(const CurveBuildPlanDev& plan, int n_scen, const double* rates_dev, double* dfs,
-                              double* jac, double* hess, double* d2pv_scratch, const CurvePackOut& out,
-                              hipStream_t stream) {
+                              double* jac, double* hess, double* d2pv_scratch, double* dpv_scratch,
+                              const CurvePackOut& out, hipStream_t stream) {
     if (n_scen <= 0) return hipSuccess;
-    const size_t lds = bootstrap_kernel_lds_bytes(plan.K, plan.P);
+    const size_t lds = bootstrap_kernel_lds_bytes(plan.K, plan.P, plan.dpv_global != 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bootstrap_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bootstrap_kernel, dim3(n_scen), dim3(kBuildThreads), lds, stream, plan, rates_dev, dfs, jac,
-                       hess, d2pv_scratch);
+                       hess, d2pv_scratch, dpv_scratch);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(pack_kernel, dim3(plan.Kc, n_scen), dim3(kBuildThreads), 0, stream, plan, dfs, jac, hess, out);

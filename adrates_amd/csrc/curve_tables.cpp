@@ -137,6 +137,12 @@ std::string build_curve_tables(int K, int P, const double* times, const double* 
                 ea[col_off[bq] + aq] = aq; eb[col_off[bq] + aq] = bq;
                 live[col_off[bq] + aq] = aq <= bq;
             }
+        out.wide_pq.assign(static_cast<size_t>(row) * 2, 255);
+        for (int e = 0; e < E; ++e)
+            if (live[e]) {
+                out.wide_pq[2 * e] = static_cast<uint8_t>(out.wide_order[ea[e]]);
+                out.wide_pq[2 * e + 1] = static_cast<uint8_t>(out.wide_order[eb[e]]);
+            }
         out.wide_ent.assign(static_cast<size_t>(nch) * 64, 0u);
         for (int ch = 0; ch < nch; ++ch)
             for (int lane = 0; lane < 64; ++lane) {

@@ -89,6 +89,7 @@ struct CurveTables {
     std::vector<uint32_t> wide_ent;    // [wide_nch][64] the lane's pair: row a | column b << 8 | (entry 0 inside the triangle) << 16 | (entry 1) << 17
     std::vector<double> lcflat;        // [Kc][wide_nch * 128] LC_k on the packed entries, zero beyond the triangle
     std::vector<uint32_t> wide_knot_chunks;   // [Kc] bit c: chunk c of the knot's row has a structural non-zero
+    std::vector<uint8_t> wide_pq;             // [wide_nch * 128][2] pillars of the packed entry, 255 where the slot is padding
     std::vector<uint32_t> wide_store_map;     // [ceil(P * P / 128)][64] packed entry of element 128 band + 2 lane | the next one's << 16
                                               //                         of the row-major P x P matrix, 0xffff beyond it
 

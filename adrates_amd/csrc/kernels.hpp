@@ -217,6 +217,10 @@ struct CurveBuildPlanDev {
     const int16_t* knot_class;    // [Kc]
     const int32_t* core_pillars;  // [Pc]
     const uint8_t* lcc_pq;        // [Ec][2] pillars of the pair at each position of a lcc row
+    // 33-64 pillars: the wide layout of the base curve (curve_tables.hpp); no tiled tables are written
+    int wide_nch;                 // chunks per row of the packed triangle, 0 for P <= 32
+    const uint8_t* wide_pq;       // [wide_nch * 128][2] pillars of the packed entry, 255 where the slot is padding
+    int dpv_global;               // the PV01 gradients go through `dpv_scratch` instead of LDS (K * P doubles do not fit)
 };
 
 struct CurvePackOut {             // every array has a leading scenario axis
@@ -226,12 +230,14 @@ struct CurvePackOut {             // every array has a leading scenario axis
     double* ljc;                  // [S][Kcore + 1][pc_pad], zero-initialised
     double* lcc;                  // [S][Kcore + 1][Ec + 1], zero-initialised, or null
     MiniKnot* mini;               // [S][n_mini], pillar / entry fields pre-filled
+    double* lj64;                 // [S][Kc][64] (wide layout)
+    double* lcflat;               // [S][Kc][wide_nch * 128], zero-initialised, or null
 };
 
-size_t bootstrap_kernel_lds_bytes(int K, int P);
+size_t bootstrap_kernel_lds_bytes(int K, int P, bool dpv_global = false);
 hipError_t launch_curve_build(const CurveBuildPlanDev& plan, int n_scen, const double* rates_dev, double* dfs,
-                              double* jac, double* hess, double* d2pv_scratch, const CurvePackOut& out,
-                              hipStream_t stream);
+                              double* jac, double* hess, double* d2pv_scratch, double* dpv_scratch,
+                              const CurvePackOut& out, hipStream_t stream);
 
 size_t general_kernel_lds_bytes(int K, int Kc, bool two_tiles = false);
 int general_kernel_threads(const CurveDev& cv, bool gamma);          // block size of the variant launch_price_general picks

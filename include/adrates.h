@@ -67,7 +67,8 @@ typedef enum adr_status {
  * whose wide tables exceed the LDS of a CU (several hundred reachable knots), or a curve uploaded with ADR_WIDE_KERNEL=0
  * in the environment, is priced by the general kernel once per pair of 32-pillar tiles instead: 3 launches for GAMMA, 2
  * for DELTA, 1 for VALUE alone.  Odd pillar counts are served by the general kernel as well (the fast kernel stores the
- * [P][P] matrices as 16-byte pairs).  The device curve builder (adr_curve_plan_create) takes at most 32 pillars. */
+ * [P][P] matrices as 16-byte pairs).  The device curve builder (adr_curve_plan_create) takes the same 64: curves it
+ * builds on 33-64 pillars carry the wide layout's tables only. */
 #define ADR_MAX_PILLARS 64
 
 int adr_version(void);

@@ -162,3 +162,47 @@ def test_price_dev_calls_can_be_captured_into_a_hip_graph():
     assert torch.equal(pv, eager[0]) and torch.equal(delta, eager[1]) and torch.equal(agg, eager[2])
     assert float(pv.abs().max()) > 0.0
     trades.close(); grid.close()
+
+
+@pytest.mark.parametrize("P", [40, 64])
+def test_device_bootstrap_of_wide_curves(gpu_ctx, P):
+    """33-64 pillars (the reference has no pillar limit, engine.py:2388-2389): the device builder's knot values and
+    derivatives equal the host builder's bit for bit - at 64 pillars the PV01 gradients of the 1 242-knot grid go through a
+    scratch buffer instead of LDS -, and a built curve (the wide layout's tables only) prices a mixed batch like the same
+    rates uploaded from the host, and like the C oracle."""
+    from oracle import port
+    from .test_gpu_many_pillars import _mixed_batch, many_pillar_quotes
+    from ._parity import assert_batch_parity
+    vd = F.README_VALUE_DT
+    px, tenors = many_pillar_quotes(P)
+    curve = F.gbp_model(vd, px=px, tenors=tenors).curves.GBP_OIS_SONIA
+    base = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    rates = _scenario_rates(curve, 3, seed=P)
+    plan = _native.CurvePlan(gpu_ctx, curve._interp_type.value, base)
+    cset = plan.build(rates)
+    batch = _mixed_batch(vd, 1203, seed=P + 1)
+    dt = _native.DeviceTrades(gpu_ctx, batch)
+    try:
+        for i in range(len(cset)):
+            host = build_engine_curve(list(rates[i]), curve.swap_times, curve.year_fracs)
+            dfs, jac, hess = cset.download(i)
+            assert np.array_equal(dfs, host.dfs)
+            assert np.array_equal(jac, host.jac)
+            assert np.array_equal(hess, host.hess)
+        host = build_engine_curve(list(rates[2]), curve.swap_times, curve.year_fracs)
+        uploaded = _native.DeviceCurve(gpu_ctx, curve._interp_type.value, host.times, host.dfs, host.jac, host.hess)
+        a = _native.price(gpu_ctx, cset[2], dt, aggregate=True)
+        b = _native.price(gpu_ctx, uploaded, dt, aggregate=True)
+        ref = port.price(curve._interp_type.value, host.times, host.dfs, host.jac, host.hess, batch)
+        assert_batch_parity(a, ref, batch.notional)
+        for key in ("pv", "delta", "gamma", "agg_gamma"):
+            scale = np.max(np.abs(b[key])) + 1e-300
+            assert np.max(np.abs(a[key] - b[key])) <= 1e-13 * scale, key      # tables differ by the libm log only
+        only_d = _native.price(gpu_ctx, cset[1], dt, want_gamma=False)
+        host1 = build_engine_curve(list(rates[1]), curve.swap_times, curve.year_fracs)
+        ref1 = port.price(curve._interp_type.value, host1.times, host1.dfs, host1.jac, host1.hess, batch)
+        assert_batch_parity(only_d, dict(pv=ref1["pv"], delta=ref1["delta"]), batch.notional)
+    finally:
+        dt.close()
+        cset.close()
+        plan.close()
