@@ -59,6 +59,11 @@ _SIGNATURES = {
     "adr_allreduce_agg": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "adr_curve_df": (C.c_int, [_vp, _vp, C.c_int64, _dp, _dp]),
     "adr_curve_df_dev": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "adr_leg_counts_host": (C.c_int, [C.c_int64, _i64p, _i64p, _i64p, _i64p]),
+    "adr_leg_times_host": (C.c_int, [C.c_int64, _i64p, _i64p, _i64p, _i64p, C.c_int, C.c_int, _dp, C.c_int64, C.c_double,
+                                     _i64p, _dp, _dp, _dp, _dp, C.POINTER(C.c_uint8)]),
+    "adr_xccy_assemble_host": (C.c_int, [C.c_int64, _i64p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp,
+                                         C.POINTER(C.c_uint8), _i64p, _dp, _dp, _dp, _dp, _i64p, _dp, _dp, _dp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -367,6 +372,55 @@ def curve_layout_host(times, dfs, jac, hess=None):
             "mini_knots", "lds_bytes", "general_lds_bytes", "general_lds_rows", "core_slots_per_lane", "hub_layout",
             "wide_chunks", "wide_lds_bytes", "wide_max_knot_chunks", "reserved")
     return dict(zip(keys, (int(v) for v in info)))
+
+
+def leg_times_host(effective, termination, months_per_period, payment_lag, bd_value, weekend_calendar, denominator,
+                   value_serial, payment_denominator=None):
+    """Coupon schedules of many legs (adr_leg_counts_host + adr_leg_times_host; threads on the host, no GPU):
+    ``(off, tp, ts, te, alpha, plain)`` - CSR offsets over the coupons, payment / accrual start / accrual end times as year
+    fractions from ``value_serial``, accrual fractions, and the mask of legs with strictly increasing dates."""
+    i64 = lambda a, n: np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.int64), (n,)))
+    eff = np.ascontiguousarray(effective, dtype=np.int64)
+    n = eff.shape[0]
+    term, mpp, lag = i64(termination, n), i64(months_per_period, n), i64(payment_lag, n)
+    den = np.ascontiguousarray(np.broadcast_to(np.asarray(denominator, dtype=np.float64), (n,)))
+    counts = np.empty(n, dtype=np.int64)
+    lib = load()
+    _check(lib.adr_leg_counts_host(n, _ptr(eff, _i64p), _ptr(term, _i64p), _ptr(mpp, _i64p), _ptr(counts, _i64p)),
+           "adr_leg_counts_host")
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=off[1:])
+    m = int(off[-1])
+    tp, ts, te, al = (np.empty(m) for _ in range(4))
+    plain = np.empty(n, dtype=np.uint8)
+    _check(lib.adr_leg_times_host(n, _ptr(eff, _i64p), _ptr(term, _i64p), _ptr(mpp, _i64p), _ptr(lag, _i64p), int(bd_value),
+                                  1 if weekend_calendar else 0, _ptr(den), int(value_serial),
+                                  float(payment_denominator or 0.0), _ptr(off, _i64p), _ptr(tp), _ptr(ts), _ptr(te), _ptr(al),
+                                  _ptr(plain, C.POINTER(C.c_uint8))), "adr_leg_times_host")
+    return off, tp, ts, te, al, plain.astype(bool)
+
+
+def xccy_assemble_host(for_off, tp_x, ts, te, alpha, disc, growth, for_n, for_spread, for_sign, spot, exch_t, exch_on,
+                       pv_const):
+    """Foreign-leg batches of a cross-currency book (adr_xccy_assemble_host): ``(rates_off, rates_ts, rates_te, rates_alpha,
+    rates_weight, flows_off, flows_tp, flows_pay, pv_const)``; ``pv_const`` comes in with the domestic constants."""
+    for_off = np.ascontiguousarray(for_off, dtype=np.int64)
+    n, m = for_off.shape[0] - 1, int(for_off[-1])
+    cols = [_f64(a) for a in (tp_x, ts, te, alpha, disc, growth, for_n, for_spread, for_sign)]
+    exch_t = _f64(exch_t).reshape(-1)
+    exch_on = np.ascontiguousarray(exch_on, dtype=np.uint8)
+    pv = np.array(pv_const, dtype=np.float64)
+    r_off, f_off = np.empty(n + 1, dtype=np.int64), np.empty(n + 1, dtype=np.int64)
+    r_ts, r_te, r_al, r_w = (np.empty(m) for _ in range(4))
+    f_tp, f_pay = np.empty(m + 2 * n), np.empty(m + 2 * n)
+    u8 = C.POINTER(C.c_uint8)
+    _check(load().adr_xccy_assemble_host(n, _ptr(for_off, _i64p), *(_ptr(a) for a in cols), float(spot), _ptr(exch_t),
+                                         _ptr(exch_on, u8), _ptr(r_off, _i64p), _ptr(r_ts), _ptr(r_te), _ptr(r_al), _ptr(r_w),
+                                         _ptr(f_off, _i64p), _ptr(f_tp), _ptr(f_pay), _ptr(pv)), "adr_xccy_assemble_host")
+    if n == 0:
+        r_off[:] = 0; f_off[:] = 0
+    kr, kf = int(r_off[-1]), int(f_off[-1])
+    return r_off, r_ts[:kr], r_te[:kr], r_al[:kr], r_w[:kr], f_off, f_tp[:kf], f_pay[:kf], pv
 
 
 _default_ctx = {}

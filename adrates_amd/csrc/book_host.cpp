@@ -1,0 +1,252 @@
+// Host side of a book's terms -> trade arrays step, on a pool of threads (no GPU involved).
+//
+// adr_leg_counts_host / adr_leg_times_host: the coupon schedules of many swap legs at once - what
+// `Schedule(effective, termination, freq, WEEKEND calendar, bd, BACKWARD)._adjusted_dts` and
+// `SwapFloatLeg.generate_payment_dts` produce per leg in the reference (cavour/utils/schedule.py:163-270,
+// cavour/utils/date.py:597-653, 796-879, cavour/utils/calendar.py:139-253, cavour/trades/rates/swap_float_leg.py:130-186):
+// unadjusted dates backwards from the termination date in whole periods (day of month clamped to the month's length), every
+// date but the first adjusted to a business day, payment dates a number of business days after the accrual ends, times as
+// year fractions on a day count with a fixed denominator.  Dates are Excel serials (>= 1-Mar-1900), as `Date.excel_dt()`.
+// adr_xccy_assemble_host: the foreign-leg batches of a cross-currency book from its coupons and the discount factors the
+// device returned for them (cavour/market/position/engine.py:1640-1712; adrates_amd/market/position/xccy_engine.py).
+//
+// Every floating-point result is ONE IEEE operation on integers converted to double (a difference of serials divided by the
+// denominator), or the same sequence of operations the NumPy route performs, so the two routes agree bit for bit
+// (tests/test_book_native.py).
+#include <algorithm>
+#include <cstdint>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/adrates.h"
+
+int adr_set_error(int status, const std::string& msg);      // capi.hip
+
+namespace {
+
+constexpr int64_t kEpochSerial = 25569;     // Excel serial of 1970-01-01
+constexpr int64_t kMinSerial = 61;          // 1-Mar-1900: below it the Lotus off-by-one applies
+constexpr int kFirstYear = 1900, kLastYear = 2300;
+
+// days since 1970-01-01 of a civil date (proleptic Gregorian), and back
+inline int64_t days_from_civil(int64_t y, int m, int d) {
+    y -= m <= 2;
+    const int64_t era = (y >= 0 ? y : y - 399) / 400;
+    const int64_t yoe = y - era * 400;
+    const int64_t doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+    const int64_t doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+    return era * 146097 + doe - 719468;
+}
+inline void civil_from_days(int64_t z, int64_t& y, int& m, int& d) {
+    z += 719468;
+    const int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+    const int64_t doe = z - era * 146097;
+    const int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+    y = yoe + era * 400;
+    const int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+    const int64_t mp = (5 * doy + 2) / 153;
+    d = static_cast<int>(doy - (153 * mp + 2) / 5 + 1);
+    m = static_cast<int>(mp < 10 ? mp + 3 : mp - 9);
+    y += m <= 2;
+}
+
+inline int month_length(int64_t month_index) {          // months since 0000-01
+    const int64_t y = month_index / 12;
+    const int m = static_cast<int>(month_index % 12) + 1;
+    static const int len[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+    if (m == 2 && (y % 4 == 0) && (y % 100 != 0 || y % 400 == 0)) return 29;
+    return len[m - 1];
+}
+inline bool month_in_range(int64_t month_index) {
+    return month_index >= kFirstYear * 12 + 2 && month_index < (kLastYear + 1) * 12;
+}
+// serial of day min(day, month length) of a month: the clamping of Date._shift_months
+inline int64_t serial_of(int64_t month_index, int day) {
+    const int64_t y = month_index / 12;
+    const int m = static_cast<int>(month_index % 12) + 1;
+    return days_from_civil(y, m, std::min(day, month_length(month_index))) + kEpochSerial;
+}
+inline int weekday(int64_t serial) { return static_cast<int>((serial + 5) % 7); }      // Monday = 0
+inline int64_t roll(int64_t serial, int step) {
+    const int wd = weekday(serial);
+    if (step > 0) return serial + (wd == 5 ? 2 : (wd == 6 ? 1 : 0));
+    return serial - (wd == 5 ? 1 : (wd == 6 ? 2 : 0));
+}
+inline int64_t month_of(int64_t serial) {
+    int64_t y; int m, d;
+    civil_from_days(serial - kEpochSerial, y, m, d);
+    return y * 12 + m - 1;
+}
+// Calendar(WEEKEND).adjust; bd: BusDayAdjustTypes (1 NONE, 2 FOLLOWING, 3 MODIFIED_FOLLOWING, 4 PRECEDING, 5 MODIFIED_PRECEDING)
+inline int64_t adjust(int64_t serial, int bd, bool weekend) {
+    if (!weekend || bd == 1) return serial;
+    if (bd == 2) return roll(serial, +1);
+    if (bd == 4) return roll(serial, -1);
+    const int step = bd == 3 ? +1 : -1;
+    const int64_t rolled = roll(serial, step);
+    return month_of(rolled) != month_of(serial) ? roll(serial, -step) : rolled;
+}
+// Calendar.add_business_days: weekdays only (the NONE calendar skips weekends here too)
+inline int64_t add_business_days(int64_t serial, int64_t num_days) {
+    const int step = num_days >= 0 ? 1 : -1;
+    for (int64_t left = num_days >= 0 ? num_days : -num_days; left > 0; --left) {
+        serial += step;
+        const int wd = weekday(serial);
+        if (step > 0) serial += (wd == 5 ? 2 : (wd == 6 ? 1 : 0));
+        else serial -= (wd == 5 ? 1 : (wd == 6 ? 2 : 0));
+    }
+    return serial;
+}
+
+struct LegShape { int64_t t_idx; int td; int64_t n_flows; };
+
+// number of unadjusted dates termination - k periods that lie after the effective date (schedule_np.backward_schedules)
+inline bool leg_shape(int64_t eff, int64_t term, int64_t mpp, LegShape& s) {
+    int64_t ey, ty; int em, ed, tm, td;
+    civil_from_days(eff - kEpochSerial, ey, em, ed);
+    civil_from_days(term - kEpochSerial, ty, tm, td);
+    const int64_t e_idx = ey * 12 + em - 1, t_idx = ty * 12 + tm - 1;
+    const int64_t gap = t_idx - e_idx;
+    const int64_t whole = gap / mpp;
+    const bool lands = gap % mpp == 0;
+    int64_t n_flows = whole + 1;
+    if (lands) {
+        const int64_t at = t_idx - whole * mpp;
+        if (!month_in_range(at)) return false;
+        n_flows = whole + (std::min(td, month_length(at)) > ed ? 1 : 0);
+    }
+    s.t_idx = t_idx; s.td = td; s.n_flows = n_flows;
+    return month_in_range(t_idx - n_flows * mpp) && month_in_range(t_idx);
+}
+
+template <class Body>
+void parallel_ranges(int64_t n, int64_t grain, Body&& body) {
+    const int n_threads = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(std::thread::hardware_concurrency()), 16, n / grain + 1})));
+    std::vector<std::thread> pool;
+    for (int k = 1; k < n_threads; ++k) pool.emplace_back([&, k] { body(n * k / n_threads, n * (k + 1) / n_threads); });
+    body(0, n / n_threads);
+    for (auto& th : pool) th.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+int adr_leg_counts_host(int64_t n, const int64_t* eff, const int64_t* term, const int64_t* months_per_period,
+                        int64_t* n_coupons) {
+    if (n < 0 || (n > 0 && (!eff || !term || !months_per_period || !n_coupons)))
+        return adr_set_error(ADR_ERR_INVALID, "adr_leg_counts_host: bad count / null array");
+    std::vector<int> bad;
+    std::vector<char> flag(1, 0);
+    char* failed = flag.data();
+    parallel_ranges(n, 8192, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) {
+            LegShape s;
+            if (eff[i] < kMinSerial || term[i] < kMinSerial || months_per_period[i] < 1) { *failed = 1; n_coupons[i] = 0; continue; }
+            if (eff[i] >= term[i]) { *failed = 2; n_coupons[i] = 0; continue; }
+            if (!leg_shape(eff[i], term[i], months_per_period[i], s)) { *failed = 1; n_coupons[i] = 0; continue; }
+            n_coupons[i] = s.n_flows;
+        }
+    });
+    if (*failed == 2) return adr_set_error(ADR_ERR_INVALID, "adr_leg_counts_host: Effective date must be before termination date.");
+    if (*failed) return adr_set_error(ADR_ERR_INVALID, "adr_leg_counts_host: dates before 1-Mar-1900 or after 2300 are not supported");
+    return ADR_OK;
+}
+
+int adr_leg_times_host(int64_t n, const int64_t* eff, const int64_t* term, const int64_t* months_per_period,
+                       const int64_t* payment_lag, int bd_type, int weekend_calendar, const double* denominator,
+                       int64_t value_serial, double payment_denominator, const int64_t* off, double* tp, double* ts,
+                       double* te, double* alpha, uint8_t* plain) {
+    if (n < 0 || (n > 0 && (!eff || !term || !months_per_period || !payment_lag || !denominator || !off || !tp || !ts || !te ||
+                            !alpha || !plain)))
+        return adr_set_error(ADR_ERR_INVALID, "adr_leg_times_host: bad count / null array");
+    if (bd_type < 1 || bd_type > 5) return adr_set_error(ADR_ERR_INVALID, "adr_leg_times_host: Unknown adjustment convention");
+    std::vector<char> flag(1, 0);
+    char* failed = flag.data();
+    const bool weekend = weekend_calendar != 0;
+    parallel_ranges(n, 4096, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) {
+            LegShape s;
+            if (eff[i] < kMinSerial || eff[i] >= term[i] || months_per_period[i] < 1 ||
+                !leg_shape(eff[i], term[i], months_per_period[i], s) || off[i + 1] - off[i] != s.n_flows) { *failed = 1; plain[i] = 0; continue; }
+            const int64_t mpp = months_per_period[i];
+            const double d = denominator[i], dp = payment_denominator > 0.0 ? payment_denominator : d;
+            int64_t prev = eff[i];                       // the previous coupon date: the effective date, never adjusted
+            bool increasing = true;
+            for (int64_t j = 1; j <= s.n_flows; ++j) {
+                const int64_t date = adjust(serial_of(s.t_idx - (s.n_flows - j) * mpp, s.td), bd_type, weekend);
+                increasing = increasing && date > prev;
+                const int64_t pay = add_business_days(date, payment_lag[i]);
+                const int64_t at = off[i] + j - 1;
+                tp[at] = static_cast<double>(pay - value_serial) / dp;
+                ts[at] = static_cast<double>(prev - value_serial) / d;
+                te[at] = static_cast<double>(date - value_serial) / d;
+                alpha[at] = static_cast<double>(date - prev) / d;
+                prev = date;
+            }
+            plain[i] = increasing ? 1 : 0;
+        }
+    });
+    if (*failed) return adr_set_error(ADR_ERR_INVALID, "adr_leg_times_host: a leg's dates are out of range or its offsets do not match adr_leg_counts_host");
+    return ADR_OK;
+}
+
+int adr_xccy_assemble_host(int64_t n, const int64_t* for_off, const double* tp_x, const double* ts, const double* te,
+                           const double* alpha, const double* disc, const double* growth, const double* for_n,
+                           const double* for_spread, const double* for_sign, double spot, const double* exch_t,
+                           const uint8_t* exch_on, int64_t* rates_off, double* rates_ts, double* rates_te,
+                           double* rates_alpha, double* rates_weight, int64_t* flows_off, double* flows_tp,
+                           double* flows_pay, double* pv_const) {
+    if (n < 0 || (n > 0 && (!for_off || !for_n || !for_spread || !for_sign || !exch_t || !exch_on || !rates_off || !flows_off || !pv_const)))
+        return adr_set_error(ADR_ERR_INVALID, "adr_xccy_assemble_host: bad count / null array");
+    if (n == 0) return ADR_OK;
+    // pass 1: how many accruing live coupons (rate ladders) and later flows (coupons paid after the value time, exchanges
+    // after the value time) every swap has
+    rates_off[0] = 0; flows_off[0] = 0;
+    parallel_ranges(n, 8192, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) {
+            int64_t kept = 0, later = 0;
+            for (int64_t j = for_off[i]; j < for_off[i + 1]; ++j) {
+                if (tp_x[j] >= 0.0 && alpha[j] > 0.0) ++kept;
+                if (tp_x[j] > 0.0) ++later;
+            }
+            if (exch_on[i]) later += (exch_t[2 * i] > 0.0) + (exch_t[2 * i + 1] > 0.0);
+            rates_off[i + 1] = kept; flows_off[i + 1] = later;
+        }
+    });
+    for (int64_t i = 0; i < n; ++i) { rates_off[i + 1] += rates_off[i]; flows_off[i + 1] += flows_off[i]; }
+    // pass 2: fill
+    parallel_ranges(n, 8192, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) {
+            int64_t kr = rates_off[i], kf = flows_off[i];
+            double pv = pv_const[i];
+            for (int64_t j = for_off[i]; j < for_off[i + 1]; ++j) {
+                const bool accrues = alpha[j] > 0.0, live = tp_x[j] >= 0.0;
+                const double fwd = accrues ? (growth[j] - 1.0) / alpha[j] : 0.0;
+                const double amount = (fwd + for_spread[i]) * alpha[j] * for_n[i];
+                if (live && accrues) {
+                    rates_ts[kr] = ts[j]; rates_te[kr] = te[j]; rates_alpha[kr] = alpha[j]; rates_weight[kr] = disc[j];
+                    ++kr;
+                }
+                if (live && tp_x[j] == 0.0) pv += (for_sign[i] * amount) / spot;
+                if (tp_x[j] > 0.0) { flows_tp[kf] = tp_x[j]; flows_pay[kf] = amount; ++kf; }
+            }
+            double e_const = 0.0;
+            if (exch_on[i]) {
+                const double amounts[2] = {-for_n[i], for_n[i]};
+                double c2[2] = {0.0, 0.0};
+                for (int q = 0; q < 2; ++q) {
+                    const double t = exch_t[2 * i + q];
+                    if (t > 0.0) { flows_tp[kf] = t; flows_pay[kf] = amounts[q]; ++kf; }
+                    if (t == 0.0) c2[q] = for_sign[i] * amounts[q] / spot;
+                }
+                e_const = c2[0] + c2[1];
+            }
+            pv_const[i] = pv + e_const;
+        }
+    });
+    return ADR_OK;
+}
+
+}  // extern "C"

@@ -128,6 +128,9 @@ struct adr_trades {
     std::vector<void*> allocations;
 };
 
+// the host-only translation units (book_host.cpp) report errors through the same per-thread message
+int adr_set_error(int status, const std::string& msg) { return fail(status, msg); }
+
 extern "C" {
 
 int adr_version(void) { return 100; }

@@ -273,6 +273,36 @@ def compile_xccy(raw: RawXccy, spot, df_x, df_f):
     domestic = TradeBatch(dfix_off, raw.dom_off, dfix_tp, dfix_pay, raw.dom_tp, raw.dom_ts, raw.dom_te, raw.dom_al,
                           raw.dom_n, raw.dom_spread, raw.dom_sign, raw.dom_sign)
 
+    # foreign coupons, all swaps at once: forwards off the foreign OIS grid, discount factors off the XCCY knots (device
+    # lookups), then the two foreign batches in one native pass over the coupons (`adr_xccy_assemble_host`;
+    # `compile_xccy_np` is the array form it replaces, kept as the checker of tests/test_book_native.py)
+    tp_x, ts, te, al = raw.for_tpx, raw.for_ts, raw.for_te, raw.for_al
+    c = df_x(tp_x) / df_x(0.0)                                          # relative to the value time
+    growth = df_f(ts) / df_f(te)
+    (kept_off, k_ts, k_te, k_al, k_c, fix_off, flow_tp, flow_pay, pv_const) = _native.xccy_assemble_host(
+        raw.for_off, tp_x, ts, te, al, c, growth, raw.for_n, raw.for_spread, raw.for_sign, spot, raw.for_exch_t,
+        raw.for_exch, pv_const)
+    foreign_rates = TradeBatch(np.zeros(n + 1, dtype=np.int64), kept_off, none, none, np.zeros(k_ts.shape[0]),
+                               k_ts, k_te, k_al, raw.for_n, zeros_n, raw.for_sign, raw.for_sign, flt_weight=k_c)
+    foreign_flows = TradeBatch(fix_off, np.zeros(n + 1, dtype=np.int64), flow_tp, flow_pay, none, none, none, none,
+                               raw.for_n, zeros_n, raw.for_sign, raw.for_sign)
+    return domestic, foreign_rates, foreign_flows, pv_const
+
+
+def compile_xccy_np(raw: RawXccy, spot, df_x, df_f):
+    """`compile_xccy` on NumPy arrays alone (the form the native pass replaces; the checker of the tests).
+    The three trade batches of the assembly above, plus the per-swap PV of the flows dated at the value time.
+
+    ``df_x(t)`` / ``df_f(t)``: discount factors off the XCCY curve and off the foreign OIS curve's engine grid at
+    arrays of times - on the product path the device lookups of `adr_curve_df` (the reference evaluates them inside
+    its leg function, engine.py:1640-1712).  Returns ``(domestic, foreign_rates, foreign_flows, pv_const)``;
+    ``foreign_rates`` carries `flt_weight`."""
+    n = raw.n
+    zeros_n, none = np.zeros(n), np.zeros(0)
+    dfix_off, dfix_tp, dfix_pay, pv_const = _exchange_flows(raw.dom_exch_t, raw.dom_n, raw.dom_exch, raw.dom_sign, 1.0)
+    domestic = TradeBatch(dfix_off, raw.dom_off, dfix_tp, dfix_pay, raw.dom_tp, raw.dom_ts, raw.dom_te, raw.dom_al,
+                          raw.dom_n, raw.dom_spread, raw.dom_sign, raw.dom_sign)
+
     # foreign coupons, all swaps at once: forwards off the foreign OIS grid, discount factors off the XCCY knots
     off = raw.for_off
     owner = np.repeat(np.arange(n), np.diff(off))

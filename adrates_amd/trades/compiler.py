@@ -130,6 +130,8 @@ def _column(value, n, kind):
     if kind == "bool":
         return np.broadcast_to(np.asarray(value, dtype=bool), (n,)).copy() if not seq else np.asarray(value, dtype=bool)
     if kind == "date":     # -> Excel serials
+        if isinstance(value, np.ndarray) and value.dtype.kind in "iu":       # serials already: no per-element pass
+            return value.astype(np.int64, copy=False)
         if seq:
             return np.array([v if isinstance(v, (int, np.integer)) else int(v.excel_dt()) for v in value], dtype=np.int64)
         return np.full(n, value if isinstance(value, (int, np.integer)) else int(value.excel_dt()), dtype=np.int64)

@@ -178,6 +178,19 @@ def backward_schedules(effective, termination, months_per_period, bd_type, weeke
 
 def leg_times(effective, termination, months_per_period, payment_lag, bd_type, weekend_calendar, denominator,
               value_serial, payment_denominator=None):
+    """`leg_times_np` on the library's host threads (`adr_leg_counts_host` / `adr_leg_times_host`, csrc/book_host.cpp):
+    the same arrays, bit for bit (tests/test_book_native.py), without the whole-book temporaries - 100 000 swaps x 2 legs
+    in a few milliseconds instead of ~0.1 s."""
+    from .. import _native
+    eff = np.asarray(effective, dtype=np.int64)
+    if eff.size and (eff >= np.asarray(termination, dtype=np.int64)).any():
+        raise LibError("Effective date must be before termination date.")
+    return _native.leg_times_host(eff, termination, months_per_period, payment_lag, bd_type.value, weekend_calendar,
+                                  denominator, value_serial, payment_denominator)
+
+
+def leg_times_np(effective, termination, months_per_period, payment_lag, bd_type, weekend_calendar, denominator,
+                 value_serial, payment_denominator=None):
     """The arrays `SwapFixedLeg.generate_payments` / `SwapFloatLeg.generate_payment_dts` produce, for many legs on a day
     count with a fixed denominator (ACT/365F, ACT/360, SIMPLE): CSR offsets over the coupons, payment / accrual start /
     accrual end times as year fractions from ``value_serial`` (``payment_denominator``: another day count's denominator

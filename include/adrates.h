@@ -125,6 +125,45 @@ int adr_curve_layout_host(int K, int P, const double* times, const double* dfs,
                           const double* jac, const double* hess, int64_t* info);
 
 /*
+ * Book compilers, host side (multi-threaded, no GPU): the coupon schedules of many swap legs at once, and the foreign-leg
+ * batches of a cross-currency book.  They replace the per-swap Python the reference runs before its leg functions:
+ * Schedule._generate (cavour/utils/schedule.py:163-270) + Calendar.adjust / add_business_days
+ * (cavour/utils/calendar.py:139-253) + SwapFloatLeg.generate_payment_dts (cavour/trades/rates/swap_float_leg.py:130-186),
+ * and the coupon loop of Engine._compute_xccy (cavour/market/position/engine.py:1486-1578, 1640-1712).
+ *
+ * Dates are Excel serials (Date.excel_dt(), >= 1-Mar-1900).  Conventions covered: BACKWARD date generation without
+ * end-of-month rolling, the WEEKEND calendar (weekend_calendar 0: NONE), bd_type = BusDayAdjustTypes value (1 NONE,
+ * 2 FOLLOWING, 3 MODIFIED_FOLLOWING, 4 PRECEDING, 5 MODIFIED_PRECEDING), payment lags in business days, day counts with a
+ * fixed denominator.  adr_leg_counts_host: coupons per leg.  adr_leg_times_host: with off = the exclusive prefix sums of
+ * those counts ([n + 1]), payment / accrual start / accrual end times as year fractions from value_serial (payment times on
+ * payment_denominator when > 0, else on the leg's own), accrual fractions, and plain[i] = 1 when the leg's dates are
+ * strictly increasing (0: the reference's schedule de-duplication applies - the entries are then not its schedule and the
+ * caller takes the object route for that leg).
+ */
+int adr_leg_counts_host(int64_t n, const int64_t* eff, const int64_t* term, const int64_t* months_per_period,
+                        int64_t* n_coupons);
+int adr_leg_times_host(int64_t n, const int64_t* eff, const int64_t* term, const int64_t* months_per_period,
+                       const int64_t* payment_lag, int bd_type, int weekend_calendar, const double* denominator,
+                       int64_t value_serial, double payment_denominator, const int64_t* off, double* tp, double* ts,
+                       double* te, double* alpha, uint8_t* plain);
+/*
+ * Foreign leg of n cross-currency basis swaps (CSR for_off over the coupons: payment times on the XCCY curve's day count,
+ * accrual start / end times, accrual fractions) given, per coupon, disc = D_x(tp) / D_x(0) off the XCCY curve and
+ * growth = D_f(ts) / D_f(te) off the foreign OIS grid (adr_curve_df): (1) the rate-ladder batch - every live accruing coupon
+ * with its discount factor as notional multiplier (adr_trades_upload_weighted's flt_weight) -, (2) the fixed flows
+ * N (fwd + spread) alpha at tp > 0 followed by the notional exchanges (exch_t [n][2] effective / maturity times, exch_on [n])
+ * at t > 0, and (3) pv_const [n] (in: the domestic constants; out: + flows dated at the value time, in domestic currency).
+ * Output arrays are sized by the caller for every coupon (rates_*: for_off[n]; flows_*: for_off[n] + 2 n); the offsets
+ * ([n + 1]) say what was filled.
+ */
+int adr_xccy_assemble_host(int64_t n, const int64_t* for_off, const double* tp_x, const double* ts, const double* te,
+                           const double* alpha, const double* disc, const double* growth, const double* for_n,
+                           const double* for_spread, const double* for_sign, double spot, const double* exch_t,
+                           const uint8_t* exch_on, int64_t* rates_off, double* rates_ts, double* rates_te,
+                           double* rates_alpha, double* rates_weight, int64_t* flows_off, double* flows_tp,
+                           double* flows_pay, double* pv_const);
+
+/*
  * Curve builder on the device, for batches of par-rate scenarios on one knot grid.  It replaces
  * Engine.build_curve_ad (engine.py:2246-2360: the lax.scan d = (1 - r PV01_prev) / (1 + r acc)) and the
  * jacrev / hessian of Engine._cached_curve (engine.py:2388-2389) for the case the reference handles by
