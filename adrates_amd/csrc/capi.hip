@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <functional>
+#include <queue>
 #include <string>
 #include <thread>
 #include <vector>
@@ -877,38 +879,42 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         std::stable_sort(list.begin(), list.end(), [&](int32_t a, int32_t b) { return rows_of(a) > rows_of(b); });
         const int G = adr::fast_kernel_groups();
         const int64_t W = static_cast<int64_t>(blocks) * waves_per_block;
-        std::vector<std::vector<std::vector<Piece>>> column(static_cast<size_t>(W));   // [wave][round][group]
-        std::vector<int64_t> height(static_cast<size_t>(W), 0);
-        for (size_t i = 0; i < list.size(); i += static_cast<size_t>(G)) {
-            const size_t w = static_cast<size_t>(std::min_element(height.begin(), height.end()) - height.begin());
-            const int64_t len = rows_of(list[i]);                       // the longest of the pair (sorted)
-            for (int64_t j = 0; j < len; ++j) {
-                std::vector<Piece> unit(static_cast<size_t>(G), Piece{-1, 0, j + 1 < len});
-                for (int g = 0; g < G && i + static_cast<size_t>(g) < list.size(); ++g) {
-                    const int64_t t = list[i + static_cast<size_t>(g)];
-                    if (j < rows_of(t)) unit[static_cast<size_t>(g)].trade = t;
-                    unit[static_cast<size_t>(g)].first = j * adr::kRowSlots;
-                }
-                // results are written after the chain's last row, by the row's trade index: an empty
-                // padding row of the shorter trade still has to carry that index
-                for (int g = 0; g < G && i + static_cast<size_t>(g) < list.size(); ++g)
-                    if (unit[static_cast<size_t>(g)].trade < 0 && j + 1 == len)
-                        unit[static_cast<size_t>(g)] = Piece{list[i + static_cast<size_t>(g)], j * adr::kRowSlots, false};
-                column[w].push_back(unit);
-            }
-            height[w] += len;
+        // pass 1: the wave column and first round of every pair - always the shortest column, the lowest-numbered one among
+        // equals (a heap of (height, column): with tens of thousands of pairs and thousands of columns a linear search
+        // per pair was most of the upload's host time for books of long legs)
+        const size_t n_pairs = (list.size() + static_cast<size_t>(G) - 1) / static_cast<size_t>(G);
+        std::vector<int64_t> pair_col(n_pairs), pair_round(n_pairs);
+        typedef std::pair<int64_t, int64_t> HW;                                  // (height, column)
+        std::priority_queue<HW, std::vector<HW>, std::greater<HW>> heap;
+        for (int64_t w = 0; w < W; ++w) heap.push(HW(0, w));
+        int64_t rounds = 0;
+        for (size_t pi = 0; pi < n_pairs; ++pi) {
+            const HW top = heap.top();
+            heap.pop();
+            const int64_t len = rows_of(list[pi * static_cast<size_t>(G)]);     // the longest of the pair (sorted)
+            pair_col[pi] = top.second; pair_round[pi] = top.first;
+            heap.push(HW(top.first + len, top.second));
+            rounds = std::max(rounds, top.first + len);
         }
-        const int64_t rounds = *std::max_element(height.begin(), height.end());
+        // pass 2: the rows
         const size_t total = static_cast<size_t>(rounds * W * G);
         std::vector<int32_t> p_trade(total, -1), p_first(total, 0);
         std::vector<uint8_t> p_more(total, 0);
-        for (int64_t w = 0; w < W; ++w)
-            for (size_t r = 0; r < column[static_cast<size_t>(w)].size(); ++r)
+        for (size_t pi = 0; pi < n_pairs; ++pi) {
+            const size_t i = pi * static_cast<size_t>(G);
+            const int64_t len = rows_of(list[i]);
+            for (int64_t j = 0; j < len; ++j)
                 for (int g = 0; g < G; ++g) {
-                    const Piece& pc = column[static_cast<size_t>(w)][r][static_cast<size_t>(g)];
-                    const size_t at = static_cast<size_t>((static_cast<int64_t>(r) * W + w) * G + g);
-                    p_trade[at] = static_cast<int32_t>(pc.trade); p_first[at] = static_cast<int32_t>(pc.first); p_more[at] = pc.more ? 1 : 0;
+                    const size_t at = static_cast<size_t>(((pair_round[pi] + j) * W + pair_col[pi]) * G + g);
+                    p_more[at] = j + 1 < len ? 1 : 0;
+                    if (i + static_cast<size_t>(g) >= list.size()) continue;          // an odd trade out: the slot stays empty
+                    const int64_t t = list[i + static_cast<size_t>(g)];
+                    p_first[at] = static_cast<int32_t>(j * adr::kRowSlots);
+                    // results are written after the chain's last row, by the row's trade index: an empty padding row of
+                    // the shorter trade still has to carry that index
+                    if (j < rows_of(t) || j + 1 == len) p_trade[at] = static_cast<int32_t>(t);
                 }
+        }
         build_rows(std::move(p_trade), std::move(p_first), std::move(p_more), dst, lagged);
         dst.rows_chained = 1;
     };

@@ -277,8 +277,11 @@ def compile_xccy(raw: RawXccy, spot, df_x, df_f):
     # lookups), then the two foreign batches in one native pass over the coupons (`adr_xccy_assemble_host`;
     # `compile_xccy_np` is the array form it replaces, kept as the checker of tests/test_book_native.py)
     tp_x, ts, te, al = raw.for_tpx, raw.for_ts, raw.for_te, raw.for_al
-    c = df_x(tp_x) / df_x(0.0)                                          # relative to the value time
-    growth = df_f(ts) / df_f(te)
+    m = tp_x.shape[0]
+    dx = df_x(np.concatenate((tp_x, [0.0])))                           # one device round trip per curve
+    c = dx[:m] / dx[m]                                                  # relative to the value time
+    df2 = df_f(np.concatenate((ts, te)))
+    growth = df2[:m] / df2[m:]
     (kept_off, k_ts, k_te, k_al, k_c, fix_off, flow_tp, flow_pay, pv_const) = _native.xccy_assemble_host(
         raw.for_off, tp_x, ts, te, al, c, growth, raw.for_n, raw.for_spread, raw.for_sign, spot, raw.for_exch_t,
         raw.for_exch, pv_const)
