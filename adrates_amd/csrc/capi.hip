@@ -1101,13 +1101,13 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         const int threads = adr::wide_kernel_threads(curve->dev.wide_nch, want_gamma), waves = threads / 64;
         const int64_t need = (n + waves - 1) / waves;
         const int blocks = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * adr::wide_kernel_blocks_per_cu(lds, threads)));
-        if (static_cast<size_t>(blocks) * adr::kAggWide > static_cast<size_t>(ctx->max_blocks) * adr::kAggStride)
+        if (static_cast<size_t>(blocks) * adr::wide_partial_doubles(curve->dev.wide_nch) > static_cast<size_t>(ctx->max_blocks) * adr::kAggStride)
             return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
         adr::TradesDev all = trades->dev;
         all.list = nullptr; all.n_list = n;
         o.block_partials = agg_dev ? ctx->partials : nullptr;
         ADR_HIP(adr::launch_price_wide(curve->dev, all, o, want_delta, want_gamma, blocks, stream));
-        if (agg_dev) ADR_HIP(adr::launch_reduce_wide(ctx->partials, blocks, P, want_delta, want_gamma, agg_dev, stream));
+        if (agg_dev) ADR_HIP(adr::launch_reduce_wide(curve->dev, ctx->partials, blocks, want_delta, want_gamma, agg_dev, stream));
         return ADR_OK;
     }
     if (curve->dev.T > 1) {

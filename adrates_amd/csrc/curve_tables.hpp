@@ -25,7 +25,6 @@ constexpr int kMaxPillars = 64;                                 // more than 32 
 constexpr int kWidePad = 64;                                    // wide kernel: ladders padded to one wavefront of pillars
 constexpr int kWideChunk = 128;                                 // ... packed gamma entries per chunk: two per lane
 constexpr int kWideMaxChunks = 17;                              // ... 64 * 65 / 2 = 2080 packed entries
-constexpr int kAggWide = 1 + kWidePad + kWidePad * kWidePad;    // ... padded [pv, delta, gamma] record of a block partial
 // chunks per row of the packed triangle (columns padded to an even length), rounded up to the kernel variants
 // (7: up to 41 pillars, 10: up to 49, 17: up to 64)
 inline int wide_chunks(int P) {

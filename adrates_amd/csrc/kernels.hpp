@@ -256,9 +256,10 @@ int wide_kernel_threads(int nch, bool gamma);
 int wide_kernel_blocks_per_cu(size_t lds_bytes, int threads);
 hipError_t launch_price_wide(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                              bool want_gamma, int n_blocks, hipStream_t stream);
-// block partials of the wide kernel ([n_blocks][kAggWide]) -> agg[1 + P + P*P], fixed order
-hipError_t launch_reduce_wide(const double* partials, int n_blocks, int P, bool has_delta, bool has_gamma, double* agg,
-                              hipStream_t stream);
+// block partials of the wide kernel ([n_blocks][wide_partial_doubles(nch)]) -> agg[1 + P + P*P], fixed order
+int wide_partial_doubles(int nch);
+hipError_t launch_reduce_wide(const CurveDev& cv, const double* partials, int n_blocks, bool has_delta, bool has_gamma,
+                              double* agg, hipStream_t stream);
 hipError_t launch_price_fast(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                              bool want_gamma, int n_blocks, hipStream_t stream);
 hipError_t launch_curve_df(const CurveDev& cv, int64_t n, const double* t_dev, double* df_dev, int n_cu, hipStream_t stream);

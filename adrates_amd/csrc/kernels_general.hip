@@ -517,11 +517,14 @@ __global__ __launch_bounds__(general_block_threads(LDSLC, WIDE), (WIDE > 10) ? 1
                 const double x0 = e0 != 0xffffu ? wstage[e0] : 0.0;
                 const double x1 = e1 != 0xffffu ? wstage[e1] : 0.0;
                 double* dst = g + band * 128 + 2 * lane;
+                // write-once output: non-temporal, it should not displace the convexity rows in L2
                 if (vec) {
-                    if (e0 != 0xffffu) *reinterpret_cast<double2*>(dst) = make_double2(x0, x1);
+                    typedef double nt_pair __attribute__((ext_vector_type(2)));
+                    nt_pair xx; xx.x = x0; xx.y = x1;
+                    if (e0 != 0xffffu) __builtin_nontemporal_store(xx, reinterpret_cast<nt_pair*>(dst));
                 } else {
-                    if (e0 != 0xffffu) dst[0] = x0;
-                    if (e1 != 0xffffu) dst[1] = x1;
+                    if (e0 != 0xffffu) __builtin_nontemporal_store(x0, dst);
+                    if (e1 != 0xffffu) __builtin_nontemporal_store(x1, dst + 1);
                 }
             }
         }
@@ -865,34 +868,30 @@ __global__ __launch_bounds__(general_block_threads(LDSLC, WIDE), (WIDE > 10) ? 1
     // ------------------------------------------------------------------------ block partial of the aggregate
     if constexpr (WIDE > 0) {
         if (out.block_partials) {
-            // one padded record [pv, delta[64], gamma[64][64]] per block: the waves add their totals in turn (fixed order)
-            __syncthreads();   // every wave is done with the curve tables; reuse the LDS for the reduction
-            double* red = reinterpret_cast<double*>(smem_raw);   // [kAggWide]
-            for (int i = threadIdx.x; i < kAggWide; i += kBlockThreads) red[i] = 0.0;
+            // one record [pv, delta[64], packed gamma entries] per block, in the kernel's own layouts: every wave leaves its
+            // totals in its hand-off buffer (pv, delta) and its staging area (gamma), thread e adds entry e over the waves
+            // in a fixed order and the sums go out as contiguous stores; the packed entries are mapped to the matrix by
+            // the final reduction (reduce_wide_kernel)
+            flush_gamma();
             __syncthreads();
-            for (int w = 0; w < kWavesPerBlock; ++w) {
-                if (wave == w) {
-                    if (lane == 0) red[0] += total.pv;
-                    if (DELTA) red[1 + lane] += total.delta;
-                    if constexpr (GAMMA) {
+            vbuf[lane] = DELTA ? total.delta : 0.0;
+            if (lane == 0) vbuf[kWidePad] = total.pv;
+            if constexpr (GAMMA) {
 #pragma unroll
-                        for (int ch = 0; ch < WIDE; ++ch) {
-                            const unsigned w = c.went[ch];
-                            const int aq = w & 0xff, bq = (w >> 8) & 0xff;
-#pragma unroll
-                            for (int q = 0; q < 2; ++q) {
-                                if (!(w & (0x10000u << q))) continue;
-                                const int i = cv.wide_order[aq + q], j = cv.wide_order[bq];
-                                red[1 + kWidePad + i * kWidePad + j] += total.gamma[2 * ch + q];
-                                if (i != j) red[1 + kWidePad + j * kWidePad + i] += total.gamma[2 * ch + q];
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
+                for (int ch = 0; ch < WIDE; ++ch)
+                    *reinterpret_cast<double2*>(wstage + ch * kWideChunk + 2 * lane) = make_double2(total.gamma[2 * ch], total.gamma[2 * ch + 1]);
             }
-            double* dst = out.block_partials + static_cast<size_t>(blockIdx.x) * kAggWide;
-            for (int i = threadIdx.x; i < kAggWide; i += kBlockThreads) dst[i] = red[i];
+            __syncthreads();
+            constexpr int kRecord = 1 + kWidePad + (GAMMA ? WIDE * kWideChunk : 0);
+            double* dst = out.block_partials + static_cast<size_t>(blockIdx.x) * (1 + kWidePad + cv.wide_nch * kWideChunk);
+            for (int i = threadIdx.x; i < kRecord; i += kBlockThreads) {
+                double sum = 0.0;
+#pragma unroll
+                for (int w = 0; w < kWavesPerBlock; ++w)
+                    sum += i == 0 ? s_vbuf[w * kVbuf + kWidePad] : (i <= kWidePad ? s_vbuf[w * kVbuf + i - 1]
+                                                                                 : s_wstage[w * (WIDE * kWideChunk) + i - 1 - kWidePad]);
+                dst[i] = sum;
+            }
         }
     } else
     if (out.block_partials) {
@@ -995,20 +994,25 @@ hipError_t launch_price_general(const CurveDev& cv, const TradesDev& tr, const O
 // ------------------------------------------------------------------------------------------ wide variants
 namespace {
 
-// Fixed-order sum of the wide kernel's block partials -> agg[1 + P + P*P]: one wavefront per output, lanes stride over the
-// blocks, then a fixed butterfly.
-__global__ __launch_bounds__(256) void reduce_wide_kernel(const double* partials, int n_blocks, int P, int has_delta,
-                                                           int has_gamma, double* agg) {
+// Fixed-order sum of the wide kernel's block partials ([n_blocks][1 + 64 + nch * 128]: pv, delta by pillar, gamma on the
+// packed triangle) -> agg[1 + P + P*P]: one wavefront per output, lanes stride over the blocks, then a fixed butterfly;
+// element (r, c) of the matrix reads its packed entry through the curve's store map.
+__global__ __launch_bounds__(256) void reduce_wide_kernel(const double* partials, int n_blocks, int P, int stride, int has_delta,
+                                                           int has_gamma, const uint32_t* store_map, double* agg) {
     const int lane = threadIdx.x & 63;
     const int o = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);       // index into agg
     if (o >= 1 + P + P * P) return;
-    int i = 0;                                                               // index into a padded record
+    int i = 0;                                                               // index into a block's record
     bool live = true;
-    if (o >= 1 + P) { const int r = (o - 1 - P) / P, q = (o - 1 - P) % P; i = 1 + kWidePad + r * kWidePad + q; live = has_gamma != 0; }
-    else if (o >= 1) { i = o; live = has_delta != 0; }
+    if (o >= 1 + P) {
+        const int f = o - 1 - P;                                             // flat index r * P + c
+        const uint32_t w = store_map[(f >> 7) * 64 + ((f & 127) >> 1)];
+        i = 1 + kWidePad + static_cast<int>((f & 1) ? (w >> 16) : (w & 0xffffu));
+        live = has_gamma != 0;
+    } else if (o >= 1) { i = o; live = has_delta != 0; }
     double s = 0.0;
     if (live)
-        for (int b = lane; b < n_blocks; b += 64) s += partials[static_cast<size_t>(b) * kAggWide + i];
+        for (int b = lane; b < n_blocks; b += 64) s += partials[static_cast<size_t>(b) * stride + i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) agg[o] = s;
@@ -1031,10 +1035,10 @@ size_t wide_kernel_lds_bytes(int K, int Kc, int nch, bool gamma) {
                                      (gamma ? static_cast<size_t>(kWavesPerBlock) * nch * kWideChunk : 0)) +
                    (gamma ? sizeof(unsigned long long) * static_cast<size_t>((Kc + 1) / 2) : 0) +
                    sizeof(int16_t) * (2 * static_cast<size_t>(K) + 2 * kLutMax);
-    const size_t reduce = sizeof(double) * kAggWide;
-    if (bytes < reduce) bytes = reduce;
     return (bytes + 15) & ~static_cast<size_t>(15);
 }
+
+int wide_partial_doubles(int nch) { return 1 + kWidePad + nch * kWideChunk; }
 
 int wide_kernel_threads(int nch, bool gamma) { return general_block_threads(false, gamma ? nch : 7); }
 
@@ -1068,11 +1072,11 @@ hipError_t launch_price_wide(const CurveDev& cv, const TradesDev& tr, const Outp
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_wide(const double* partials, int n_blocks, int P, bool has_delta, bool has_gamma, double* agg,
-                              hipStream_t stream) {
-    const int n_out = 1 + P + P * P;
+hipError_t launch_reduce_wide(const CurveDev& cv, const double* partials, int n_blocks, bool has_delta, bool has_gamma,
+                              double* agg, hipStream_t stream) {
+    const int P = cv.P, n_out = 1 + P + P * P;
     hipLaunchKernelGGL(reduce_wide_kernel, dim3((n_out + 3) / 4), dim3(256), 0, stream, partials, n_blocks, P,
-                       has_delta ? 1 : 0, has_gamma ? 1 : 0, agg);
+                       wide_partial_doubles(cv.wide_nch), has_delta ? 1 : 0, has_gamma ? 1 : 0, cv.wide_store_map, agg);
     return hipGetLastError();
 }
 
