@@ -58,6 +58,12 @@ __device__ __forceinline__ double readlane_d(double x, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+typedef double nt_pair __attribute__((ext_vector_type(2)));      // operand type of the non-temporal 16-byte stores
+__device__ __forceinline__ void nt_store2(double2* dst, double x, double y) {
+    nt_pair v; v.x = x; v.y = y;
+    __builtin_nontemporal_store(v, reinterpret_cast<nt_pair*>(dst));
+}
+
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
@@ -197,12 +203,19 @@ struct ConvLds {
 // CF: the convexity coefficients of the entries come from `cf` (final values: the caller has summed the weights
 // of the nodes that share a knot) instead of omega * b; without CF the argument is ignored.
 // LDSLC: the knot words carry the knot's class (curve_tables.hpp, knot_class) in their high half, `conv` is used.
-template <int NK, bool DELTA, bool GAMMA, bool CF = false, bool LDSLC = false>
+// NCORR (LINEAR_FWD_RATES, LDS-resident convexity rows): the rank-one corrections of the node's NCORR = NK / 2 lookups
+// (`add_df_correction`), weight kw[q] on the vector LJ[k[2q]] - LJ[k[2q+1]], ride in the node's own walk - their vectors are
+// differences of the Jacobian entries the walk has just read, and they reach the lanes through the idle halves of the
+// hand-off buffers (one tile: lanes 32-63 of `vbuf` hold a copy; `stage2` is the wave's trade-end staging area): one walk
+// per node instead of one per node and lookup (a payment-lag coupon: two walks instead of six).
+template <int NK, bool DELTA, bool GAMMA, bool CF = false, bool LDSLC = false, int NCORR = 0>
 __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k)[NK], const double (&b)[NK],
                                           double omega, const CurveLds& c, const double* __restrict__ lc_lanes,
                                           const unsigned long long* lc_block_mask,
                                           double* vbuf, int lane, Ladders<GAMMA>& acc, const double (&cf)[NK],
-                                          const ConvLds& conv = ConvLds{}) {
+                                          const ConvLds& conv = ConvLds{},
+                                          const double (&kw)[NCORR > 0 ? NCORR : 1] = {0.0}, double* stage2 = nullptr) {
+    static_assert(NCORR == 0 || (NCORR == NK / 2 && LDSLC && GAMMA), "fused corrections: one per lookup, LDS rows, gamma");
     const int p = lane & 31;
     const int bi = lane >> 3, bj = lane & 7;
     while (mask) {
@@ -221,15 +234,30 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
         double cc[NK];
 #pragma unroll
         for (int i = 0; i < NK; ++i) cc[i] = (CF && GAMMA) ? readlane_d(cf[i], n) : om * bb[i];
-        double v = 0.0;
+        double v = 0.0, ljv[NK];
 #pragma unroll
-        for (int i = 0; i < NK; ++i) v = fma(bb[i], c.lj[c.lj_off + kk[i] * kPillarPad + p], v);
+        for (int i = 0; i < NK; ++i) { ljv[i] = c.lj[c.lj_off + kk[i] * kPillarPad + p]; v = fma(bb[i], ljv[i], v); }
         if (DELTA) acc.delta = fma(om, v, acc.delta);
+        double wq[NCORR > 0 ? NCORR : 1];
+        if constexpr (NCORR > 0) {
+#pragma unroll
+            for (int q = 0; q < NCORR; ++q) wq[q] = readlane_d(kw[q], n);
+        }
         if (GAMMA) {
             // hand v[0..31] to every lane through the wave's LDS slot (same-wave LDS ops are ordered)
             // (the DS instructions of one wavefront execute in issue order: a compiler barrier is all the
             // hand-off needs, no wait for the write to retire)
             __builtin_amdgcn_wave_barrier();
+            if constexpr (NCORR > 0) {
+                const double d0 = ljv[0] - ljv[1];
+                vbuf[lane] = lane < 32 ? v : d0;
+                if constexpr (NCORR > 1) {
+                    const double d1 = ljv[2] - ljv[3];
+                    double d2 = 0.0;
+                    if constexpr (NCORR > 2) d2 = ljv[4] - ljv[5];
+                    stage2[lane] = lane < 32 ? d1 : d2;
+                }
+            } else
             vbuf[lane] = v;                       // lanes 32-63: the column tile's v (a copy on diagonal tile pairs)
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -270,6 +298,19 @@ __device__ __forceinline__ void add_nodes(unsigned long long mask, const int (&k
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) acc.gamma[i * 4 + jx] = fma(vr[i], vc[jx], acc.gamma[i * 4 + jx]);
+            if constexpr (NCORR > 0) {
+#pragma unroll
+                for (int q = 0; q < NCORR; ++q) {
+                    const double* src = (q == 0 ? vbuf + 32 : (q == 1 ? stage2 : stage2 + 32));
+                    double dr[4], dc_[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { dr[i] = wq[q] * src[4 * bi + i]; dc_[i] = src[4 * bj + i]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jx = 0; jx < 4; ++jx) acc.gamma[i * 4 + jx] = fma(dr[i], dc_[jx], acc.gamma[i * 4 + jx]);
+                }
+            }
             // curve-convexity part: sum_i om*b_i * LC[k_i]
             if constexpr (!LDSLC)
 #pragma unroll
@@ -482,6 +523,8 @@ __global__ __launch_bounds__(general_block_threads(LDSLC, WIDE), (WIDE > 10) ? 1
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar loads of the header
     const int knot0 = c.compact_of[0];                                    // the value-time knot (t = 0)
     constexpr bool linear_df = LINDF;                                     // LINEAR_FWD_RATES: see `Lookup`
+    // ... with LDS-resident convexity rows the corrections of a node's lookups ride in the node's walk (`add_nodes`, NCORR)
+    constexpr bool FUSE = LINDF && LDSLC && GAMMA && WIDE == 0;
     double* vbuf = s_vbuf + wave * kVbuf;
     const int P = cv.P;
     c.lj_off = (lane >= 32 && !diag) ? n_lj : 0;
@@ -519,9 +562,7 @@ __global__ __launch_bounds__(general_block_threads(LDSLC, WIDE), (WIDE > 10) ? 1
                 double* dst = g + band * 128 + 2 * lane;
                 // write-once output: non-temporal, it should not displace the convexity rows in L2
                 if (vec) {
-                    typedef double nt_pair __attribute__((ext_vector_type(2)));
-                    nt_pair xx; xx.x = x0; xx.y = x1;
-                    if (e0 != 0xffffu) __builtin_nontemporal_store(xx, reinterpret_cast<nt_pair*>(dst));
+                    if (e0 != 0xffffu) nt_store2(reinterpret_cast<double2*>(dst), x0, x1);
                 } else {
                     if (e0 != 0xffffu) __builtin_nontemporal_store(x0, dst);
                     if (e1 != 0xffffu) __builtin_nontemporal_store(x1, dst + 1);
@@ -627,8 +668,12 @@ __global__ __launch_bounds__(general_block_threads(LDSLC, WIDE), (WIDE > 10) ? 1
                 { int kt_[2];
 #pragma unroll
                   for (int i_ = 0; i_ < 2; ++i_) kt_[i_] = tag(k[i_]);
+                  if constexpr (FUSE) {
+                      const double kw1[1] = {omega * kap};
+                      add_nodes<2, DELTA, GAMMA, false, LDSLC, 1>(__ballot(own_start), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b, conv, kw1, stage);
+                  } else
                   add_nodes_any<2, DELTA, GAMMA, false, LDSLC, WIDE>(__ballot(own_start), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b, conv); }
-                if constexpr (linear_df) add_df_correction<GAMMA, LDSLC, WIDE>(own_start, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+                if constexpr (linear_df && !FUSE) add_df_correction<GAMMA, LDSLC, WIDE>(own_start, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
             }
             const bool own_ratio = valid && ratio;
             if (__ballot(own_ratio)) {   // payment lag: N D(ts) D(tp) / D(te) keeps all three lookups
@@ -705,6 +750,10 @@ __global__ __launch_bounds__(general_block_threads(LDSLC, WIDE), (WIDE > 10) ? 1
                 { int kt_[6];
 #pragma unroll
                   for (int i_ = 0; i_ < 6; ++i_) kt_[i_] = tag(k[i_]);
+                  if constexpr (FUSE) {
+                      const double kw3[3] = {omega * kap[0], omega * kap[1], omega * kap[2]};
+                      add_nodes<6, DELTA, GAMMA, true, LDSLC, 3>(__ballot(own_ratio && !pay_flat), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf, conv, kw3, stage);
+                  } else
                   add_nodes_any<6, DELTA, GAMMA, true, LDSLC, WIDE>(__ballot(own_ratio && !pay_flat), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf, conv); }
                 const unsigned long long flat_mask = __ballot(own_ratio && pay_flat);
                 if (flat_mask) {
@@ -714,9 +763,13 @@ __global__ __launch_bounds__(general_block_threads(LDSLC, WIDE), (WIDE > 10) ? 1
                     { int kt_[4];
 #pragma unroll
                       for (int i_ = 0; i_ < 4; ++i_) kt_[i_] = tag(k4[i_]);
+                      if constexpr (FUSE) {
+                          const double kw2[2] = {omega * kap[0], omega * kap[1]};      // (the payment lookup sits on the value-time knot: no correction)
+                          add_nodes<4, DELTA, GAMMA, true, LDSLC, 2>(flat_mask, kt_, b4, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf4, conv, kw2, stage);
+                      } else
                       add_nodes_any<4, DELTA, GAMMA, true, LDSLC, WIDE>(flat_mask, kt_, b4, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cf4, conv); }
                 }
-                if constexpr (linear_df) {
+                if constexpr (linear_df && !FUSE) {
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
                         add_df_correction<GAMMA, LDSLC, WIDE>(own_ratio, kc[2 * q], kc[2 * q + 1], omega * kap[q], c, lc_lanes, lc_block_mask, vbuf, lane, acc);
@@ -725,8 +778,12 @@ __global__ __launch_bounds__(general_block_threads(LDSLC, WIDE), (WIDE > 10) ? 1
             { int kt_[2];
 #pragma unroll
               for (int i_ = 0; i_ < 2; ++i_) kt_[i_] = tag(kp[i_]);
+              if constexpr (FUSE) {
+                  const double kw1[1] = {omega_p * qpay.kappa};
+                  add_nodes<2, DELTA, GAMMA, true, LDSLC, 1>(__ballot(pay_node), kt_, bp, omega_p, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cfp, conv, kw1, stage);
+              } else
               add_nodes_any<2, DELTA, GAMMA, true, LDSLC, WIDE>(__ballot(pay_node), kt_, bp, omega_p, c, lc_lanes, lc_block_mask, vbuf, lane, acc, cfp, conv); }
-            if constexpr (linear_df) add_df_correction<GAMMA, LDSLC, WIDE>(pay_node, kp[0], kp[1], omega_p * qpay.kappa, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+            if constexpr (linear_df && !FUSE) add_df_correction<GAMMA, LDSLC, WIDE>(pay_node, kp[0], kp[1], omega_p * qpay.kappa, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
         }
         // ---------------------------------------------------------------- fixed coupons not merged above
         for (int base = 0; base < n_fix; base += 64) {
@@ -752,8 +809,12 @@ __global__ __launch_bounds__(general_block_threads(LDSLC, WIDE), (WIDE > 10) ? 1
             { int kt_[2];
 #pragma unroll
               for (int i_ = 0; i_ < 2; ++i_) kt_[i_] = tag(k[i_]);
+              if constexpr (FUSE) {
+                  const double kw1[1] = {omega * kap};
+                  add_nodes<2, DELTA, GAMMA, false, LDSLC, 1>(__ballot(on), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b, conv, kw1, stage);
+              } else
               add_nodes_any<2, DELTA, GAMMA, false, LDSLC, WIDE>(__ballot(on), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b, conv); }
-            if constexpr (linear_df) add_df_correction<GAMMA, LDSLC, WIDE>(on, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
+            if constexpr (linear_df && !FUSE) add_df_correction<GAMMA, LDSLC, WIDE>(on, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
         }
 
         // ---------------------------------------------------------------- results of this trade
@@ -832,8 +893,8 @@ __global__ __launch_bounds__(general_block_threads(LDSLC, WIDE), (WIDE > 10) ? 1
                 if (g && r < P && mine_block) {
                     if (one_tile && P == kPillarPad) {
                         double2* dst = reinterpret_cast<double2*>(g + r * kPillarPad + 4 * bj);
-                        dst[0] = make_double2(gv[0], gv[1]);
-                        dst[1] = make_double2(gv[2], gv[3]);
+                        nt_store2(dst, gv[0], gv[1]);        // write-once output: it should not displace the tables in L2
+                        nt_store2(dst + 1, gv[2], gv[3]);
                     } else {
 #pragma unroll
                         for (int jx = 0; jx < 4; ++jx)
@@ -851,8 +912,8 @@ __global__ __launch_bounds__(general_block_threads(LDSLC, WIDE), (WIDE > 10) ? 1
                     for (int i = 0; i < 4; ++i) gt[i] = acc.gamma[i * 4 + jx] * 1e-8;
                     if (one_tile && P == kPillarPad) {
                         double2* dst = reinterpret_cast<double2*>(g + r * kPillarPad + 4 * bi);
-                        dst[0] = make_double2(gt[0], gt[1]);
-                        dst[1] = make_double2(gt[2], gt[3]);
+                        nt_store2(dst, gt[0], gt[1]);
+                        nt_store2(dst + 1, gt[2], gt[3]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)

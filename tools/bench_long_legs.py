@@ -16,7 +16,8 @@ mask = int(sys.argv[3]) if len(sys.argv) > 3 else 7       # 1 value, 3 value+del
 curve = gbp_model().curves.GBP_OIS_SONIA
 host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
 ctx = _native.Context(0)
-dc = _native.DeviceCurve(ctx, 4, host.times, host.dfs, host.jac, host.hess)
+interp = int(os.environ.get("ADR_BENCH_INTERP", "4"))       # 4 LINEAR_ZERO_RATES, 1 FLAT_FWD_RATES, 2 LINEAR_FWD_RATES
+dc = _native.DeviceCurve(ctx, interp, host.times, host.dfs, host.jac, host.hess)
 rng = np.random.default_rng(2)
 months = rng.integers(120, 361, n) if mode in ("long", "longlag") else rng.integers(1, 361, n)
 terms = OISTerms(vd, [f"{int(m)}M" for m in months], rng.uniform(0.01, 0.07, n), np.round(rng.uniform(1e6, 5e7, n), -5),
@@ -40,4 +41,4 @@ with torch.cuda.stream(s):
     b.record(s); s.synchronize()
 ms = a.elapsed_time(b) / 5
 print(json.dumps({"mode": mode, "mask": mask, "trades": n, "mean_float_coupons": float(np.diff(batch.flt_off).mean()), "ms": ms,
-                  "trades_per_s": n / ms * 1e3, "aggregate": not noagg, "lib": os.environ.get("ADRATES_HIP_LIB", "default")}))
+                  "trades_per_s": n / ms * 1e3, "aggregate": not noagg, "interp": interp, "lib": os.environ.get("ADRATES_HIP_LIB", "default")}))
