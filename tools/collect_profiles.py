@@ -16,6 +16,9 @@ copies = {
     f"bench_{tag}_curve_build.json": "curve_build_bench.json", f"ablate_{tag}.log": "final_ablations.txt",
     f"pmc_{tag}.txt": "final_pmc_counters.txt", f"pmc_{tag}_lag.txt": "payment_lag_pmc_counters.txt",
     f"stamps_{tag}.txt": "final_phase_stamps.txt", f"stamps_{tag}_lag.txt": "payment_lag_phase_stamps.txt",
+    f"bench_{tag}_many_pillars.json": "many_pillars_bench.json", f"bench_{tag}_payment_lag_linfwd.json": "payment_lag_linfwd_bench.json",
+    f"ablate_{tag}_wide.log": "wide_ablations.txt", f"pmc_{tag}_wide.txt": "wide_pmc_counters.txt",
+    f"routing_audit_{tag}.txt": "routing_audit.txt",
 }
 for src, dst in copies.items():
     if os.path.exists(f"{G}/{src}"):
@@ -24,7 +27,7 @@ for src, dst in copies.items():
     else:
         print("missing", src)
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
-for path, name in ((f"prof_{tag}_lag", "payment_lag"), (f"prof_{tag}_xccy", "xccy")):
+for path, name in ((f"prof_{tag}_lag", "payment_lag"), (f"prof_{tag}_xccy", "xccy"), (f"prof_{tag}_wide", "wide")):
     try:
         shutil.copy(newest(f"{G}/{path}/trace/*/*kernel_stats.csv"), f"{P}/{rnd}_{name}_kernel_stats.csv")
     except ValueError:
@@ -45,6 +48,23 @@ try:
     json.dump(out, open(f"{P}/{rnd}_payment_lag_traffic.json", "w"), indent=1)
 except ValueError:
     print("missing lag traffic passes")
+# ... and of the wide route (40 pillars, 100 000 trades, every output stored)
+try:
+    out = {"tag": tag, "workload": "ABLATE_ONLY=stored tools/ablate_wide.py 40 100000 offgrid",
+           "algorithmic_bytes_per_launch": 100000 * (8 * (1 + 40 + 40 * 40) + 16 * 15.5 + 32 * 15.5 + 40)}
+    for name in ("fetch", "write"):
+        vals = {}
+        for r in csv.DictReader(open(newest(f"{G}/prof_{tag}_wide/{name}/*/*counter_collection.csv"))):
+            if "price_" in r["Kernel_Name"]:
+                vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for k, v in vals.items():
+            out[k + "_KiB_per_launch"] = sum(v) / len(v)
+    rd, wr = 2.0 * out.get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024, out.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
+    out.update(read_bytes_corrected=rd, write_bytes=wr, hbm_bytes_per_launch=rd + wr,
+               note="read = 2 x FETCH_SIZE x 1024 (gfx950 half-count correction), write = WRITE_SIZE x 1024")
+    json.dump(out, open(f"{P}/{rnd}_wide_traffic.json", "w"), indent=1)
+except ValueError:
+    print("missing wide traffic passes")
 subprocess.check_call([sys.executable, "tools/profile_summary.py", tag, rnd])
 for a, b in ((f"{P}/{rnd}_{tag}_kernel_stats.csv", f"{P}/{rnd}_final_kernel_stats.csv"), (f"{P}/{rnd}_{tag}_traffic.json", f"{P}/{rnd}_final_traffic.json")):
     os.replace(a, b)
