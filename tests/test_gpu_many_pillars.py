@@ -178,3 +178,45 @@ def test_seventeen_pillar_curve_all_requests(gpu_ctx):
     only_d = _native.price(gpu_ctx, dc, dt, want_gamma=False)
     assert_batch_parity(only_d, dict(pv=ref["pv"], delta=ref["delta"]), batch.notional)
     dt.close()
+
+
+def test_wide_route_aggregate_without_per_trade_gamma_and_two_streams(gpu_ctx):
+    """`adr_price_dev` on a 40-pillar curve with the aggregate ladder alone (no per-trade gamma buffer: the kernel's
+    staging / store path is skipped, the totals are the same), and two batches priced concurrently on two streams of one
+    ctx without aggregates - bitwise the serial results."""
+    import torch
+    vd = F.README_VALUE_DT
+    px, tenors = forty_pillar_quotes()
+    curve = F.gbp_model(vd, px=px, tenors=tenors).curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    P = dc.n_pillars
+    dev = torch.device("cuda", 0)
+    batches = [_mixed_batch(vd, 4001, seed=21), _mixed_batch(vd, 3001, seed=22)]
+    dts = [_native.DeviceTrades(gpu_ctx, b) for b in batches]
+    full = [_native.price(gpu_ctx, dc, dt, aggregate=True) for dt in dts]
+    # aggregate only
+    n = batches[0].n_trades
+    pv = torch.empty(n, dtype=torch.float64, device=dev); de = torch.empty((n, P), dtype=torch.float64, device=dev)
+    ag = torch.zeros(1 + P + P * P, dtype=torch.float64, device=dev)
+    _native.price_dev(gpu_ctx, dc, dts[0], 7, pv.data_ptr(), de.data_ptr(), 0, ag.data_ptr())
+    gpu_ctx.sync()
+    agg = ag.cpu().numpy()
+    assert np.array_equal(agg[1 + P:].reshape(P, P), full[0]["agg_gamma"])       # same totals, same order of summation
+    assert np.array_equal(agg[1:1 + P], full[0]["agg_delta"]) and agg[0] == full[0]["agg_pv"]
+    assert np.array_equal(de.cpu().numpy(), full[0]["delta"])
+    # two streams, no aggregates
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    outs = []
+    for b, dt, st in zip(batches, dts, streams):
+        m = b.n_trades
+        bufs = (torch.empty(m, dtype=torch.float64, device=dev), torch.empty((m, P), dtype=torch.float64, device=dev),
+                torch.empty((m, P, P), dtype=torch.float64, device=dev))
+        outs.append(bufs)
+    for rep in range(3):
+        for dt, st, bufs in zip(dts, streams, outs):
+            _native.price_dev(gpu_ctx, dc, dt, 7, bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), 0, st.cuda_stream)
+    torch.cuda.synchronize()
+    for bufs, ref in zip(outs, full):
+        assert np.array_equal(bufs[2].cpu().numpy(), ref["gamma"]) and np.array_equal(bufs[0].cpu().numpy(), ref["pv"])
+    for dt in dts:
+        dt.close()
