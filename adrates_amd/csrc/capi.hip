@@ -823,6 +823,8 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     csr.flt_sign = static_cast<const double*>(put(flt_sign, n * sizeof(double)));
 
     tr->dev.n = n;
+    tr->dev.any_ratio = 0;
+    for (uint8_t lg : lagged_of) if (lg) { tr->dev.any_ratio = 1; break; }
     {
         adr::TradeHeader* hdr = static_cast<adr::TradeHeader*>(alloc(static_cast<size_t>(n) * sizeof(adr::TradeHeader)));
         if (e == hipSuccess && n > 0) e = adr::launch_build_headers(csr, hdr, stream);

@@ -74,6 +74,7 @@ struct TradesDev {
     const double* flt_te;
     const double* flt_alpha;
     const double* flt_weight;    // per-coupon multiplier of the notional, or null (= 1); general kernel only
+    int any_ratio;               // some trade has a coupon with te != tp or a notional multiplier != 1 (ratio nodes)
     // General kernel: the launch covers n_list trades: list[i] when list != null, else trade i.
     const int32_t* list;
     int64_t n_list;

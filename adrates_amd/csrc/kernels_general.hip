@@ -446,7 +446,9 @@ __device__ __forceinline__ void add_df_correction(bool on, int ka, int kb, doubl
 // LINDF: the curve interpolates with LINEAR_FWD_RATES (a compile-time switch: the state of the corrections would
 // otherwise cost the log-linear instantiations registers - measured +9 % on the gamma paths)
 // LDSLC: the convexity rows are LDS-resident (`ConvLds`): one 512-thread block per CU instead of two of 256.
-template <bool DELTA, bool GAMMA, bool LINDF, bool LDSLC, int WIDE = 0>
+// RATIO (wide variants): false for batches without payment lag / weighted coupons - the ratio-node path, whose state sets the
+// kernel's register ceiling, is compiled out
+template <bool DELTA, bool GAMMA, bool LINDF, bool LDSLC, int WIDE = 0, bool RATIO = true>
 // Two waves per SIMD either way (two blocks of 4 waves, the curve tables being about 75 KB, or one block of 8 waves next
 // to 112 KB of convexity rows): the register budget is pinned to that (without the bound the gamma instantiation
 // drifts to 256 VGPRs + AGPRs and one wave per SIMD).
@@ -675,8 +677,8 @@ __global__ __launch_bounds__(general_block_threads(LDSLC, WIDE), (WIDE > 10) ? 1
                   add_nodes_any<2, DELTA, GAMMA, false, LDSLC, WIDE>(__ballot(own_start), kt_, b, omega, c, lc_lanes, lc_block_mask, vbuf, lane, acc, b, conv); }
                 if constexpr (linear_df && !FUSE) add_df_correction<GAMMA, LDSLC, WIDE>(own_start, k[0], k[1], omega * kap, c, lc_lanes, lc_block_mask, vbuf, lane, acc);
             }
-            const bool own_ratio = valid && ratio;
-            if (__ballot(own_ratio)) {   // payment lag: N D(ts) D(tp) / D(te) keeps all three lookups
+            const bool own_ratio = RATIO && valid && ratio;
+            if (RATIO && __ballot(own_ratio)) {   // payment lag: N D(ts) D(tp) / D(te) keeps all three lookups
                 int k[6]; double b[6]; double omega = 0.0;
                 int kc[6]; double kap[3] = {0.0, 0.0, 0.0};    // LINEAR_FWD: the lookups' own knots and correction weights
 #pragma unroll
@@ -1081,6 +1083,11 @@ __global__ __launch_bounds__(256) void reduce_wide_kernel(const double* partials
 
 template <bool LINDF>
 void collect_wide(std::vector<const void*>& fns) {
+    if (!LINDF) {
+        fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, false, false, 7, false>));
+        fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, false, false, 10, false>));
+        fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, false, false, 17, false>));
+    }
     fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, LINDF, false, 7>));
     fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, LINDF, false, 10>));
     fns.push_back(reinterpret_cast<const void*>(&price_general_kernel<true, true, LINDF, false, 17>));
@@ -1117,7 +1124,14 @@ hipError_t launch_price_wide(const CurveDev& cv, const TradesDev& tr, const Outp
     dim3 grid(n_blocks), block(wide_kernel_threads(cv.wide_nch, want_gamma));
     using Fn = void (*)(CurveDev, TradesDev, OutputsDev);
     Fn fn = nullptr;
-    if (want_gamma) {
+    if (want_gamma && !lin && !tr.any_ratio) {
+        switch (cv.wide_nch) {
+            case 7: fn = &price_general_kernel<true, true, false, false, 7, false>; break;
+            case 10: fn = &price_general_kernel<true, true, false, false, 10, false>; break;
+            case 17: fn = &price_general_kernel<true, true, false, false, 17, false>; break;
+            default: return hipErrorInvalidValue;
+        }
+    } else if (want_gamma) {
         switch (cv.wide_nch) {
             case 7: fn = lin ? &price_general_kernel<true, true, true, false, 7> : &price_general_kernel<true, true, false, false, 7>; break;
             case 10: fn = lin ? &price_general_kernel<true, true, true, false, 10> : &price_general_kernel<true, true, false, false, 10>; break;

@@ -116,6 +116,14 @@ def test_wide_kernel_block_counts_vs_c_oracle(gpu_ctx, P, interp):
     assert_batch_parity(only_v, dict(pv=ref["pv"]), batch.notional)
     assert np.all(only_v["agg_delta"] == 0.0) and np.all(only_v["agg_gamma"] == 0.0)
     dt.close()
+    # a batch without payment lag or weighted coupons takes the kernel's instantiation without the ratio-node path
+    plain = synthetic.synthesize(vd, 1501, seed=P)
+    dtp = _native.DeviceTrades(gpu_ctx, plain)
+    refp = port.price(interp.value, host.times, host.dfs, host.jac, host.hess, plain)
+    gotp = _native.price(gpu_ctx, dc, dtp, aggregate=True)
+    assert_batch_parity(gotp, refp, plain.notional)
+    assert np.allclose(gotp["agg_gamma"], refp["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+    dtp.close()
     print(f"{P} pillars, {interp.name}: worst error {worst:.2e}")
 
 
