@@ -1097,18 +1097,54 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     o.gamma = want_gamma ? gamma_dev : nullptr;
 
     if (curve->dev.T > 1 && curve->dev.wide_nch > 0) {
-        // More than 32 pillars: the wide variants of the general kernel price every trade once - a wavefront of 64 lanes
-        // holds the whole delta ladder, the lanes share the 4x4 blocks of the upper triangle of the gamma matrix.
-        const size_t lds = adr::wide_kernel_lds_bytes(curve->dev.K, curve->dev.Kc, curve->dev.wide_nch, want_gamma);
-        const int threads = adr::wide_kernel_threads(curve->dev.wide_nch, want_gamma), waves = threads / 64;
-        const int64_t need = (n + waves - 1) / waves;
-        const int blocks = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * adr::wide_kernel_blocks_per_cu(lds, threads)));
-        if (static_cast<size_t>(blocks) * adr::wide_partial_doubles(curve->dev.wide_nch) > static_cast<size_t>(ctx->max_blocks) * adr::kAggStride)
+        // More than 32 pillars, one launch for the whole ladder.  GAMMA: the wide variants of the general kernel - a
+        // wavefront of 64 lanes holds the delta ladder, the gamma matrix is accumulated on its packed upper triangle.
+        // PV / PV + delta: the lite kernel's 64-pillar instantiations take the trades of its row tables (no payment lag
+        // and at most 32 coupons per leg; with payment lag, on a log-linear scheme: up to 360), the wide general kernel
+        // the rest.
+        const int stride = adr::wide_partial_doubles(curve->dev.wide_nch);
+        const bool lite_fits = adr::lite_kernel_lds_bytes(curve->dev, want_delta) <= kLdsBudget;
+        const bool use_lite = !want_gamma && lite_fits && trades->lite.n_units > 0;
+        const bool use_lite_lag = !want_gamma && lite_fits && trades->lite_lag.n_units > 0 && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
+        adr::TradesDev rest = trades->dev;
+        rest.list = nullptr; rest.n_list = n;
+        if (use_lite) {
+            rest.list = use_lite_lag ? trades->list_nonlite_b : trades->list_nonlite;
+            rest.n_list = use_lite_lag ? trades->n_nonlite_b : trades->n_nonlite;
+        } else if (use_lite_lag) {     // no plain lite rows: no trade is outside list_nonlite
+            rest.list = trades->list_nonlite_b; rest.n_list = trades->n_nonlite_b;
+        }
+        int blocks_lite = 0, blocks_litelag = 0, blocks_wide = 0;
+        auto lite_blocks = [&](const adr::LiteRowsDev& lt) {
+            const size_t lds = adr::lite_kernel_lds_bytes(curve->dev, want_delta);
+            const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
+            const int64_t need = (lt.n_units + adr::kLiteThreads / 64 - 1) / (adr::kLiteThreads / 64);
+            return static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * per_cu));
+        };
+        if (use_lite) blocks_lite = lite_blocks(trades->lite);
+        if (use_lite_lag) blocks_litelag = lite_blocks(trades->lite_lag);
+        if (rest.n_list > 0) {
+            const size_t lds = adr::wide_kernel_lds_bytes(curve->dev.K, curve->dev.Kc, curve->dev.wide_nch, want_gamma);
+            const int threads = adr::wide_kernel_threads(curve->dev.wide_nch, want_gamma), waves = threads / 64;
+            const int64_t need = (rest.n_list + waves - 1) / waves;
+            blocks_wide = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * adr::wide_kernel_blocks_per_cu(lds, threads)));
+        }
+        const int blocks = blocks_lite + blocks_litelag + blocks_wide;
+        if (static_cast<size_t>(blocks) * stride > static_cast<size_t>(ctx->max_blocks) * adr::kAggStride)
             return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
-        adr::TradesDev all = trades->dev;
-        all.list = nullptr; all.n_list = n;
-        o.block_partials = agg_dev ? ctx->partials : nullptr;
-        ADR_HIP(adr::launch_price_wide(curve->dev, all, o, want_delta, want_gamma, blocks, stream));
+        auto partials_at = [&](int first_block) { return agg_dev ? ctx->partials + static_cast<size_t>(first_block) * stride : nullptr; };
+        if (blocks_lite > 0) {
+            o.block_partials = partials_at(0);
+            ADR_HIP(adr::launch_price_lite(curve->dev, trades->lite, o, want_delta, blocks_lite, stream));
+        }
+        if (blocks_litelag > 0) {
+            o.block_partials = partials_at(blocks_lite);
+            ADR_HIP(adr::launch_price_lite(curve->dev, trades->lite_lag, o, want_delta, blocks_litelag, stream));
+        }
+        if (blocks_wide > 0) {
+            o.block_partials = partials_at(blocks_lite + blocks_litelag);
+            ADR_HIP(adr::launch_price_wide(curve->dev, rest, o, want_delta, want_gamma, blocks_wide, stream));
+        }
         if (agg_dev) ADR_HIP(adr::launch_reduce_wide(curve->dev, ctx->partials, blocks, want_delta, want_gamma, agg_dev, stream));
         return ADR_OK;
     }

@@ -23,6 +23,8 @@
 //     special cases (the dense 32-wide LJ of all reachable knots fits LDS once the gamma tables are not needed);
 //   * neighbour moves and the 16-lane PV sum are DPP row operations (VALU, no LDS traffic).
 // Any curve of the three schemes qualifies (no packed layout, any pillar count up to 32).
+// W64 instantiations (round 3): curves of 33-64 pillars - the 64-wide Jacobian table of the wide layout (curve_tables.hpp),
+// four pillars per lane (two b128 reads of the row and four FMAs per entry), block partials in the wide route's record.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -103,15 +105,17 @@ struct CurveLds {
 // lane simply leaves three pairs of entries (ts: +, te: -, tp: + with both amounts) in three sweeps; no telescoping.
 // NSEG: segments of the row table the kernel looks at (3 covers tables of at most three distinct row counts - every
 // table of trades without payment lag; kLiteSegments otherwise)
-template <bool DELTA, bool LINDF, bool LAG, int NSEG>
+template <bool DELTA, bool LINDF, bool LAG, int NSEG, bool W64 = false>
 __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                                                                                        OutputsDev out) {
     static_assert(!(LAG && LINDF), "payment-lag trades under LINEAR_FWD_RATES go to the general kernel");
+    constexpr int PW = W64 ? kWidePad : kPillarPad;       // pillars per row of the Jacobian table
+    constexpr int PPL = PW / L;                           // pillars per lane: 2, or 4 on the 64-wide table
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS carve-up: per-wave entry slots (16-byte aligned), doubles, int16 tables
     unsigned char* s_rec = smem_raw;
     double* s_lj = reinterpret_cast<double*>(s_rec + (DELTA ? kWavesPerBlock * kRecBytesPerWave : 0));
-    double* s_x = s_lj + (DELTA ? cv.Kc * kPillarPad : 0);
+    double* s_x = s_lj + (DELTA ? cv.Kc * PW : 0);
     double* s_log = s_x + cv.K;
     double* s_invx = s_log + cv.Kc;
     double* s_invdx = s_invx + cv.Kc;
@@ -119,8 +123,10 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
     int16_t* s_comp = s_first + cv.K;
     int16_t* s_lut = s_comp + cv.K;
 
-    if (DELTA)
-        for (int i = threadIdx.x; i < cv.Kc * kPillarPad; i += kBlockThreads) s_lj[i] = cv.lj[i];
+    if (DELTA) {
+        const double* lj_src = W64 ? cv.lj64 : cv.lj;
+        for (int i = threadIdx.x; i < cv.Kc * PW; i += kBlockThreads) s_lj[i] = lj_src[i];
+    }
     for (int i = threadIdx.x; i < cv.K; i += kBlockThreads) {
         s_x[i] = cv.x[i];
         {   // jnp.interp returns fp[i-1] when |dx| <= 2^-104: weight 0
@@ -151,9 +157,9 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
     unsigned char* rec_wave = s_rec + wave * kRecBytesPerWave;
     const unsigned char* rec_group = rec_wave + g * ((2 * L + 1) * 16);
     unsigned char* rec_mine = rec_wave + (g * (2 * L + 1) + 2 * l) * 16;
-    const unsigned char* lj_lane = reinterpret_cast<const unsigned char*>(s_lj) + l * 16;    // pillars 2l, 2l + 1
+    const unsigned char* lj_lane = reinterpret_cast<const unsigned char*>(s_lj) + l * (8 * PPL);    // pillars PPL l .. PPL l + PPL - 1
 
-    double tot_pv = 0.0, tot_d0 = 0.0, tot_d1 = 0.0;
+    double tot_pv = 0.0, tot_d0 = 0.0, tot_d1 = 0.0, tot_d2 = 0.0, tot_d3 = 0.0;
 
     // ---------------------------------------------------------------------------------------------------
     // Main loop over (unit, row) steps.  A unit is 4 trade slots (one per group of 16 lanes); its trades have R rows
@@ -213,6 +219,7 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
     int n_flt = 0, n_fix = 0, t = -1;
     bool live = false;
     double pv = 0.0, d0 = 0.0, d1 = 0.0, e0 = 0.0, e1 = 0.0;     // two accumulator pairs: shorter FMA chains
+    double d2 = 0.0, d3 = 0.0, e2 = 0.0, e3 = 0.0;               // W64: pillars 4l + 2, 4l + 3
 #ifdef ADR_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = clock64();
@@ -230,6 +237,7 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
             n_flt = nx_meta & 0x1ff; n_fix = (nx_meta >> 9) & 0x1ff;            // (up to 360 coupons per leg: 24 rows)
             sl = (nx_meta & 0x40000) ? -1.0 : 1.0; sf = (nx_meta & 0x80000) ? -1.0 : 1.0;
             pv = d0 = d1 = e0 = e1 = 0.0;
+            d2 = d3 = e2 = e3 = 0.0;
         }
         // ---- request the next step's inputs
         const bool last_row = r + 1 == R;
@@ -301,15 +309,22 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                 }
                 const int n_e = 2 * (32 - __builtin_clz(rows_any));      // entries up to the highest live lane of any row
                 for (int e = 0; e < n_e; e += kBatch) {                   // lanes past n_e wrote zero entries
-                    double2 rc[kBatch], rw[kBatch];
+                    double2 rc[kBatch], rw[kBatch], rv[W64 ? kBatch : 1];
 #pragma unroll
                     for (int i = 0; i < kBatch; ++i) rc[i] = *reinterpret_cast<const double2*>(rec_group + (e + i) * 16);
 #pragma unroll
-                    for (int i = 0; i < kBatch; ++i) rw[i] = *reinterpret_cast<const double2*>(lj_lane + __double2loint(rc[i].y));
+                    for (int i = 0; i < kBatch; ++i) {
+                        rw[i] = *reinterpret_cast<const double2*>(lj_lane + __double2loint(rc[i].y));
+                        if (W64) rv[i] = *reinterpret_cast<const double2*>(lj_lane + __double2loint(rc[i].y) + 16);
+                    }
 #pragma unroll
                     for (int i = 0; i < kBatch; ++i) {
                         if (i & 1) { e0 = fma(rc[i].x, rw[i].x, e0); e1 = fma(rc[i].x, rw[i].y, e1); }
                         else { d0 = fma(rc[i].x, rw[i].x, d0); d1 = fma(rc[i].x, rw[i].y, d1); }
+                        if (W64) {
+                            if (i & 1) { e2 = fma(rc[i].x, rv[i].x, e2); e3 = fma(rc[i].x, rv[i].y, e3); }
+                            else { d2 = fma(rc[i].x, rv[i].x, d2); d3 = fma(rc[i].x, rv[i].y, d3); }
+                        }
                     }
                 }
 #if ADR_LITE_SWEEP_PRIO
@@ -334,7 +349,7 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                 pv += om_r + om_p;
                 ADR_STAMP(2);   // lookups + exp
                 if (DELTA) {
-                    const int row = kPillarPad * 8;
+                    const int row = PW * 8;
                     sweep(ratio, om_r * qs.ba, om_r * qs.bb, qs.ka * row, qs.kb * row);
                     sweep(ratio, -om_r * qe.ba, -om_r * qe.bb, qe.ka * row, qe.kb * row);
                     sweep(valid, (om_r + om_p) * qp.ba, (om_r + om_p) * qp.bb, qp.ka * row, qp.kb * row);
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                         pv += omega;
                         ca = omega * q.ba; cb = omega * q.bb;
                     }
-                    off_a = q.ka * (kPillarPad * 8); off_b = q.kb * (kPillarPad * 8);
+                    off_a = q.ka * (PW * 8); off_b = q.kb * (PW * 8);
                 }
                 ADR_STAMP(2);   // lookup + exp
                 if (!DELTA) continue;
@@ -384,13 +399,17 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
         if (DELTA && live) {
             d0 = (d0 + e0) * 1e-4; d1 = (d1 + e1) * 1e-4;
             tot_d0 += d0; tot_d1 += d1;
+            if (W64) { d2 = (d2 + e2) * 1e-4; d3 = (d3 + e3) * 1e-4; tot_d2 += d2; tot_d3 += d3; }
             if (out.delta) {
-                double* dst = out.delta + static_cast<int64_t>(t) * P + 2 * l;
+                double* dst = out.delta + static_cast<int64_t>(t) * P + PPL * l;
                 if ((P & 1) == 0) {
-                    if (2 * l < P) { nt_pair pr; pr.x = d0; pr.y = d1; __builtin_nontemporal_store(pr, reinterpret_cast<nt_pair*>(dst)); }
+                    if (PPL * l < P) { nt_pair pr; pr.x = d0; pr.y = d1; __builtin_nontemporal_store(pr, reinterpret_cast<nt_pair*>(dst)); }
+                    if (W64 && PPL * l + 2 < P) { nt_pair pr; pr.x = d2; pr.y = d3; __builtin_nontemporal_store(pr, reinterpret_cast<nt_pair*>(dst + 2)); }
                 } else {                 // odd pillar count: rows are not 16-byte aligned
-                    if (2 * l < P) dst[0] = d0;
-                    if (2 * l + 1 < P) dst[1] = d1;
+                    if (PPL * l < P) dst[0] = d0;
+                    if (PPL * l + 1 < P) dst[1] = d1;
+                    if (W64 && PPL * l + 2 < P) dst[2] = d2;
+                    if (W64 && PPL * l + 3 < P) dst[3] = d3;
                 }
             }
         }
@@ -414,17 +433,23 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
             tot_pv += __shfl_xor(tot_pv, off, 64);
             tot_d0 += __shfl_xor(tot_d0, off, 64);
             tot_d1 += __shfl_xor(tot_d1, off, 64);
+            if (W64) { tot_d2 += __shfl_xor(tot_d2, off, 64); tot_d3 += __shfl_xor(tot_d3, off, 64); }
         }
         __syncthreads();   // every wave is done with the tables; reuse the LDS
-        double* red = reinterpret_cast<double*>(smem_raw);          // [waves][1 + 32]
-        if (lane == 0) red[wave * 33] = tot_pv;
-        if (g == 0) { red[wave * 33 + 1 + 2 * l] = tot_d0; red[wave * 33 + 2 + 2 * l] = tot_d1; }
+        constexpr int kRed = 1 + PW;
+        double* red = reinterpret_cast<double*>(smem_raw);          // [waves][1 + PW]
+        if (lane == 0) red[wave * kRed] = tot_pv;
+        if (g == 0) {
+            red[wave * kRed + 1 + PPL * l] = tot_d0; red[wave * kRed + 2 + PPL * l] = tot_d1;
+            if (W64) { red[wave * kRed + 3 + PPL * l] = tot_d2; red[wave * kRed + 4 + PPL * l] = tot_d3; }
+        }
         __syncthreads();
-        double* dst = out.block_partials + static_cast<size_t>(blockIdx.x) * kAggStride;
-        if (threadIdx.x < 1 + kPillarPad) {
+        // (W64: the wide route's record - pv, delta[64], then the packed gamma entries, which no delta request reads)
+        double* dst = out.block_partials + static_cast<size_t>(blockIdx.x) * (W64 ? 1 + kWidePad + cv.wide_nch * kWideChunk : kAggStride);
+        if (threadIdx.x < kRed) {
             double s = 0.0;
 #pragma unroll
-            for (int w = 0; w < kWavesPerBlock; ++w) s += red[w * 33 + threadIdx.x];
+            for (int w = 0; w < kWavesPerBlock; ++w) s += red[w * kRed + threadIdx.x];
             dst[threadIdx.x] = (DELTA || threadIdx.x == 0) ? s : 0.0;     // the gamma part is not read (no gamma requested)
         }
     }
@@ -435,23 +460,29 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
 namespace {
 using LiteFn = void (*)(CurveDev, LiteRowsDev, OutputsDev);
 
-template <bool DELTA, bool LINDF, bool LAG>
+template <bool DELTA, bool LINDF, bool LAG, bool W64>
 LiteFn lite_kernel_nseg(bool many) {
-    return many ? &price_lite_kernel<DELTA, LINDF, LAG, kLiteSegments> : &price_lite_kernel<DELTA, LINDF, LAG, 3>;
+    return many ? &price_lite_kernel<DELTA, LINDF, LAG, kLiteSegments, W64> : &price_lite_kernel<DELTA, LINDF, LAG, 3, W64>;
 }
 
-LiteFn lite_kernel(bool delta, bool lindf, bool lag, bool many_segments) {
-    if (lag) return delta ? lite_kernel_nseg<true, false, true>(many_segments) : lite_kernel_nseg<false, false, true>(many_segments);
-    if (lindf) return delta ? lite_kernel_nseg<true, true, false>(many_segments) : lite_kernel_nseg<false, true, false>(many_segments);
-    return delta ? lite_kernel_nseg<true, false, false>(many_segments) : lite_kernel_nseg<false, false, false>(many_segments);
+template <bool W64>
+LiteFn lite_kernel_w(bool delta, bool lindf, bool lag, bool many_segments) {
+    if (lag) return delta ? lite_kernel_nseg<true, false, true, W64>(many_segments) : lite_kernel_nseg<false, false, true, W64>(many_segments);
+    if (lindf) return delta ? lite_kernel_nseg<true, true, false, W64>(many_segments) : lite_kernel_nseg<false, true, false, W64>(many_segments);
+    return delta ? lite_kernel_nseg<true, false, false, W64>(many_segments) : lite_kernel_nseg<false, false, false, W64>(many_segments);
+}
+
+LiteFn lite_kernel(bool delta, bool lindf, bool lag, bool many_segments, bool w64 = false) {
+    return w64 ? lite_kernel_w<true>(delta, lindf, lag, many_segments) : lite_kernel_w<false>(delta, lindf, lag, many_segments);
 }
 }  // namespace
 
 size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta) {
-    size_t bytes = delta ? static_cast<size_t>(kWavesPerBlock) * kRecBytesPerWave + sizeof(double) * cv.Kc * kPillarPad : 0;
+    const size_t pw = cv.T > 1 ? kWidePad : kPillarPad;           // more than 32 pillars: the 64-wide table (W64 instantiations)
+    size_t bytes = delta ? static_cast<size_t>(kWavesPerBlock) * kRecBytesPerWave + sizeof(double) * cv.Kc * pw : 0;
     bytes += sizeof(double) * (2 * static_cast<size_t>(cv.K) + 2 * cv.Kc);
     bytes += sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + 2 * static_cast<size_t>(cv.n_lut));
-    const size_t reduce = sizeof(double) * kWavesPerBlock * 33;
+    const size_t reduce = sizeof(double) * kWavesPerBlock * (1 + pw);
     if (bytes < reduce) bytes = reduce;
     return (bytes + 15) & ~static_cast<size_t>(15);
 }
@@ -461,7 +492,8 @@ hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const Ou
     const size_t lds = lite_kernel_lds_bytes(cv, want_delta);
     const dim3 grid(n_blocks), block(kBlockThreads);
     if (tr.te_w && cv.method == 2) return hipErrorInvalidValue;        // payment-lag rows: log-linear schemes only
-    hipLaunchKernelGGL(lite_kernel(want_delta, cv.method == 2, tr.te_w != nullptr, tr.n_seg > 3), grid, block, lds, stream, cv, tr, out);
+    if (cv.T > 1 && !cv.lj64) return hipErrorInvalidValue;             // 33-64 pillars: the wide layout's table
+    hipLaunchKernelGGL(lite_kernel(want_delta, cv.method == 2, tr.te_w != nullptr, tr.n_seg > 3, cv.T > 1), grid, block, lds, stream, cv, tr, out);
     return hipGetLastError();
 }
 
@@ -471,7 +503,10 @@ hipError_t set_lite_kernel_lds_limit(size_t bytes) {
         for (int lin = 0; lin < 2; ++lin)
             for (int lag = 0; lag < 2; ++lag)
                 for (int many = 0; many < 2; ++many)
-                    if (!(lin && lag)) fns.push_back(reinterpret_cast<const void*>(lite_kernel(d != 0, lin != 0, lag != 0, many != 0)));
+                    if (!(lin && lag)) {
+                        fns.push_back(reinterpret_cast<const void*>(lite_kernel(d != 0, lin != 0, lag != 0, many != 0, false)));
+                        fns.push_back(reinterpret_cast<const void*>(lite_kernel(d != 0, lin != 0, lag != 0, many != 0, true)));
+                    }
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
         if (e != hipSuccess) return e;

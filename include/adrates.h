@@ -62,8 +62,9 @@ typedef enum adr_status {
 /* Largest pillar count (the reference has none, cavour/market/position/engine.py:2388-2389).  Curves of up to 32
  * pillars take the fast kernels.  Curves of 33-64 pillars take the WIDE variants of the general kernel: one wavefront holds
  * the whole delta ladder (lane = pillar), the gamma matrix is accumulated as its packed upper triangle and written once -
- * one launch per request, every trade type and all three schemes; 40 pillars: 86 M trades/s with GAMMA, 340 M with DELTA
- * (profiles/r03_many_pillars_bench.json; 26 M / 244 M on the tiled route it replaces), 64 pillars: 42 M / 333 M.  A curve
+ * one launch per request, every trade type and all three schemes; PV / PV + DELTA requests run on 64-pillar instantiations
+ * of the delta-only kernel.  40 pillars: 111 M trades/s with GAMMA, 960 M with DELTA (profiles/r03_many_pillars_bench.json;
+ * 26 M / 244 M on the tiled route it replaces), 64 pillars: 44 M / 914 M.  A curve
  * whose wide tables exceed the LDS of a CU (several hundred reachable knots), or a curve uploaded with ADR_WIDE_KERNEL=0
  * in the environment, is priced by the general kernel once per pair of 32-pillar tiles instead: 3 launches for GAMMA, 2
  * for DELTA, 1 for VALUE alone.  Odd pillar counts are served by the general kernel as well (the fast kernel stores the
