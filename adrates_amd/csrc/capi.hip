@@ -350,7 +350,8 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     // the fast kernels store the [P][P] matrices as 16-byte pairs of the flat array: P must be even
     // LINEAR_FWD_RATES is linear in the knot DFs, not in their logs: only the general kernel carries the extra
     // Hessian term (kernels_general.hip, `Lookup`)
-    c->dev.packed_ok = (t.packed_ok && t.P % 2 == 0) ? 1 : 0;
+    c->dev.packed_ok = t.packed_ok ? 1 : 0;
+    c->dev.odd_last = t.odd_last;
     c->dev.Pc = t.Pc; c->dev.pc_pad = t.pc_pad; c->dev.Ec = t.Ec; c->dev.Eu = t.Eu; c->dev.epg = t.epg; c->dev.cpg = t.cpg; c->dev.hub = t.hub ? 1 : 0;
     c->dev.Kcore = t.Kcore; c->dev.n_mini = t.n_mini; c->dev.fringe_start = t.fringe_start; c->dev.n_fringe = t.n_fringe; c->dev.fringe_own = t.fringe_own ? 1 : 0;
     c->dev.ljc = d_ljc; c->dev.lcc = d_lcc; c->dev.mini = d_mini; c->dev.knot_class = d_class;
@@ -496,7 +497,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
 
     adr::CurveBuildPlanDev& d = plan->dev;
     d.K = K; d.P = P; d.Kc = t.Kc; d.acc = d_acc; d.pillar = d_pil; d.prev_idx = d_prev; d.knot_index = d_kidx;
-    d.packed_ok = (t.packed_ok && t.P % 2 == 0) ? 1 : 0;   // as in adr_curve_upload
+    d.packed_ok = t.packed_ok ? 1 : 0;   // as in adr_curve_upload
     d.Pc = t.Pc; d.pc_pad = t.pc_pad; d.Ec = t.Ec; d.Kcore = t.Kcore; d.n_mini = t.n_mini;
     d.knot_class = d_class; d.core_pillars = d_core; d.lcc_pq = d_lccpq;
     d.wide_nch = wide ? t.wide_nch : 0; d.wide_pq = d_wpq; d.dpv_global = dpv_global ? 1 : 0;
@@ -508,6 +509,7 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
     c.x = d_x; c.inv_x = d_invx; c.first_of = d_first; c.compact_of = d_comp; c.lc_block_mask = d_lcmask;
     c.lut = d_lut; c.n_lut = static_cast<int>(t.lut.size() / 2);
     c.packed_ok = d.packed_ok;
+    c.odd_last = t.odd_last;
     c.Pc = t.Pc; c.pc_pad = t.pc_pad; c.Ec = t.Ec; c.Eu = t.Eu; c.epg = t.epg; c.cpg = t.cpg; c.hub = t.hub ? 1 : 0; c.Kcore = t.Kcore; c.n_mini = t.n_mini; c.fringe_start = t.fringe_start; c.n_fringe = t.n_fringe; c.fringe_own = t.fringe_own ? 1 : 0;
     c.knot_class = d_class; c.pillar_to_core = d_p2c; c.out_map = d_omap; c.store_map = d_smap; c.ent_pq = d_pq; c.core_pos = d_cpos; c.lcc_pos = d_lpos;
     size_t fast_lds = 0;
@@ -1198,8 +1200,11 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     // other packed curves keep the older variant of kernels_fast.hip for the one-row trades
     const bool new_lag = trades->lag_dates && adr::lag_kernel_takes(curve->dev);
     const bool use_lag = want_gamma && use_fast && (lagged.n_rows > 0 || lagged_long.n_rows > 0) && trades->lag_scratch != nullptr &&
-                         curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES &&
+                         curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES && curve->dev.P % 2 == 0 &&
                          trades->lagged_chained_blocks <= trades->lag_blocks;
+    // (odd pillar counts: the variant's patch of the elements without a packed entry works on aligned PAIRS of one matrix row -
+    // with an odd row length a pair of the flat array can straddle two rows; such curves leave their payment-lag trades with
+    // GAMMA to the general kernel, everything else takes the fast kernels)
     if (!use_lag) { lagged.n_rows = 0; lagged_long.n_rows = 0; }
     // (chained rows are laid out for one kernel's grid: a batch uploaded for the date-record kernel on a curve that kernel
     // does not take leaves its chained payment-lag trades to the general kernel)

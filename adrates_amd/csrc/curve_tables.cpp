@@ -485,6 +485,11 @@ bool build_packed_layout(CurveTables& t) {
     t.store_map.assign(kPillarPad * kPillarPad, -2);
     for (int r = 0; r < P; ++r)
         for (int q = 0; q < P; ++q) t.store_map[r * P + q] = t.out_map[r * kPillarPad + q];
+    t.odd_last = -3;
+    if (P % 2) {     // the last element has no partner inside the matrix: its pair goes to the kernels' sink
+        t.odd_last = t.store_map[P * P - 1] < 0 ? -1 : t.store_map[P * P - 1];
+        t.store_map[P * P - 1] = -2;
+    }
 
     t.knot_class.assign(Kc, -2);
     t.Kcore = 0;

@@ -118,6 +118,9 @@ struct CurveTables {
                                            //                  Ec + 1 + ordinal of the fringe pair, -1 for pairs no node creates
     std::vector<int16_t> out_map;          // [32*32]          packed entry feeding gamma[r][c] (32-wide rows), -1 if none
     std::vector<int16_t> store_map;        // [32*32]          the same by flat index r*P + c; -2 beyond P*P
+    int odd_last = -3;                     // odd P: packed entry of element (P-1, P-1) (-1: none), whose pair of the flat array
+                                           //        straddles the end of the matrix - its slot in store_map says -2 and the
+                                           //        kernels store it on its own; -3 for even P
     std::vector<MiniKnot> mini;            // [n_mini]
 };
 

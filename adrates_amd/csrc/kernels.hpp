@@ -190,6 +190,7 @@ struct CurveDev {
     const int16_t* pillar_to_core;  // [32]
     const int16_t* out_map;      // [32*32] packed entry of gamma[r][c], rows 32 wide (aggregate)
     const int16_t* store_map;    // [32*32] packed entry by flat index r*P + c of the caller's matrix; -2 beyond P*P
+    int odd_last;                // odd P: packed entry of the last element, stored on its own (curve_tables.hpp); -3 for even P
     const uint8_t* ent_pq;       // [Eu][2]
     const int16_t* core_pos;     // [32*cpg] hub layout only: row position of core entry e
     const int16_t* lcc_pos;      // [32*32] flat index of pair (r, c) for the general kernel's LDS rows: its position in a

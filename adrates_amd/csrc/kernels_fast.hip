@@ -991,6 +991,12 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                         }
                     }
                 }
+                // odd pillar count: the matrix's last element has no partner inside it (its pair went to the sink above) and is
+                // stored on its own; the 16-byte stores of odd-numbered trades are 8-byte aligned only, which the hardware takes
+                if (STORE && cv.odd_last != -3) {
+                    const double x_last = cv.odd_last >= 0 ? slot[cv.odd_last] : 0.0;
+                    if (lane == 0 && tt >= 0) __builtin_nontemporal_store(x_last, out.gamma + static_cast<int64_t>(tt) * (P * P) + (P * P - 1));
+                }
             }
         }
 #if ADR_OUT_PRIO

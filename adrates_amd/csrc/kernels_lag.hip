@@ -962,7 +962,7 @@ KernelFn lag_kernel_for(int epg) {
 }  // namespace
 
 bool lag_kernel_takes(const CurveDev& cv) {
-    return cv.packed_ok && cv.hub && cv.cpg == cv.epg - 2 && cv.method != 2;
+    return cv.packed_ok && cv.hub && cv.cpg == cv.epg - 2 && cv.method != 2 && cv.P % 2 == 0;
 }
 
 int lag_kernel_threads() { return kThreads; }

@@ -67,8 +67,9 @@ typedef enum adr_status {
  * 26 M / 244 M on the tiled route it replaces), 64 pillars: 44 M / 914 M.  A curve
  * whose wide tables exceed the LDS of a CU (several hundred reachable knots), or a curve uploaded with ADR_WIDE_KERNEL=0
  * in the environment, is priced by the general kernel once per pair of 32-pillar tiles instead: 3 launches for GAMMA, 2
- * for DELTA, 1 for VALUE alone.  Odd pillar counts are served by the general kernel as well (the fast kernel stores the
- * [P][P] matrices as 16-byte pairs).  The device curve builder (adr_curve_plan_create) takes the same 64: curves it
+ * for DELTA, 1 for VALUE alone.  Odd pillar counts take the fast kernels too (their 16-byte stores are legal on 8-byte
+ * boundaries on gfx950; the last element of a matrix is stored on its own): 31 pillars 354 M trades/s with GAMMA against
+ * 93 M on the general kernel before; only payment-lag trades with GAMMA stay on the general kernel there.  The device curve builder (adr_curve_plan_create) takes the same 64: curves it
  * builds on 33-64 pillars carry the wide layout's tables only. */
 #define ADR_MAX_PILLARS 64
 

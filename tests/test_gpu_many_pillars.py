@@ -228,3 +228,27 @@ def test_wide_route_aggregate_without_per_trade_gamma_and_two_streams(gpu_ctx):
         assert np.array_equal(bufs[2].cpu().numpy(), ref["gamma"]) and np.array_equal(bufs[0].cpu().numpy(), ref["pv"])
     for dt in dts:
         dt.close()
+
+
+@pytest.mark.parametrize("drop,interp", [(13, InterpTypes.LINEAR_ZERO_RATES), (31, InterpTypes.FLAT_FWD_RATES), (0, InterpTypes.LINEAR_FWD_RATES)])
+def test_odd_pillar_count_on_the_fast_kernels(gpu_ctx, drop, interp):
+    """31 pillars (one README pillar dropped: the first, a middle one, the last): the packed layout and the fast kernels take odd
+    pillar counts - the matrices of odd-numbered trades start on 8-byte boundaries (16-byte stores there are legal on gfx950)
+    and the last element of a matrix, whose pair of the flat array would reach into the next trade's matrix, is stored on its
+    own.  Plain, payment-lag and 80-coupon trades; every neighbour of a matrix's last element is checked by the batch parity."""
+    vd = F.README_VALUE_DT
+    tenors = [t for i, t in enumerate(F.TENORS) if i != drop]
+    px = [p for i, p in enumerate(F.GBP_PX) if i != drop]
+    curve = F.gbp_model(vd, interp, px=px, tenors=tenors).curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    assert dc.n_pillars == 31
+    assert _native.curve_layout_host(host.times, host.dfs, host.jac, host.hess)["packed_ok"] == 1
+    for batch in (synthetic.synthesize(vd, 5003, seed=drop), _mixed_batch(vd, 3001, seed=drop + 1)):
+        dt = _native.DeviceTrades(gpu_ctx, batch)
+        ref = port.price(interp.value, host.times, host.dfs, host.jac, host.hess, batch)
+        got = _native.price(gpu_ctx, dc, dt, aggregate=True)
+        assert_batch_parity(got, ref, batch.notional)
+        assert np.allclose(got["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+        only_d = _native.price(gpu_ctx, dc, dt, want_gamma=False)
+        assert_batch_parity(only_d, dict(pv=ref["pv"], delta=ref["delta"]), batch.notional)
+        dt.close()

@@ -23,7 +23,8 @@ extra64 = [f"{y}Y" for y in range(1, 50) if f"{y}Y" not in TENORS]
 tenors64 = sorted(list(TENORS) + extra64, key=years)[:64]
 px64 = [float(np.interp(years(t), base_t, GBP_PX)) if t not in TENORS else GBP_PX[TENORS.index(t)] for t in tenors64]
 for label, model, wide in (("40 pillars", gbp_model(vd, px=px, tenors=tenors), "1"), ("40 pillars, tiled route", gbp_model(vd, px=px, tenors=tenors), "0"),
-                           ("64 pillars", gbp_model(vd, px=px64, tenors=tenors64), "1"), ("32 pillars", gbp_model(vd), "1")):
+                           ("64 pillars", gbp_model(vd, px=px64, tenors=tenors64), "1"), ("32 pillars", gbp_model(vd), "1"),
+                           ("31 pillars (odd count)", gbp_model(vd, px=list(GBP_PX[:13]) + list(GBP_PX[14:]), tenors=list(TENORS[:13]) + list(TENORS[14:])), "1")):
     curve = model.curves.GBP_OIS_SONIA
     host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
     os.environ["ADR_WIDE_KERNEL"] = wide
