@@ -187,3 +187,17 @@ def test_wide_layout_of_curves_with_more_than_32_pillars():
     info32 = _native.curve_layout_host(*(lambda h: (h.times, h.dfs, h.jac, h.hess))(
         build_engine_curve(*(lambda c: (c.swap_rates, c.swap_times, c.year_fracs))(F.gbp_model().curves.GBP_OIS_SONIA))))
     assert info32["wide_chunks"] == 0 and info32["packed_ok"] == 1
+
+
+def test_odd_pillar_counts_keep_the_packed_layout():
+    """31 and 17 pillars: the packed layout (fast kernels) no longer needs an even pillar count - the layout analysis is the
+    same as for the 32-pillar curve minus the dropped pillar (CPU; GPU parity: tests/test_gpu_many_pillars.py)."""
+    from tests import _fixtures as F
+    for drop in (0, 13, 31):
+        tenors = [t for i, t in enumerate(F.TENORS) if i != drop]
+        px = [p for i, p in enumerate(F.GBP_PX) if i != drop]
+        curve = F.gbp_model(F.README_VALUE_DT, px=px, tenors=tenors).curves.GBP_OIS_SONIA
+        h = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+        info = _native.curve_layout_host(h.times, h.dfs, h.jac, h.hess)
+        assert info["packed_ok"] == 1 and info["wide_chunks"] == 0, (drop, info)
+        assert info["core_pillars"] in (16, 17) and 0 < info["lds_bytes"] <= 160 * 1024
