@@ -1,0 +1,46 @@
+"""AddressSanitizer + UBSan run of the native book compilers (csrc/book_host.cpp) on the CPU: random legs under all five
+business-day rules, books with flows at and before the value time, empty and one-leg inputs, the error paths.
+Built and run by tools/asan_book_host.sh (GPU sanitizers are not available on the pool; this code is host-only)."""
+import ctypes as C, numpy as np, sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+lib = C.CDLL(os.environ["ADR_ASAN_LIB"])
+i64p, dp, u8p = C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+P = lambda a, t: a.ctypes.data_as(t)
+from adrates_amd.utils import schedule_np as S, BusDayAdjustTypes
+rng = np.random.default_rng(3)
+for trial in range(6):
+    n = [0, 1, 7, 5000, 20011, 3][trial]
+    eff = rng.integers(36526, 55000, n).astype(np.int64)
+    months = rng.choice([1, 2, 3, 5, 6, 9, 12, 18, 24, 60, 120, 361, 600], n)
+    y, m, d = S.ymd_from_serial(eff) if n else (np.zeros(0, int),) * 3
+    term = (S.serial_of(y * 12 + m - 1 + months, d) + rng.integers(0, 3, n)).astype(np.int64) if n else np.zeros(0, np.int64)
+    mpp = rng.choice([1, 3, 6, 12], n).astype(np.int64); lag = rng.choice([0, 1, 2, 5, -2], n).astype(np.int64)
+    den = rng.choice([365.0, 360.0], n)
+    counts = np.empty(n, np.int64)
+    assert lib.adr_leg_counts_host(C.c_int64(n), P(eff, i64p), P(term, i64p), P(mpp, i64p), P(counts, i64p)) == 0
+    off = np.zeros(n + 1, np.int64); np.cumsum(counts, out=off[1:]); mtot = int(off[-1])
+    tp, ts, te, al = (np.empty(mtot) for _ in range(4)); plain = np.empty(n, np.uint8)
+    for bd in (1, 2, 3, 4, 5):
+        rc = lib.adr_leg_times_host(C.c_int64(n), P(eff, i64p), P(term, i64p), P(mpp, i64p), P(lag, i64p), bd, 1, P(den, dp), C.c_int64(44000), C.c_double(365.0),
+                                    P(off, i64p), P(tp, dp), P(ts, dp), P(te, dp), P(al, dp), P(plain, u8p))
+        assert rc == 0
+    if n:
+        want = S.leg_times_np(eff, term, mpp, lag, BusDayAdjustTypes.MODIFIED_PRECEDING, True, den, 44000, 365)
+        assert np.array_equal(tp, want[1]) and np.array_equal(al, want[4])
+    # assembly
+    for_off = off
+    tpx = tp.copy(); tpx[rng.random(mtot) < 0.05] = 0.0; tpx[rng.random(mtot) < 0.05] = -1.0
+    disc, growth = rng.uniform(0.5, 1, mtot), rng.uniform(1, 1.1, mtot)
+    fn, fs, sg = rng.uniform(1e6, 1e7, n), rng.uniform(0, 0.01, n), rng.choice([-1.0, 1.0], n)
+    ex = rng.choice([0.0, -0.5, 1.0, 7.5], (n, 2)).copy(); on = (rng.random(n) < 0.8).astype(np.uint8)
+    r_off, f_off = np.empty(n + 1, np.int64), np.empty(n + 1, np.int64)
+    r = [np.empty(mtot) for _ in range(4)]; f = [np.empty(mtot + 2 * n) for _ in range(2)]; pv = np.zeros(n)
+    rc = lib.adr_xccy_assemble_host(C.c_int64(n), P(for_off, i64p), P(tpx, dp), P(ts, dp), P(te, dp), P(al, dp), P(disc, dp), P(growth, dp), P(fn, dp), P(fs, dp), P(sg, dp),
+                                    C.c_double(1.27), P(ex, dp), P(on, u8p), P(r_off, i64p), *(P(a, dp) for a in r), P(f_off, i64p), *(P(a, dp) for a in f), P(pv, dp))
+    assert rc == 0
+    print("trial", trial, "n", n, "coupons", mtot, "ok")
+# error paths
+e = np.array([45000], np.int64); t = np.array([45000], np.int64); mp = np.array([12], np.int64); c = np.empty(1, np.int64)
+print("rc same-date:", lib.adr_leg_counts_host(C.c_int64(1), P(e, i64p), P(t, i64p), P(mp, i64p), P(c, i64p)))
+print("rc null:", lib.adr_leg_counts_host(C.c_int64(1), None, None, None, None))
