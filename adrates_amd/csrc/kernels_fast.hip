@@ -674,8 +674,19 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                                 const bool owner = mine && e >= 0 && (e % L) == l;
                                 const double add = owner ? coef * m.lc[j] : 0.0;
                                 const int at = e / L;
+                                if constexpr (CPG < EPG) {
+                                    // exact variants: a short-end knot's pairs are fringe pairs - the last slots - unless its second
+                                    // pillar is a core pillar; the core slots are visited only then
 #pragma unroll
-                                for (int i = 0; i < EPG; ++i) acc[i] += (i == at) ? add : 0.0;
+                                    for (int i = CPG; i < EPG; ++i) acc[i] += (i == at) ? add : 0.0;
+                                    if (__ballot(owner && at < CPG)) {
+#pragma unroll
+                                        for (int i = 0; i < CPG; ++i) acc[i] += (i == at) ? add : 0.0;
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int i = 0; i < EPG; ++i) acc[i] += (i == at) ? add : 0.0;
+                                }
                             }
                         }
                     }
