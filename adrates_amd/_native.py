@@ -62,6 +62,7 @@ _SIGNATURES = {
     "adr_leg_counts_host": (C.c_int, [C.c_int64, _i64p, _i64p, _i64p, _i64p]),
     "adr_leg_times_host": (C.c_int, [C.c_int64, _i64p, _i64p, _i64p, _i64p, C.c_int, C.c_int, _dp, C.c_int64, C.c_double,
                                      _i64p, _dp, _dp, _dp, _dp, C.POINTER(C.c_uint8)]),
+    "adr_exchange_flows_host": (C.c_int, [C.c_int64, _dp, _dp, C.POINTER(C.c_uint8), _dp, C.c_double, _i64p, _dp, _dp, _dp]),
     "adr_xccy_assemble_host": (C.c_int, [C.c_int64, _i64p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp,
                                          C.POINTER(C.c_uint8), _i64p, _dp, _dp, _dp, _dp, _i64p, _dp, _dp, _dp]),
 }
@@ -400,10 +401,25 @@ def leg_times_host(effective, termination, months_per_period, payment_lag, bd_va
     return off, tp, ts, te, al, plain.astype(bool)
 
 
+def exchange_flows_host(exch_t, notional, on, sign, scale):
+    """Notional exchanges of n legs (adr_exchange_flows_host): ``(off, flow_tp, flow_pay, pv_const)``."""
+    exch_t = _f64(exch_t).reshape(-1)
+    notional, sign = _f64(notional), _f64(sign)
+    n = notional.shape[0]
+    on = np.ascontiguousarray(on, dtype=np.uint8)
+    off = np.zeros(n + 1, dtype=np.int64)
+    tp, pay, const = np.empty(2 * n), np.empty(2 * n), np.empty(n)
+    _check(load().adr_exchange_flows_host(n, _ptr(exch_t), _ptr(notional), _ptr(on, C.POINTER(C.c_uint8)), _ptr(sign), float(scale),
+                                          _ptr(off, _i64p), _ptr(tp), _ptr(pay), _ptr(const)), "adr_exchange_flows_host")
+    k = int(off[-1])
+    return off, tp[:k], pay[:k], const
+
+
 def xccy_assemble_host(for_off, tp_x, ts, te, alpha, disc, growth, for_n, for_spread, for_sign, spot, exch_t, exch_on,
                        pv_const):
     """Foreign-leg batches of a cross-currency book (adr_xccy_assemble_host): ``(rates_off, rates_ts, rates_te, rates_alpha,
-    rates_weight, flows_off, flows_tp, flows_pay, pv_const)``; ``pv_const`` comes in with the domestic constants."""
+    rates_weight, flows_off, flows_tp, flows_pay, pv_const)``; ``pv_const`` comes in with the domestic constants.
+    ``disc`` [m + 1]: D_x at the payment times, then at the value time; ``growth`` [2 m]: D_f at the accrual starts, then ends."""
     for_off = np.ascontiguousarray(for_off, dtype=np.int64)
     n, m = for_off.shape[0] - 1, int(for_off[-1])
     cols = [_f64(a) for a in (tp_x, ts, te, alpha, disc, growth, for_n, for_spread, for_sign)]

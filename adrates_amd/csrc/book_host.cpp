@@ -192,8 +192,29 @@ int adr_leg_times_host(int64_t n, const int64_t* eff, const int64_t* term, const
     return ADR_OK;
 }
 
+int adr_exchange_flows_host(int64_t n, const double* exch_t, const double* notional, const uint8_t* on, const double* sign,
+                            double scale, int64_t* off, double* flow_tp, double* flow_pay, double* pv_const) {
+    if (n < 0 || (n > 0 && (!exch_t || !notional || !on || !sign || !off || !flow_tp || !flow_pay || !pv_const)))
+        return adr_set_error(ADR_ERR_INVALID, "adr_exchange_flows_host: bad count / null array");
+    if (off) off[0] = 0;
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double amounts[2] = {-notional[i], notional[i]};
+        double c2[2] = {0.0, 0.0};
+        if (on[i])
+            for (int q = 0; q < 2; ++q) {
+                const double t = exch_t[2 * i + q];
+                if (t > 0.0) { flow_tp[k] = t; flow_pay[k] = amounts[q]; ++k; }
+                if (t == 0.0) c2[q] = sign[i] * amounts[q] / scale;
+            }
+        pv_const[i] = c2[0] + c2[1];
+        off[i + 1] = k;
+    }
+    return ADR_OK;
+}
+
 int adr_xccy_assemble_host(int64_t n, const int64_t* for_off, const double* tp_x, const double* ts, const double* te,
-                           const double* alpha, const double* disc, const double* growth, const double* for_n,
+                           const double* alpha, const double* df_x, const double* df_f, const double* for_n,
                            const double* for_spread, const double* for_sign, double spot, const double* exch_t,
                            const uint8_t* exch_on, int64_t* rates_off, double* rates_ts, double* rates_te,
                            double* rates_alpha, double* rates_weight, int64_t* flows_off, double* flows_tp,
@@ -201,6 +222,9 @@ int adr_xccy_assemble_host(int64_t n, const int64_t* for_off, const double* tp_x
     if (n < 0 || (n > 0 && (!for_off || !for_n || !for_spread || !for_sign || !exch_t || !exch_on || !rates_off || !flows_off || !pv_const)))
         return adr_set_error(ADR_ERR_INVALID, "adr_xccy_assemble_host: bad count / null array");
     if (n == 0) return ADR_OK;
+    const int64_t m = for_off[n];
+    if (m > 0 && (!df_x || !df_f)) return adr_set_error(ADR_ERR_INVALID, "adr_xccy_assemble_host: null discount factors");
+    const double dx0 = m > 0 ? df_x[m] : 1.0;             // D_x at the value time
     // pass 1: how many accruing live coupons (rate ladders) and later flows (coupons paid after the value time, exchanges
     // after the value time) every swap has
     rates_off[0] = 0; flows_off[0] = 0;
@@ -223,10 +247,10 @@ int adr_xccy_assemble_host(int64_t n, const int64_t* for_off, const double* tp_x
             double pv = pv_const[i];
             for (int64_t j = for_off[i]; j < for_off[i + 1]; ++j) {
                 const bool accrues = alpha[j] > 0.0, live = tp_x[j] >= 0.0;
-                const double fwd = accrues ? (growth[j] - 1.0) / alpha[j] : 0.0;
+                const double fwd = accrues ? (df_f[j] / df_f[m + j] - 1.0) / alpha[j] : 0.0;
                 const double amount = (fwd + for_spread[i]) * alpha[j] * for_n[i];
                 if (live && accrues) {
-                    rates_ts[kr] = ts[j]; rates_te[kr] = te[j]; rates_alpha[kr] = alpha[j]; rates_weight[kr] = disc[j];
+                    rates_ts[kr] = ts[j]; rates_te[kr] = te[j]; rates_alpha[kr] = alpha[j]; rates_weight[kr] = df_x[j] / dx0;
                     ++kr;
                 }
                 if (live && tp_x[j] == 0.0) pv += (for_sign[i] * amount) / spot;

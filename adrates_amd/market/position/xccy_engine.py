@@ -269,7 +269,7 @@ def compile_xccy(raw: RawXccy, spot, df_x, df_f):
     ``foreign_rates`` carries `flt_weight`."""
     n = raw.n
     zeros_n, none = np.zeros(n), np.zeros(0)
-    dfix_off, dfix_tp, dfix_pay, pv_const = _exchange_flows(raw.dom_exch_t, raw.dom_n, raw.dom_exch, raw.dom_sign, 1.0)
+    dfix_off, dfix_tp, dfix_pay, pv_const = _native.exchange_flows_host(raw.dom_exch_t, raw.dom_n, raw.dom_exch, raw.dom_sign, 1.0)
     domestic = TradeBatch(dfix_off, raw.dom_off, dfix_tp, dfix_pay, raw.dom_tp, raw.dom_ts, raw.dom_te, raw.dom_al,
                           raw.dom_n, raw.dom_spread, raw.dom_sign, raw.dom_sign)
 
@@ -278,12 +278,10 @@ def compile_xccy(raw: RawXccy, spot, df_x, df_f):
     # `compile_xccy_np` is the array form it replaces, kept as the checker of tests/test_book_native.py)
     tp_x, ts, te, al = raw.for_tpx, raw.for_ts, raw.for_te, raw.for_al
     m = tp_x.shape[0]
-    dx = df_x(np.concatenate((tp_x, [0.0])))                           # one device round trip per curve
-    c = dx[:m] / dx[m]                                                  # relative to the value time
-    df2 = df_f(np.concatenate((ts, te)))
-    growth = df2[:m] / df2[m:]
+    dx = df_x(np.concatenate((tp_x, [0.0])))                           # one device round trip per curve; the native pass takes
+    df2 = df_f(np.concatenate((ts, te)))                               # the ratios D_x(tp) / D_x(0) and D_f(ts) / D_f(te) itself
     (kept_off, k_ts, k_te, k_al, k_c, fix_off, flow_tp, flow_pay, pv_const) = _native.xccy_assemble_host(
-        raw.for_off, tp_x, ts, te, al, c, growth, raw.for_n, raw.for_spread, raw.for_sign, spot, raw.for_exch_t,
+        raw.for_off, tp_x, ts, te, al, dx, df2, raw.for_n, raw.for_spread, raw.for_sign, spot, raw.for_exch_t,
         raw.for_exch, pv_const)
     foreign_rates = TradeBatch(np.zeros(n + 1, dtype=np.int64), kept_off, none, none, np.zeros(k_ts.shape[0]),
                                k_ts, k_te, k_al, raw.for_n, zeros_n, raw.for_sign, raw.for_sign, flt_weight=k_c)

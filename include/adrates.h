@@ -150,16 +150,21 @@ int adr_leg_times_host(int64_t n, const int64_t* eff, const int64_t* term, const
                        double* te, double* alpha, uint8_t* plain);
 /*
  * Foreign leg of n cross-currency basis swaps (CSR for_off over the coupons: payment times on the XCCY curve's day count,
- * accrual start / end times, accrual fractions) given, per coupon, disc = D_x(tp) / D_x(0) off the XCCY curve and
- * growth = D_f(ts) / D_f(te) off the foreign OIS grid (adr_curve_df): (1) the rate-ladder batch - every live accruing coupon
+ * accrual start / end times, accrual fractions) given the discount factors the device returned for them (adr_curve_df):
+ * df_x [m + 1] = D_x at the m payment times, then at the value time; df_f [2 m] = D_f at the m accrual starts, then at the m
+ * accrual ends: (1) the rate-ladder batch - every live accruing coupon
  * with its discount factor as notional multiplier (adr_trades_upload_weighted's flt_weight) -, (2) the fixed flows
  * N (fwd + spread) alpha at tp > 0 followed by the notional exchanges (exch_t [n][2] effective / maturity times, exch_on [n])
  * at t > 0, and (3) pv_const [n] (in: the domestic constants; out: + flows dated at the value time, in domestic currency).
  * Output arrays are sized by the caller for every coupon (rates_*: for_off[n]; flows_*: for_off[n] + 2 n); the offsets
  * ([n + 1]) say what was filled.
  */
+/* The notional exchanges of n legs (exch_t [n][2]: effective / maturity times; on [n]): flows -N, +N at t > 0 as CSR arrays
+ * (off [n + 1]; flow_tp / flow_pay sized 2 n), flows dated AT the value time as pv_const [n] = sum sign * amount / scale. */
+int adr_exchange_flows_host(int64_t n, const double* exch_t, const double* notional, const uint8_t* on, const double* sign,
+                            double scale, int64_t* off, double* flow_tp, double* flow_pay, double* pv_const);
 int adr_xccy_assemble_host(int64_t n, const int64_t* for_off, const double* tp_x, const double* ts, const double* te,
-                           const double* alpha, const double* disc, const double* growth, const double* for_n,
+                           const double* alpha, const double* df_x, const double* df_f, const double* for_n,
                            const double* for_spread, const double* for_sign, double spot, const double* exch_t,
                            const uint8_t* exch_on, int64_t* rates_off, double* rates_ts, double* rates_te,
                            double* rates_alpha, double* rates_weight, int64_t* flows_off, double* flows_tp,

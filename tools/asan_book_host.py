@@ -31,12 +31,12 @@ for trial in range(6):
     # assembly
     for_off = off
     tpx = tp.copy(); tpx[rng.random(mtot) < 0.05] = 0.0; tpx[rng.random(mtot) < 0.05] = -1.0
-    disc, growth = rng.uniform(0.5, 1, mtot), rng.uniform(1, 1.1, mtot)
+    dfx, dff = rng.uniform(0.5, 1, mtot + 1), rng.uniform(0.9, 1.0, 2 * mtot)
     fn, fs, sg = rng.uniform(1e6, 1e7, n), rng.uniform(0, 0.01, n), rng.choice([-1.0, 1.0], n)
     ex = rng.choice([0.0, -0.5, 1.0, 7.5], (n, 2)).copy(); on = (rng.random(n) < 0.8).astype(np.uint8)
     r_off, f_off = np.empty(n + 1, np.int64), np.empty(n + 1, np.int64)
     r = [np.empty(mtot) for _ in range(4)]; f = [np.empty(mtot + 2 * n) for _ in range(2)]; pv = np.zeros(n)
-    rc = lib.adr_xccy_assemble_host(C.c_int64(n), P(for_off, i64p), P(tpx, dp), P(ts, dp), P(te, dp), P(al, dp), P(disc, dp), P(growth, dp), P(fn, dp), P(fs, dp), P(sg, dp),
+    rc = lib.adr_xccy_assemble_host(C.c_int64(n), P(for_off, i64p), P(tpx, dp), P(ts, dp), P(te, dp), P(al, dp), P(dfx, dp), P(dff, dp), P(fn, dp), P(fs, dp), P(sg, dp),
                                     C.c_double(1.27), P(ex, dp), P(on, u8p), P(r_off, i64p), *(P(a, dp) for a in r), P(f_off, i64p), *(P(a, dp) for a in f), P(pv, dp))
     assert rc == 0
     print("trial", trial, "n", n, "coupons", mtot, "ok")
