@@ -35,6 +35,7 @@ _SIGNATURES = {
     "adr_free_ctx": (None, [_vp]),
     "adr_sync": (C.c_int, [_vp]),
     "adr_curve_upload": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.POINTER(_vp)]),
+    "adr_curve_upload_ex": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_uint32, C.POINTER(_vp)]),
     "adr_free_curve": (None, [_vp]),
     "adr_curve_pillars": (C.c_int, [_vp]),
     "adr_curve_tables_host": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, _dp, _i32p, _dp, _dp, _dp]),
@@ -136,7 +137,9 @@ class Context:
 class DeviceCurve:
     """Curve tables resident on the GPU (adr_curve_upload)."""
 
-    def __init__(self, ctx: Context, interp_method: int, times, dfs, jac, hess=None):
+    PILLAR_TILES = 1      # ADR_CURVE_PILLAR_TILES (include/adrates.h)
+
+    def __init__(self, ctx: Context, interp_method: int, times, dfs, jac, hess=None, flags: int = 0):
         times, dfs, jac = _f64(times), _f64(dfs), _f64(jac)
         K, P = jac.shape
         if times.shape != (K,) or dfs.shape != (K,):
@@ -147,8 +150,8 @@ class DeviceCurve:
             if hess_c.shape != (K, P, P):
                 raise LibError("hess must have shape [K, P, P]")
         h = _vp()
-        _check(load().adr_curve_upload(ctx._h, int(interp_method), K, P, _ptr(times), _ptr(dfs), _ptr(jac),
-                                       _ptr(hess_c), C.byref(h)), "adr_curve_upload")
+        _check(load().adr_curve_upload_ex(ctx._h, int(interp_method), K, P, _ptr(times), _ptr(dfs), _ptr(jac),
+                                          _ptr(hess_c), int(flags), C.byref(h)), "adr_curve_upload")
         self._h, self._ctx = h, ctx
         self.n_pillars, self.n_knots = P, K
         self.has_hess = hess is not None

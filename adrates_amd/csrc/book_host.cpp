@@ -14,12 +14,14 @@
 // denominator), or the same sequence of operations the NumPy route performs, so the two routes agree bit for bit
 // (tests/test_book_native.py).
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/adrates.h"
+#include "host_pool.hpp"
 
 int adr_set_error(int status, const std::string& msg);      // capi.hip
 
@@ -120,13 +122,10 @@ inline bool leg_shape(int64_t eff, int64_t term, int64_t mpp, LegShape& s) {
     return month_in_range(t_idx - n_flows * mpp) && month_in_range(t_idx);
 }
 
+// body(first, one past the last) over contiguous ranges (host_pool.hpp: a thread that cannot be started is not an error)
 template <class Body>
 void parallel_ranges(int64_t n, int64_t grain, Body&& body) {
-    const int n_threads = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(std::thread::hardware_concurrency()), 16, n / grain + 1})));
-    std::vector<std::thread> pool;
-    for (int k = 1; k < n_threads; ++k) pool.emplace_back([&, k] { body(n * k / n_threads, n * (k + 1) / n_threads); });
-    body(0, n / n_threads);
-    for (auto& th : pool) th.join();
+    adr::parallel_ranges(n, adr::pool_threads(n, grain), [&body](int, int64_t i0, int64_t i1) { body(i0, i1); });
 }
 
 }  // namespace
@@ -137,20 +136,19 @@ int adr_leg_counts_host(int64_t n, const int64_t* eff, const int64_t* term, cons
                         int64_t* n_coupons) {
     if (n < 0 || (n > 0 && (!eff || !term || !months_per_period || !n_coupons)))
         return adr_set_error(ADR_ERR_INVALID, "adr_leg_counts_host: bad count / null array");
-    std::vector<int> bad;
-    std::vector<char> flag(1, 0);
-    char* failed = flag.data();
+    // one flag per kind of failure, written by any range's thread: the message does not depend on which thread came last
+    std::atomic<bool> out_of_range{false}, not_before{false};
     parallel_ranges(n, 8192, [&](int64_t i0, int64_t i1) {
         for (int64_t i = i0; i < i1; ++i) {
             LegShape s;
-            if (eff[i] < kMinSerial || term[i] < kMinSerial || months_per_period[i] < 1) { *failed = 1; n_coupons[i] = 0; continue; }
-            if (eff[i] >= term[i]) { *failed = 2; n_coupons[i] = 0; continue; }
-            if (!leg_shape(eff[i], term[i], months_per_period[i], s)) { *failed = 1; n_coupons[i] = 0; continue; }
+            if (eff[i] < kMinSerial || term[i] < kMinSerial || months_per_period[i] < 1) { out_of_range.store(true, std::memory_order_relaxed); n_coupons[i] = 0; continue; }
+            if (eff[i] >= term[i]) { not_before.store(true, std::memory_order_relaxed); n_coupons[i] = 0; continue; }
+            if (!leg_shape(eff[i], term[i], months_per_period[i], s)) { out_of_range.store(true, std::memory_order_relaxed); n_coupons[i] = 0; continue; }
             n_coupons[i] = s.n_flows;
         }
     });
-    if (*failed == 2) return adr_set_error(ADR_ERR_INVALID, "adr_leg_counts_host: Effective date must be before termination date.");
-    if (*failed) return adr_set_error(ADR_ERR_INVALID, "adr_leg_counts_host: dates before 1-Mar-1900 or after 2300 are not supported");
+    if (not_before.load()) return adr_set_error(ADR_ERR_INVALID, "adr_leg_counts_host: Effective date must be before termination date.");
+    if (out_of_range.load()) return adr_set_error(ADR_ERR_INVALID, "adr_leg_counts_host: dates before 1-Mar-1900 or after 2300 are not supported");
     return ADR_OK;
 }
 
@@ -162,14 +160,13 @@ int adr_leg_times_host(int64_t n, const int64_t* eff, const int64_t* term, const
                             !alpha || !plain)))
         return adr_set_error(ADR_ERR_INVALID, "adr_leg_times_host: bad count / null array");
     if (bd_type < 1 || bd_type > 5) return adr_set_error(ADR_ERR_INVALID, "adr_leg_times_host: Unknown adjustment convention");
-    std::vector<char> flag(1, 0);
-    char* failed = flag.data();
+    std::atomic<bool> failed{false};
     const bool weekend = weekend_calendar != 0;
     parallel_ranges(n, 4096, [&](int64_t i0, int64_t i1) {
         for (int64_t i = i0; i < i1; ++i) {
             LegShape s;
             if (eff[i] < kMinSerial || eff[i] >= term[i] || months_per_period[i] < 1 ||
-                !leg_shape(eff[i], term[i], months_per_period[i], s) || off[i + 1] - off[i] != s.n_flows) { *failed = 1; plain[i] = 0; continue; }
+                !leg_shape(eff[i], term[i], months_per_period[i], s) || off[i + 1] - off[i] != s.n_flows) { failed.store(true, std::memory_order_relaxed); plain[i] = 0; continue; }
             const int64_t mpp = months_per_period[i];
             const double d = denominator[i], dp = payment_denominator > 0.0 ? payment_denominator : d;
             int64_t prev = eff[i];                       // the previous coupon date: the effective date, never adjusted
@@ -188,7 +185,7 @@ int adr_leg_times_host(int64_t n, const int64_t* eff, const int64_t* term, const
             plain[i] = increasing ? 1 : 0;
         }
     });
-    if (*failed) return adr_set_error(ADR_ERR_INVALID, "adr_leg_times_host: a leg's dates are out of range or its offsets do not match adr_leg_counts_host");
+    if (failed.load()) return adr_set_error(ADR_ERR_INVALID, "adr_leg_times_host: a leg's dates are out of range or its offsets do not match adr_leg_counts_host");
     return ADR_OK;
 }
 
@@ -223,7 +220,11 @@ int adr_xccy_assemble_host(int64_t n, const int64_t* for_off, const double* tp_x
         return adr_set_error(ADR_ERR_INVALID, "adr_xccy_assemble_host: bad count / null array");
     if (n == 0) return ADR_OK;
     const int64_t m = for_off[n];
+    if (m < 0) return adr_set_error(ADR_ERR_INVALID, "adr_xccy_assemble_host: negative coupon count");
     if (m > 0 && (!df_x || !df_f)) return adr_set_error(ADR_ERR_INVALID, "adr_xccy_assemble_host: null discount factors");
+    if (m > 0 && (!tp_x || !ts || !te || !alpha || !rates_ts || !rates_te || !rates_alpha || !rates_weight))
+        return adr_set_error(ADR_ERR_INVALID, "adr_xccy_assemble_host: null coupon array");
+    if (!flows_tp || !flows_pay) return adr_set_error(ADR_ERR_INVALID, "adr_xccy_assemble_host: null flow array");
     const double dx0 = m > 0 ? df_x[m] : 1.0;             // D_x at the value time
     // pass 1: how many accruing live coupons (rate ladders) and later flows (coupons paid after the value time, exchanges
     // after the value time) every swap has

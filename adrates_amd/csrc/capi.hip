@@ -16,6 +16,7 @@
 
 #include "../../include/adrates.h"
 #include "curve_tables.hpp"
+#include "host_pool.hpp"
 #include "kernels.hpp"
 
 namespace {
@@ -107,16 +108,11 @@ struct adr_trades {
     adr::TradesDev lagged{};
     adr::TradesDev lagged_chained{};   // ... those of 33-128 coupons per leg as chains of rows (LONG + LAG), laid out for
     int lagged_chained_blocks = 0;     // this grid
-    int64_t n_lagged = 0, n_lagged_long = 0, n_rest = 0, n_rest_b = 0;
-    const int32_t* list_rest_b = nullptr;     // list_general without the one-row payment-lag trades (the older variant takes only those)
+    int64_t n_lagged = 0, n_lagged_long = 0, n_rest = 0;
     // per-wave stash of the payment-lag variant (kernels.hpp, OutputsDev::lag_scratch), sized for a grid of lag_blocks
     // blocks.  It belongs to the BATCH (not to the ctx): two batches priced on two streams never share it.
     double* lag_scratch = nullptr;
     int lag_blocks = 0;
-    // which payment-lag kernel the chained rows are laid out for: the date-record kernel (kernels_lag.hip, 12 waves per
-    // block; ADR_LAG_KERNEL=dates at upload time) or the older variant of kernels_fast.hip (8 waves per block, the default:
-    // it is the faster of the two on the benchmark portfolios)
-    bool lag_dates = false;
     const int32_t* list_rest = nullptr;
     adr::LiteRowsDev lite{};
     int64_t n_lite = 0, n_nonlite = 0;
@@ -265,8 +261,15 @@ int adr_curve_pillars(const adr_curve* curve) { return curve ? curve->dev.P : 0;
 
 int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double* times, const double* dfs,
                      const double* jac, const double* hess, adr_curve** out) {
+    return adr_curve_upload_ex(ctx, interp_method, K, P, times, dfs, jac, hess, 0u, out);
+}
+
+int adr_curve_upload_ex(adr_ctx* ctx, int interp_method, int K, int P, const double* times, const double* dfs,
+                        const double* jac, const double* hess, uint32_t flags, adr_curve** out) {
     if (!ctx || !out) return fail(ADR_ERR_INVALID, "adr_curve_upload: null ctx/out");
     *out = nullptr;
+    if (flags & ~static_cast<uint32_t>(ADR_CURVE_PILLAR_TILES))
+        return fail(ADR_ERR_INVALID, "adr_curve_upload_ex: unknown flag bits");
     if (interp_method != ADR_INTERP_FLAT_FWD_RATES && interp_method != ADR_INTERP_LINEAR_ZERO_RATES &&
         interp_method != ADR_INTERP_LINEAR_FWD_RATES)
         return fail(ADR_ERR_UNSUPPORTED, "adr_curve_upload: only FLAT_FWD_RATES (1), LINEAR_FWD_RATES (2) and "
@@ -314,8 +317,7 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P, const double
     double *d_lj64 = nullptr, *d_lcflat = nullptr;
     uint32_t *d_went = nullptr, *d_wchunks = nullptr, *d_wsmap = nullptr;
     int32_t *d_wpos = nullptr, *d_worder = nullptr;
-    const char* wide_env = std::getenv("ADR_WIDE_KERNEL");       // "0": keep the tiled route (A/B measurements, tests of that route)
-    const bool wide = t.wide_nch > 0 && t.wide_nch <= adr::kWideMaxChunks && !(wide_env && wide_env[0] == '0') &&
+    const bool wide = t.wide_nch > 0 && t.wide_nch <= adr::kWideMaxChunks && !(flags & ADR_CURVE_PILLAR_TILES) &&
                       adr::wide_kernel_lds_bytes(t.K, t.Kc, t.wide_nch, t.has_hess) <= kLdsBudget;
     if (wide) {
         track(upload(t.lj64, &d_lj64), d_lj64);
@@ -675,14 +677,9 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     // Host side of the upload: validation, the routing class of every trade and the row orders.  All of it is a
     // single pass over the caller's arrays, cut into contiguous trade ranges for a pool of threads; the tables
     // themselves are gathered on the device (trades_build.hip).
-    const int n_threads = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(std::thread::hardware_concurrency()),
-                                                                                 16, n / 4096 + 1})));
-    auto parallel_ranges = [&](auto&& body) {          // body(thread, first trade, one past the last trade)
-        std::vector<std::thread> pool;
-        for (int k = 1; k < n_threads; ++k)
-            pool.emplace_back([&, k] { body(k, n * k / n_threads, n * (k + 1) / n_threads); });
-        body(0, 0, n / n_threads);
-        for (auto& th : pool) th.join();
+    const int n_threads = adr::pool_threads(n, 4096);
+    auto parallel_ranges = [&](auto&& body) {          // body(range, first trade, one past the last trade); host_pool.hpp
+        adr::parallel_ranges(n, n_threads, body);
     };
     // the offsets index the caller's arrays: check them before anything walks those arrays
     {
@@ -773,10 +770,6 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     adr_trades* tr = new (std::nothrow) adr_trades();
     if (!tr) return fail(ADR_ERR_NOMEM, "adr_trades_upload: out of memory");
     tr->ctx = ctx;
-    {
-        const char* which = std::getenv("ADR_LAG_KERNEL");
-        tr->lag_dates = which && std::string(which) == "dates";
-    }
     tr->n_fix_flows = n_fix;
     tr->n_flt_flows = n_flt;
     hipError_t e = hipSuccess;
@@ -936,24 +929,22 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     tr->n_lagged = static_cast<int64_t>(list_lagged.size());
     tr->n_rest = static_cast<int64_t>(list_rest.size());
     tr->list_rest = static_cast<const int32_t*>(put(list_rest.data(), list_rest.size() * sizeof(int32_t)));
-    {
-        std::vector<int32_t> rest_b;
-        for (int32_t t : list_general) if (rows_of(t) > 1) rest_b.push_back(t);
-        tr->n_rest_b = static_cast<int64_t>(rest_b.size());
-        tr->list_rest_b = put32(std::move(rest_b));
-    }
     if (!list_lagged_long.empty()) {   // payment-lag legs of 33-128 coupons: chains of rows for the grid of the variant
         tr->lagged_chained_blocks = std::max(1, ctx->n_cu);
         build_chained(list_lagged_long, tr->lagged_chained, tr->lagged_chained_blocks,
-                      (tr->lag_dates ? adr::lag_kernel_threads() : adr::fast_kernel_threads(true)) / 64, true);
+                      adr::fast_kernel_threads(true) / 64, true);
     }
     if (!list_lagged.empty() || !list_lagged_long.empty()) {
-        const int blocks = std::max(1, ctx->n_cu);
+        // sized for the grids these rows can be launched on: the chained rows' fixed grid, or as many blocks as the
+        // one-row trades fill (557 KB per block: a batch with a handful of such trades must not pin 143 MB)
+        const int waves = adr::fast_kernel_threads(true) / 64, G = adr::fast_kernel_groups();
+        const int64_t units = (static_cast<int64_t>(list_lagged.size()) + G - 1) / G;
+        const int need = static_cast<int>(std::min<int64_t>(std::max(1, ctx->n_cu), (units + waves - 1) / waves));
+        const int blocks = std::max({1, need, list_lagged_long.empty() ? 0 : tr->lagged_chained_blocks});
         if (e == hipSuccess) {
-            // per-wave scratch of the payment-lag kernels: kernels_lag.hip keeps the side rows beyond its register slots and
-            // their book totals there (and expects zeros), the older variant of kernels_fast.hip its special nodes' stash
+            // per-wave scratch of the payment-lag variant: its special nodes' stash
             void* p = nullptr;
-            const size_t bytes = std::max(adr::fast_kernel_lag_scratch_bytes(blocks), adr::lag_kernel_scratch_bytes(blocks));
+            const size_t bytes = adr::fast_kernel_lag_scratch_bytes(blocks);
             e = hipMalloc(&p, bytes);
             if (e == hipSuccess) { tr->allocations.push_back(p); tr->lag_scratch = static_cast<double*>(p); tr->lag_blocks = blocks; }
             if (e == hipSuccess) e = hipMemsetAsync(p, 0, bytes, stream);
@@ -1196,9 +1187,6 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     adr::TradesDev fast = trades->dev, chained = trades->chained, general = trades->dev, lagged = trades->lagged,
                    lagged_long = trades->lagged_chained;
     // (the payment-lag variant's ratio nodes are single exponentials: not under LINEAR_FWD_RATES, which go to the general kernel)
-    // kernels_lag.hip takes them on curves with the hub layout (chained rows included: they are laid out for its grid);
-    // other packed curves keep the older variant of kernels_fast.hip for the one-row trades
-    const bool new_lag = trades->lag_dates && adr::lag_kernel_takes(curve->dev);
     const bool use_lag = want_gamma && use_fast && (lagged.n_rows > 0 || lagged_long.n_rows > 0) && trades->lag_scratch != nullptr &&
                          curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES && curve->dev.P % 2 == 0 &&
                          trades->lagged_chained_blocks <= trades->lag_blocks;
@@ -1206,10 +1194,6 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     // with an odd row length a pair of the flat array can straddle two rows; such curves leave their payment-lag trades with
     // GAMMA to the general kernel, everything else takes the fast kernels)
     if (!use_lag) { lagged.n_rows = 0; lagged_long.n_rows = 0; }
-    // (chained rows are laid out for one kernel's grid: a batch uploaded for the date-record kernel on a curve that kernel
-    // does not take leaves its chained payment-lag trades to the general kernel)
-    const bool lag_long_general = use_lag && trades->lag_dates && !new_lag && lagged_long.n_rows > 0;
-    if (lag_long_general) lagged_long.n_rows = 0;
     // (the lite kernel's payment-lag rows: PV / PV + delta of trades with payment lag or per-coupon notionals, log-linear schemes)
     const bool use_lite_lag = !want_gamma && lite_fits && trades->lite_lag.n_units > 0 && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
     if (use_lite || use_lite_lag) {
@@ -1227,15 +1211,15 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
             }
         }
     } else if (use_fast) {
-        general.list = use_lag ? (lag_long_general ? trades->list_rest_b : trades->list_rest) : trades->list_general;
-        general.n_list = use_lag ? (lag_long_general ? trades->n_rest_b : trades->n_rest) : trades->n_general;
+        general.list = use_lag ? trades->list_rest : trades->list_general;
+        general.n_list = use_lag ? trades->n_rest : trades->n_general;
     } else {
         fast.n_rows = 0; chained.n_rows = 0;   // general walks all n trades through the identity list
     }
     int blocks_fast = 0, blocks_chained = 0, blocks_general = 0, blocks_lite = 0, blocks_lag = 0, blocks_litelag = 0, blocks_laglong = 0;
     if (lagged_long.n_rows > 0) blocks_laglong = trades->lagged_chained_blocks;    // the chains are laid out for this grid
     if (lagged.n_rows > 0) {
-        const int waves = (new_lag ? adr::lag_kernel_threads() : adr::fast_kernel_threads(true)) / 64;
+        const int waves = adr::fast_kernel_threads(true) / 64;
         const int64_t units = (lagged.n_rows + adr::fast_kernel_groups() - 1) / adr::fast_kernel_groups();
         const int64_t need = (units + waves - 1) / waves;
         blocks_lag = static_cast<int>(std::min<int64_t>(need, std::min(trades->lag_blocks, ctx->n_cu)));
@@ -1289,8 +1273,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     if (blocks_lag > 0) {
         o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general);
         o.lag_scratch = trades->lag_scratch;
-        if (new_lag) ADR_HIP(adr::launch_price_lag(curve->dev, lagged, o, blocks_lag, stream));
-        else ADR_HIP(adr::launch_price_fast(curve->dev, lagged, o, want_delta, want_gamma, blocks_lag, stream));
+        ADR_HIP(adr::launch_price_fast(curve->dev, lagged, o, want_delta, want_gamma, blocks_lag, stream));
     }
     if (blocks_litelag > 0) {
         o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag);
@@ -1299,8 +1282,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     if (blocks_laglong > 0) {
         o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag);
         o.lag_scratch = trades->lag_scratch;
-        if (new_lag) ADR_HIP(adr::launch_price_lag(curve->dev, lagged_long, o, blocks_laglong, stream));
-        else ADR_HIP(adr::launch_price_fast(curve->dev, lagged_long, o, want_delta, want_gamma, blocks_laglong, stream));
+        ADR_HIP(adr::launch_price_fast(curve->dev, lagged_long, o, want_delta, want_gamma, blocks_laglong, stream));
     }
     if (agg_dev)
         ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag + blocks_laglong,

@@ -265,13 +265,6 @@ hipError_t launch_reduce_wide(const CurveDev& cv, const double* partials, int n_
 hipError_t launch_price_fast(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                              bool want_gamma, int n_blocks, hipStream_t stream);
 hipError_t launch_curve_df(const CurveDev& cv, int64_t n, const double* t_dev, double* df_dev, int n_cu, hipStream_t stream);
-// payment-lag kernel (kernels_lag.hip): curves with the packed hub layout, log-linear schemes
-bool lag_kernel_takes(const CurveDev& cv);
-int lag_kernel_threads();
-size_t lag_kernel_scratch_bytes(int n_blocks);
-size_t lag_kernel_lds_bytes(const CurveDev& cv);
-hipError_t set_lag_kernel_lds_limit(size_t bytes);
-hipError_t launch_price_lag(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, int n_blocks, hipStream_t stream);
 size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta);
 hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const OutputsDev& out, bool want_delta,
                              int n_blocks, hipStream_t stream);

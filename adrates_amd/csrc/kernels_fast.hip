@@ -1324,8 +1324,6 @@ hipError_t set_kernel_lds_limits(size_t general_bytes, size_t fast_bytes) {
     if (e != hipSuccess) return e;
     e = set_fast_lindf_lds_limit(fast_bytes);
     if (e != hipSuccess) return e;
-    e = set_lag_kernel_lds_limit(fast_bytes);
-    if (e != hipSuccess) return e;
     std::vector<const void*> fns;
     collect_gamma_kernels<true, false, false>(fns);
     collect_gamma_kernels<false, false, false>(fns);

@@ -50,8 +50,7 @@ typedef enum adr_status {
  * (cavour/utils/global_types.py:76-84) accepted by simple_interpolate
  * (cavour/market/curves/interpolator_ad.py:227-235). */
 #define ADR_INTERP_FLAT_FWD_RATES 1
-#define ADR_INTERP_LINEAR_FWD_RATES 2   /* linear in the knot DFs: the fast / lite kernels built for it; payment-lag or weighted
-                                           coupons under this scheme go to the general kernel */
+#define ADR_INTERP_LINEAR_FWD_RATES 2
 #define ADR_INTERP_LINEAR_ZERO_RATES 4
 
 /* Request mask bits: RequestTypes.VALUE / DELTA / GAMMA (cavour/utils/global_types.py:69-74). */
@@ -59,19 +58,14 @@ typedef enum adr_status {
 #define ADR_REQ_DELTA 2u
 #define ADR_REQ_GAMMA 4u
 
-/* Largest pillar count (the reference has none, cavour/market/position/engine.py:2388-2389).  Curves of up to 32
- * pillars take the fast kernels.  Curves of 33-64 pillars take the WIDE variants of the general kernel: one wavefront holds
- * the whole delta ladder (lane = pillar), the gamma matrix is accumulated as its packed upper triangle and written once -
- * one launch per request, every trade type and all three schemes; PV / PV + DELTA requests run on 64-pillar instantiations
- * of the delta-only kernel.  40 pillars: 111 M trades/s with GAMMA, 960 M with DELTA (profiles/r03_many_pillars_bench.json;
- * 26 M / 244 M on the tiled route it replaces), 64 pillars: 44 M / 914 M.  A curve
- * whose wide tables exceed the LDS of a CU (several hundred reachable knots), or a curve uploaded with ADR_WIDE_KERNEL=0
- * in the environment, is priced by the general kernel once per pair of 32-pillar tiles instead: 3 launches for GAMMA, 2
- * for DELTA, 1 for VALUE alone.  Odd pillar counts take the fast kernels too (their 16-byte stores are legal on 8-byte
- * boundaries on gfx950; the last element of a matrix is stored on its own): 31 pillars 354 M trades/s with GAMMA against
- * 93 M on the general kernel before; only payment-lag trades with GAMMA stay on the general kernel there.  The device curve builder (adr_curve_plan_create) takes the same 64: curves it
- * builds on 33-64 pillars carry the wide layout's tables only. */
+/* Largest pillar count of a curve (the reference has no limit, cavour/market/position/engine.py:2388-2389); larger
+ * curves are refused with ADR_ERR_UNSUPPORTED.  Results do not depend on the pillar count's parity or on which kernel
+ * family a curve is routed to (DESIGN.md section 5 describes the routes and their measured rates). */
 #define ADR_MAX_PILLARS 64
+
+/* Flags of adr_curve_upload_ex. */
+#define ADR_CURVE_PILLAR_TILES 1u   /* curves of 33-64 pillars: price on 32-pillar tiles (one launch per tile pair) even when
+                                       the single-launch layout fits the LDS; same results to rounding (diagnostics, A/B) */
 
 int adr_version(void);
 const char* adr_last_error(void);
@@ -97,6 +91,11 @@ int adr_curve_upload(adr_ctx* ctx, int interp_method, int K, int P,
                      const double* times, const double* dfs,
                      const double* jac, const double* hess,
                      adr_curve** out);
+/* The same with explicit layout flags (ADR_CURVE_*); adr_curve_upload is flags = 0. */
+int adr_curve_upload_ex(adr_ctx* ctx, int interp_method, int K, int P,
+                        const double* times, const double* dfs,
+                        const double* jac, const double* hess,
+                        uint32_t flags, adr_curve** out);
 void adr_free_curve(adr_curve* curve);
 int adr_curve_pillars(const adr_curve* curve);
 
@@ -224,8 +223,6 @@ void adr_free_curve_set(adr_curve_set* set);
  * device once, and the kernels' padded row tables are gathered from them ON THE DEVICE (trades_build.hip):
  * about 40 ms per million benchmark trades.  Blocks until the batch is usable; may be called from several
  * host threads on one ctx (it touches no shared state of the ctx but its stream).
- * Legs of up to 384 coupons take the fast paths (payment-lag legs with GAMMA: up to 128); environment variable
- * ADR_LAG_KERNEL=dates lays the chained payment-lag rows out for the date-record kernel (kernels_lag.hip).
  */
 int adr_trades_upload(adr_ctx* ctx, int64_t n_trades,
                       const int64_t* fix_off, const int64_t* flt_off,

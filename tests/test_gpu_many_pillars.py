@@ -1,7 +1,7 @@
 """Curves with more than 32 pillars, and with an odd pillar count (the reference has no pillar limit,
 cavour/market/position/engine.py:2388-2389).  33-64 pillars: the wide variants of the general kernel (one wavefront = 64
 pillars, the whole ladder in one launch; include/adrates.h, ADR_MAX_PILLARS), or - when the wide tables do not fit the
-LDS, or with ADR_WIDE_KERNEL=0 at upload - the general kernel once per pair of 32-pillar tiles; a 17-pillar curve takes
+LDS, or with ADR_CURVE_PILLAR_TILES at upload - the general kernel once per pair of 32-pillar tiles; a 17-pillar curve takes
 the general kernel for gamma (the fast kernel stores matrices as 16-byte pairs) and the lite kernel for delta."""
 import numpy as np
 import pytest
@@ -127,9 +127,9 @@ def test_wide_kernel_block_counts_vs_c_oracle(gpu_ctx, P, interp):
     print(f"{P} pillars, {interp.name}: worst error {worst:.2e}")
 
 
-def test_tiled_route_still_serves_wide_curves(gpu_ctx, monkeypatch):
-    """ADR_WIDE_KERNEL=0 at upload: the general kernel once per pair of 32-pillar tiles - the route of curves whose wide
-    tables do not fit the LDS.  Same numbers as the wide route, to rounding."""
+def test_tiled_route_still_serves_wide_curves(gpu_ctx):
+    """ADR_CURVE_PILLAR_TILES at upload (adr_curve_upload_ex): the general kernel once per pair of 32-pillar tiles - the route
+    of curves whose wide tables do not fit the LDS.  Same numbers as the wide route, to rounding."""
     vd = F.README_VALUE_DT
     px, tenors = forty_pillar_quotes()
     curve = F.gbp_model(vd, px=px, tenors=tenors).curves.GBP_OIS_SONIA
@@ -137,9 +137,7 @@ def test_tiled_route_still_serves_wide_curves(gpu_ctx, monkeypatch):
     dt = _native.DeviceTrades(gpu_ctx, batch)
     host, dc_wide = _device_curve(gpu_ctx, curve)
     wide = _native.price(gpu_ctx, dc_wide, dt, aggregate=True)
-    monkeypatch.setenv("ADR_WIDE_KERNEL", "0")
-    _, dc_tiled = _device_curve(gpu_ctx, curve)
-    monkeypatch.delenv("ADR_WIDE_KERNEL")
+    _, dc_tiled = _device_curve(gpu_ctx, curve, flags=_native.DeviceCurve.PILLAR_TILES)
     tiled = _native.price(gpu_ctx, dc_tiled, dt, aggregate=True)
     ref = port.price(4, host.times, host.dfs, host.jac, host.hess, batch)
     assert_batch_parity(tiled, ref, batch.notional)

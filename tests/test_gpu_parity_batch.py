@@ -23,9 +23,9 @@ pytestmark = pytest.mark.gpu
 ALL = [RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA]
 
 
-def _device_curve(ctx, curve):
+def _device_curve(ctx, curve, flags=0):
     host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
-    return host, _native.DeviceCurve(ctx, curve._interp_type.value, host.times, host.dfs, host.jac, host.hess)
+    return host, _native.DeviceCurve(ctx, curve._interp_type.value, host.times, host.dfs, host.jac, host.hess, flags=flags)
 
 
 @pytest.mark.parametrize("interp", [InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES, InterpTypes.LINEAR_FWD_RATES])
@@ -526,11 +526,10 @@ def test_monthly_legs_of_up_to_360_coupons_vs_c_oracle(gpu_ctx):
     print(f"monthly legs: worst error {worst:.2e}")
 
 
-def test_date_record_payment_lag_kernel_vs_c_oracle(gpu_ctx, monkeypatch):
-    """kernels_lag.hip - two lanes per coupon, one 64-byte date record per coupon, side rows for the special nodes, three
-    waves per SIMD - is an opt-in (ADR_LAG_KERNEL=dates when the batch is uploaded; the older variant of kernels_fast.hip
-    is faster on the benchmark books): same numbers on a mixed payment-lag book with chained rows,
-    seasoned and forward-starting trades, spreads, all lags, and on the book aggregates."""
+def test_mixed_payment_lag_book_vs_c_oracle(gpu_ctx):
+    """A mixed payment-lag book - chained rows (legs of up to 360 coupons), seasoned and forward-starting trades, spreads,
+    lags of 0 to 10 business days, two day counts - per trade and on the book aggregates, with and without the per-trade
+    outputs (the payment-lag variant of the fast kernel, its chained rows and the general kernel behind it)."""
     from adrates_amd.trades.compiler import OISTerms, compile_ois_terms
     from adrates_amd.utils import BusDayAdjustTypes, CurrencyTypes, CurveTypes, DayCountTypes, FrequencyTypes
     vd = F.README_VALUE_DT
@@ -549,7 +548,6 @@ def test_date_record_payment_lag_kernel_vs_c_oracle(gpu_ctx, monkeypatch):
                      float_spread=np.where(rng.random(n) < 0.3, rng.uniform(-0.002, 0.004, n), 0.0),
                      payment_lag=rng.choice([0, 1, 2, 5, 10], size=n), bd_type=BusDayAdjustTypes.MODIFIED_FOLLOWING)
     batch = compile_ois_terms(terms, vd)
-    monkeypatch.setenv("ADR_LAG_KERNEL", "dates")
     for interp in (InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES):
         curve = F.gbp_model(vd, interp).curves.GBP_OIS_SONIA
         host, dc = _device_curve(gpu_ctx, curve)
@@ -562,4 +560,4 @@ def test_date_record_payment_lag_kernel_vs_c_oracle(gpu_ctx, monkeypatch):
         only_agg = _native.price(gpu_ctx, dc, dt, per_trade=False, aggregate=True)
         assert np.allclose(only_agg["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
         dt.close()
-        print(f"date-record kernel, {interp.name}: worst error {worst:.2e}")
+        print(f"mixed payment-lag book, {interp.name}: worst error {worst:.2e}")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput on curves of more than 32 pillars - 40 and 64 pillars on the wide variants of the general kernel (one launch),
-the 40-pillar curve again on the tiled route (ADR_WIDE_KERNEL=0 at upload: one launch per pair of 32-pillar tiles) - and on
+the 40-pillar curve again on the tiled route (ADR_CURVE_PILLAR_TILES at upload: one launch per pair of 32-pillar tiles) - and on
 the 32-pillar curve for comparison: 100 000 benchmark trades, PV + delta + gamma and PV + delta."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,8 +27,8 @@ for label, model, wide in (("40 pillars", gbp_model(vd, px=px, tenors=tenors), "
                            ("31 pillars (odd count)", gbp_model(vd, px=list(GBP_PX[:13]) + list(GBP_PX[14:]), tenors=list(TENORS[:13]) + list(TENORS[14:])), "1")):
     curve = model.curves.GBP_OIS_SONIA
     host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
-    os.environ["ADR_WIDE_KERNEL"] = wide
-    dc = _native.DeviceCurve(ctx, 4, host.times, host.dfs, host.jac, host.hess)
+    dc = _native.DeviceCurve(ctx, 4, host.times, host.dfs, host.jac, host.hess,
+                             flags=0 if wide == "1" else _native.DeviceCurve.PILLAR_TILES)
     P = dc.n_pillars
     pv = torch.empty(n, dtype=torch.float64, device=dev); de = torch.empty((n, P), dtype=torch.float64, device=dev)
     ga = torch.empty((n, P, P), dtype=torch.float64, device=dev); ag = torch.empty(1 + P + P * P, dtype=torch.float64, device=dev)

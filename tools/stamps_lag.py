@@ -26,12 +26,10 @@ ga = torch.empty((n, P, P), dtype=torch.float64, device=dev); ag = torch.empty(1
 lib = _native.load()
 lib.adr_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 _native.price_dev(ctx, dc, dt, 7, pv.data_ptr(), de.data_ptr(), ga.data_ptr(), ag.data_ptr()); ctx.sync()
-dates = os.environ.get("ADR_LAG_KERNEL") == "dates"      # kernels_lag.hip (opt-in) or the payment-lag variant of kernels_fast.hip
-nw = 256 * (12 if dates else 8)
+nw = 256 * 8
 buf = np.zeros((nw, 8), dtype=np.uint64)
 lib.adr_debug_stamps(ctx._h, buf.ctypes.data_as(C.c_void_p), nw)
 tot = buf.sum(0).astype(float)
-names = (["input wait", "chunk build", "date walk", "irregular + fixed passes", "results: loads, totals", "results: expansion, stores", "-", "-"] if dates else
-         ["input wait", "folding", "lookup+exp (chunk build)", "walk: entry / exit", "outputs", "walk: record, Jacobian rows, loop tail", "walk: v, first-order sums, convexity coefficient", "walk: rank-one updates"])
+names = ["input wait", "folding", "lookup+exp (chunk build)", "walk: entry / exit", "outputs", "walk: record, Jacobian rows, loop tail", "walk: v, first-order sums, convexity coefficient", "walk: rank-one updates"]
 print("cycles per wave:", int(buf.sum(1).mean()))
 for nm, v in zip(names, tot[:8]): print(f"   {nm:26s} {100 * v / tot.sum():5.1f} %")
