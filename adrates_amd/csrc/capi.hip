@@ -60,7 +60,16 @@ struct adr_ctx {
     double* dump = nullptr;                 // [32*32] store sink (kernels.hpp, OutputsDev::dump)
     unsigned long long* stamps = nullptr;   // diagnostic builds: [max_blocks*16][8]
     int max_blocks = 0;
+    // aggregate-only mode (kernels_knot.hip): block records [knot_blocks][1 + 3 Kc] of the knot-space kernel and their sum
+    double* knot_partials = nullptr;
+    double* knot_reduced = nullptr;
+    int knot_blocks = 0;
 };
+
+namespace {
+constexpr int kKnotMaxKc = 640;             // reachable knots a curve can have (its dense 32-wide Jacobian must fit the LDS)
+constexpr int kKnotStrideMax = 1 + 3 * kKnotMaxKc;
+}
 
 struct adr_curve {
     adr_ctx* ctx = nullptr;
@@ -169,11 +178,18 @@ int adr_init(int device_ordinal, adr_ctx** out) {
         hipFree(ctx->partials); hipStreamDestroy(ctx->stream); delete ctx;
         return fail_hip(e, "hipMalloc(dump)");
     }
+    ctx->knot_blocks = std::max(1, ctx->n_cu) * adr::kLiteWavesPerSimd * 4 * 64 / adr::kLiteThreads;   // blocks resident at once
+    e = hipMalloc(reinterpret_cast<void**>(&ctx->knot_partials), sizeof(double) * static_cast<size_t>(ctx->knot_blocks + 1) * kKnotStrideMax);
+    if (e != hipSuccess) {
+        hipFree(ctx->dump); hipFree(ctx->partials); hipStreamDestroy(ctx->stream); delete ctx;
+        return fail_hip(e, "hipMalloc(knot partials)");
+    }
+    ctx->knot_reduced = ctx->knot_partials + static_cast<size_t>(ctx->knot_blocks) * kKnotStrideMax;
     // Dynamic-LDS ceiling of every kernel instantiation, once per device: the whole 160 KiB of a CU.  (Setting it per
     // uploaded curve to that curve's need would LOWER it below what an earlier, larger curve's launches request.)
     e = adr::set_kernel_lds_limits(kLdsBudget, kLdsBudget);
     if (e != hipSuccess) {
-        hipFree(ctx->dump); hipFree(ctx->partials); hipStreamDestroy(ctx->stream); delete ctx;
+        hipFree(ctx->knot_partials); hipFree(ctx->dump); hipFree(ctx->partials); hipStreamDestroy(ctx->stream); delete ctx;
         return fail_hip(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
 #ifdef ADR_STAMPS
@@ -196,6 +212,7 @@ void adr_free_ctx(adr_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->partials) hipFree(ctx->partials);
     if (ctx->dump) hipFree(ctx->dump);
+    if (ctx->knot_partials) hipFree(ctx->knot_partials);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1089,6 +1106,27 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     o.delta = (req_mask & ADR_REQ_DELTA) ? delta_dev : nullptr;
     o.gamma = want_gamma ? gamma_dev : nullptr;
 
+    // Aggregate-only request (agg_dev and no per-trade output - Portfolio.compute's single ladder): the trades of the lite
+    // table (no payment lag, at most 32 coupons per leg) are summed in KNOT space and projected once per launch
+    // (kernels_lite.hip KNOT instantiations, kernels_knot.hip); every other trade takes its usual kernel with the stores off,
+    // and the projection adds to what their reduction wrote.
+    const bool agg_only = agg_dev && !o.pv && !o.delta && !o.gamma;
+    const bool use_knot = agg_only && want_delta && trades->lite.n_units > 0 && 1 + 3 * curve->dev.Kc <= kKnotStrideMax &&
+                          adr::knot_kernel_lds_bytes(curve->dev, want_gamma) <= kLdsBudget;
+    auto knot_pass = [&]() -> int {      // after agg_dev has been written (or zeroed): agg_dev += the lite table's trades
+        const size_t lds = adr::knot_kernel_lds_bytes(curve->dev, want_gamma);
+        const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
+        const int waves = adr::knot_kernel_threads() / 64;
+        const int64_t need = (trades->lite.n_units + waves - 1) / waves;
+        const int blocks = static_cast<int>(std::min<int64_t>({need, static_cast<int64_t>(ctx->n_cu) * per_cu, static_cast<int64_t>(ctx->knot_blocks)}));
+        adr::OutputsDev ok{};
+        ok.knot_partials = ctx->knot_partials;
+        ADR_HIP(adr::launch_price_knot(curve->dev, trades->lite, ok, want_gamma, blocks, stream));
+        ADR_HIP(adr::launch_knot_project(curve->dev, ctx->knot_partials, blocks, ctx->knot_reduced, want_delta, want_gamma, agg_dev, stream));
+        return ADR_OK;
+    };
+    const size_t agg_bytes = sizeof(double) * (1 + P + static_cast<size_t>(P) * P);
+
     if (curve->dev.T > 1 && curve->dev.wide_nch > 0) {
         // More than 32 pillars, one launch for the whole ladder.  GAMMA: the wide variants of the general kernel - a
         // wavefront of 64 lanes holds the delta ladder, the gamma matrix is accumulated on its packed upper triangle.
@@ -1097,7 +1135,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         // the rest.
         const int stride = adr::wide_partial_doubles(curve->dev.wide_nch);
         const bool lite_fits = adr::lite_kernel_lds_bytes(curve->dev, want_delta) <= kLdsBudget;
-        const bool use_lite = !want_gamma && lite_fits && trades->lite.n_units > 0;
+        const bool use_lite = (!want_gamma && lite_fits && trades->lite.n_units > 0) || use_knot;     // the lite table's trades are priced elsewhere
         const bool use_lite_lag = !want_gamma && lite_fits && trades->lite_lag.n_units > 0 && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
         adr::TradesDev rest = trades->dev;
         rest.list = nullptr; rest.n_list = n;
@@ -1114,7 +1152,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
             const int64_t need = (lt.n_units + adr::kLiteThreads / 64 - 1) / (adr::kLiteThreads / 64);
             return static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * per_cu));
         };
-        if (use_lite) blocks_lite = lite_blocks(trades->lite);
+        if (use_lite && !use_knot) blocks_lite = lite_blocks(trades->lite);
         if (use_lite_lag) blocks_litelag = lite_blocks(trades->lite_lag);
         if (rest.n_list > 0) {
             const size_t lds = adr::wide_kernel_lds_bytes(curve->dev.K, curve->dev.Kc, curve->dev.wide_nch, want_gamma);
@@ -1138,7 +1176,9 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
             o.block_partials = partials_at(blocks_lite + blocks_litelag);
             ADR_HIP(adr::launch_price_wide(curve->dev, rest, o, want_delta, want_gamma, blocks_wide, stream));
         }
-        if (agg_dev) ADR_HIP(adr::launch_reduce_wide(curve->dev, ctx->partials, blocks, want_delta, want_gamma, agg_dev, stream));
+        if (agg_dev && blocks > 0) ADR_HIP(adr::launch_reduce_wide(curve->dev, ctx->partials, blocks, want_delta, want_gamma, agg_dev, stream));
+        if (agg_dev && blocks == 0) ADR_HIP(hipMemsetAsync(agg_dev, 0, agg_bytes, stream));
+        if (use_knot) return knot_pass();
         return ADR_OK;
     }
     if (curve->dev.T > 1) {
@@ -1152,6 +1192,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         if (blocks * n_launch > ctx->max_blocks) return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
         adr::TradesDev all = trades->dev;
         all.list = nullptr; all.n_list = n;
+        if (use_knot) { all.list = trades->list_nonlite; all.n_list = trades->n_nonlite; }
         const size_t pair_tile = static_cast<size_t>(curve->dev.Kc) * 64 * adr::kGammaPerLane;
         int launch = 0;
         if (agg_dev)   // tiles no launch covers (no GAMMA: the off-diagonal ones; PV alone: every delta tile) stay zero
@@ -1160,6 +1201,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
             for (int ti = 0; ti <= tj; ++ti) {
                 if (!want_gamma && ti != tj) continue;               // PV / delta live on the diagonal tiles
                 if (!want_delta && tj > 0) continue;                 // PV alone: tile (0, 0) has it
+                if (all.n_list == 0) continue;                       // (every trade sits in the lite table: the knot pass has them)
                 adr::CurveDev cv = curve->dev;
                 cv.tile_i = ti; cv.tile_j = tj;
                 if (cv.lc_lanes) cv.lc_lanes += static_cast<size_t>(adr::tile_pair(ti, tj)) * pair_tile;
@@ -1170,6 +1212,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
                     ADR_HIP(adr::launch_reduce_partials(o.block_partials, blocks, P, want_gamma, agg_dev, stream, ti, tj));
                 ++launch;
             }
+        if (use_knot) return knot_pass();
         return ADR_OK;
     }
 
@@ -1196,14 +1239,15 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     if (!use_lag) { lagged.n_rows = 0; lagged_long.n_rows = 0; }
     // (the lite kernel's payment-lag rows: PV / PV + delta of trades with payment lag or per-coupon notionals, log-linear schemes)
     const bool use_lite_lag = !want_gamma && lite_fits && trades->lite_lag.n_units > 0 && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
-    if (use_lite || use_lite_lag) {
-        if (use_lite) fast.n_rows = 0;                     // the lite table holds exactly the 32-slot row table's trades
+    const bool lite_elsewhere = use_lite || use_knot;      // the lite table's trades: the lite kernel, or the knot pass
+    if (!want_gamma && (lite_elsewhere || use_lite_lag)) {
+        if (lite_elsewhere) fast.n_rows = 0;               // the lite table holds exactly the 32-slot row table's trades
         if (use_fast) {                                    // long trades keep their chained rows
             general.list = use_lite_lag ? trades->list_general_b : trades->list_general;
             general.n_list = use_lite_lag ? trades->n_general_b : trades->n_general;
         } else {                                           // no packed layout: long trades join the general list
             fast.n_rows = 0; chained.n_rows = 0;
-            if (use_lite) {
+            if (lite_elsewhere) {
                 general.list = use_lite_lag ? trades->list_nonlite_b : trades->list_nonlite;
                 general.n_list = use_lite_lag ? trades->n_nonlite_b : trades->n_nonlite;
             } else {        // no plain lite rows means no trade is outside list_nonlite
@@ -1213,8 +1257,10 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     } else if (use_fast) {
         general.list = use_lag ? trades->list_rest : trades->list_general;
         general.n_list = use_lag ? trades->n_rest : trades->n_general;
+        if (use_knot) fast.n_rows = 0;
     } else {
         fast.n_rows = 0; chained.n_rows = 0;   // general walks all n trades through the identity list
+        if (use_knot) { general.list = trades->list_nonlite; general.n_list = trades->n_nonlite; }
     }
     int blocks_fast = 0, blocks_chained = 0, blocks_general = 0, blocks_lite = 0, blocks_lag = 0, blocks_litelag = 0, blocks_laglong = 0;
     if (lagged_long.n_rows > 0) blocks_laglong = trades->lagged_chained_blocks;    // the chains are laid out for this grid
@@ -1224,7 +1270,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         const int64_t need = (units + waves - 1) / waves;
         blocks_lag = static_cast<int>(std::min<int64_t>(need, std::min(trades->lag_blocks, ctx->n_cu)));
     }
-    if (use_lite) {
+    if (use_lite && !use_knot) {
         const size_t lds = adr::lite_kernel_lds_bytes(curve->dev, want_delta);
         const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
         const int64_t need = (trades->lite.n_units + adr::kLiteThreads / 64 - 1) / (adr::kLiteThreads / 64);
@@ -1284,9 +1330,10 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         o.lag_scratch = trades->lag_scratch;
         ADR_HIP(adr::launch_price_fast(curve->dev, lagged_long, o, want_delta, want_gamma, blocks_laglong, stream));
     }
-    if (agg_dev)
-        ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag + blocks_laglong,
-                                            P, want_gamma, agg_dev, stream));
+    const int blocks_all = blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag + blocks_laglong;
+    if (agg_dev && blocks_all > 0) ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_all, P, want_gamma, agg_dev, stream));
+    if (agg_dev && blocks_all == 0) ADR_HIP(hipMemsetAsync(agg_dev, 0, agg_bytes, stream));
+    if (use_knot) return knot_pass();
     return ADR_OK;
 }
 

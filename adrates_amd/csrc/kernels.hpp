@@ -204,6 +204,7 @@ struct OutputsDev {
     double* block_partials;  // [grid][kAggStride] or null
     double* dump;            // [32*32] sink for the gamma stores of the idle trade slot of a wave's last unit
     double* lag_scratch;     // payment-lag variant: [grid waves][2 groups][kLagScratchNodes][kLagStashDoubles]
+    double* knot_partials;   // aggregate-only mode: [grid][1 + 3 Kc] block sums {pv, w[Kc], D[Kc], O[Kc]} of the knot-space kernel
     unsigned long long* stamps;  // diagnostic builds only (ADR_STAMPS): [grid*waves][8] cycle sums per phase
 };
 
@@ -268,6 +269,16 @@ hipError_t launch_curve_df(const CurveDev& cv, int64_t n, const double* t_dev, d
 size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta);
 hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const OutputsDev& out, bool want_delta,
                              int n_blocks, hipStream_t stream);
+// Aggregate-only mode (kernels_lite.hip KNOT instantiations + kernels_knot.hip): the book's knot-space sums from the rows of
+// the lite table, reduced over the blocks in a fixed order, projected once to the pillar ladders and ADDED to agg
+// ([pv, delta[P], gamma[P*P]]; the caller has zeroed it or another kernel family's reduction has written it).
+size_t knot_kernel_lds_bytes(const CurveDev& cv, bool gamma);
+int knot_kernel_threads();
+hipError_t launch_price_knot(const CurveDev& cv, const LiteRowsDev& tr, const OutputsDev& out, bool want_gamma, int n_blocks,
+                             hipStream_t stream);
+// partials [n_blocks][1 + 3 Kc] -> reduced [1 + 3 Kc] (fixed order), then agg += projection; `reduced` is scratch
+hipError_t launch_knot_project(const CurveDev& cv, const double* partials, int n_blocks, double* reduced, bool want_delta,
+                               bool want_gamma, double* agg, hipStream_t stream);
 // has_gamma == false: the gamma part of the partials was not written (no gamma requested); agg's gamma part is zeroed
 // (tile_i, tile_j): the pillar tile pair the partials belong to (0, 0 for P <= 32); off-diagonal tiles are also written
 // transposed; pv comes from tile (0, 0), delta from the diagonal tiles

@@ -25,6 +25,17 @@
 // Any curve of the three schemes qualifies (no packed layout, any pillar count up to 32).
 // W64 instantiations (round 3): curves of 33-64 pillars - the 64-wide Jacobian table of the wide layout (curve_tables.hpp),
 // four pillars per lane (two b128 reads of the row and four FMAs per entry), block partials in the wide route's record.
+//
+// KNOT instantiations (round 4): the AGGREGATE-ONLY mode - Portfolio.compute's single ladder (cavour/market/portfolio/
+// portfolio.py:39-66), no per-trade output.  The reference's chain rule, jac.T @ hess_dfs @ jac + sum_k g_k hess[k]
+// (engine.py:2551-2567), is linear in the knot-space gradient g and Hessian hess_dfs of a trade, so summed over a book it
+// needs only their SUMS: in log space, per node w = c exp(ba L[ka] + bb L[kb]),
+//     w_k  += w b_k                      (first order, per knot)
+//     D_k  += w b_k^2,   O_ka += w ba bb (second order: a node's two knots are neighbours in the compact knot order)
+// - five numbers per node into a per-wave table over the reachable knots (LDS atomic adds; a wave's own instructions
+// execute in order, so the sums do not depend on scheduling), summed over waves and blocks in a fixed order, and ONE
+// projection per launch (kernels_knot.hip): delta = 1e-4 LJ^T w, gamma = 1e-8 (LJ^T W LJ + sum_k w_k LC_k).  No Jacobian
+// table in LDS, no per-trade sweep, any pillar count.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -105,17 +116,21 @@ struct CurveLds {
 // lane simply leaves three pairs of entries (ts: +, te: -, tp: + with both amounts) in three sweeps; no telescoping.
 // NSEG: segments of the row table the kernel looks at (3 covers tables of at most three distinct row counts - every
 // table of trades without payment lag; kLiteSegments otherwise)
-template <bool DELTA, bool LINDF, bool LAG, int NSEG, bool W64 = false>
+// KNOT: 0 = per-trade ladders; 1 = aggregate-only, first order (w_k); 2 = aggregate-only with the second-order sums
+template <bool DELTA, bool LINDF, bool LAG, int NSEG, bool W64 = false, int KNOT = 0>
 __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                                                                                        OutputsDev out) {
     static_assert(!(LAG && LINDF), "payment-lag trades under LINEAR_FWD_RATES go to the general kernel");
+    static_assert(KNOT == 0 || (DELTA && !LAG && !W64), "aggregate-only mode: trades without ratio nodes, any pillar count");
     constexpr int PW = W64 ? kWidePad : kPillarPad;       // pillars per row of the Jacobian table
     constexpr int PPL = PW / L;                           // pillars per lane: 2, or 4 on the 64-wide table
+    constexpr int NT = KNOT == 2 ? 3 : 1;                 // KNOT: tables per wave (w; D, O)
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    // LDS carve-up: per-wave entry slots (16-byte aligned), doubles, int16 tables
+    // LDS carve-up: per-wave entry slots (16-byte aligned) or knot tables, doubles, int16 tables
     unsigned char* s_rec = smem_raw;
-    double* s_lj = reinterpret_cast<double*>(s_rec + (DELTA ? kWavesPerBlock * kRecBytesPerWave : 0));
-    double* s_x = s_lj + (DELTA ? cv.Kc * PW : 0);
+    double* s_lj = reinterpret_cast<double*>(s_rec + ((DELTA && !KNOT) ? kWavesPerBlock * kRecBytesPerWave : 0));
+    double* s_knot = s_lj;                                // KNOT: [waves][NT][Kc]
+    double* s_x = s_lj + (KNOT ? kWavesPerBlock * NT * cv.Kc : (DELTA ? cv.Kc * PW : 0));
     double* s_log = s_x + cv.K;
     double* s_invx = s_log + cv.Kc;
     double* s_invdx = s_invx + cv.Kc;
@@ -123,7 +138,9 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
     int16_t* s_comp = s_first + cv.K;
     int16_t* s_lut = s_comp + cv.K;
 
-    if (DELTA) {
+    if (KNOT) {
+        for (int i = threadIdx.x; i < kWavesPerBlock * NT * cv.Kc; i += kBlockThreads) s_knot[i] = 0.0;
+    } else if (DELTA) {
         const double* lj_src = W64 ? cv.lj64 : cv.lj;
         for (int i = threadIdx.x; i < cv.Kc * PW; i += kBlockThreads) s_lj[i] = lj_src[i];
     }
@@ -158,6 +175,9 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
     const unsigned char* rec_group = rec_wave + g * ((2 * L + 1) * 16);
     unsigned char* rec_mine = rec_wave + (g * (2 * L + 1) + 2 * l) * 16;
     const unsigned char* lj_lane = reinterpret_cast<const unsigned char*>(s_lj) + l * (8 * PPL);    // pillars PPL l .. PPL l + PPL - 1
+    double* knot_w = s_knot + wave * (NT * cv.Kc);        // KNOT: this wave's tables
+    double* knot_d = knot_w + (NT > 1 ? cv.Kc : 0);
+    double* knot_o = knot_w + (NT > 1 ? 2 * cv.Kc : 0);
 
     double tot_pv = 0.0, tot_d0 = 0.0, tot_d1 = 0.0, tot_d2 = 0.0, tot_d3 = 0.0;
 
@@ -287,7 +307,24 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
             // nodes need no flags.  (On curves whose pillar dates are runs of duplicate knots a node's right-hand knot -
             // the first of a run - is never the next node's left-hand knot - the last of that run -, so merging
             // neighbours' entries buys nothing: tried, slower.)
-            auto sweep = [&](bool on, double ca, double cb, int off_a, int off_b) {
+            auto sweep = [&](bool on, double ca, double cb, int ka, int kb, double ba, double bb) {
+                if constexpr (KNOT != 0) {
+                    // aggregate-only: the node's five numbers into this wave's knot tables.  (ca, cb) = w (ba, bb) - under
+                    // LINEAR_FWD_RATES the two single-knot amounts, each with weight 1 on its own knot and no cross term.
+                    if (on) {
+                        __hip_atomic_fetch_add(knot_w + ka, ca, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        if (cb != 0.0) __hip_atomic_fetch_add(knot_w + kb, cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        if (KNOT == 2) {
+                            __hip_atomic_fetch_add(knot_d + ka, LINDF ? ca : ca * ba, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            if (cb != 0.0) {
+                                __hip_atomic_fetch_add(knot_d + kb, LINDF ? cb : cb * bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                if (!LINDF) __hip_atomic_fetch_add(knot_o + ka, ca * bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            }
+                        }
+                    }
+                    return;
+                }
+                const int off_a = ka * (PW * 8), off_b = kb * (PW * 8);
 #if ADR_LITE_SWEEP_PRIO
                 __builtin_amdgcn_s_setprio(ADR_LITE_SWEEP_PRIO);
 #endif
@@ -349,10 +386,9 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                 pv += om_r + om_p;
                 ADR_STAMP(2);   // lookups + exp
                 if (DELTA) {
-                    const int row = PW * 8;
-                    sweep(ratio, om_r * qs.ba, om_r * qs.bb, qs.ka * row, qs.kb * row);
-                    sweep(ratio, -om_r * qe.ba, -om_r * qe.bb, qe.ka * row, qe.kb * row);
-                    sweep(valid, (om_r + om_p) * qp.ba, (om_r + om_p) * qp.bb, qp.ka * row, qp.kb * row);
+                    sweep(ratio, om_r * qs.ba, om_r * qs.bb, qs.ka, qs.kb, qs.ba, qs.bb);
+                    sweep(ratio, -om_r * qe.ba, -om_r * qe.bb, qe.ka, qe.kb, qe.ba, qe.bb);
+                    sweep(valid, (om_r + om_p) * qp.ba, (om_r + om_p) * qp.bb, qp.ka, qp.kb, qp.ba, qp.bb);
                 }
                 ADR_STAMP(3);   // entries + ladder
             }
@@ -364,8 +400,8 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                     if (!more_starts) break;
                     qt = ts; qa = sl * N; qon = own_start;
                 }
-                double ca = 0.0, cb = 0.0;
-                int off_a = 0, off_b = 0;
+                double ca = 0.0, cb = 0.0, q_ba = 0.0, q_bb = 0.0;
+                int q_ka = 0, q_kb = 0;
                 if (qon) {
                     const Lookup q = curve_lookup<true>(c, qt);
                     if (LINDF) {
@@ -377,11 +413,11 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                         pv += omega;
                         ca = omega * q.ba; cb = omega * q.bb;
                     }
-                    off_a = q.ka * (PW * 8); off_b = q.kb * (PW * 8);
+                    q_ka = q.ka; q_kb = q.kb; q_ba = q.ba; q_bb = q.bb;
                 }
                 ADR_STAMP(2);   // lookup + exp
                 if (!DELTA) continue;
-                sweep(qon, ca, cb, off_a, off_b);
+                sweep(qon, ca, cb, q_ka, q_kb, q_ba, q_bb);
                 ADR_STAMP(3);   // entries + ladder
             }
         }
@@ -391,12 +427,16 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
 #if ADR_LITE_OUT_PRIO
         __builtin_amdgcn_s_setprio(ADR_LITE_OUT_PRIO);
 #endif
-        pv = row_sum(pv);
-        if (live && l == 0) {
-            if (out.pv) out.pv[t] = pv;
-            tot_pv += pv;
+        if (KNOT) {
+            tot_pv += pv;                                  // per lane; the lanes are summed once, at the end
+        } else {
+            pv = row_sum(pv);
+            if (live && l == 0) {
+                if (out.pv) out.pv[t] = pv;
+                tot_pv += pv;
+            }
         }
-        if (DELTA && live) {
+        if (!KNOT && DELTA && live) {
             d0 = (d0 + e0) * 1e-4; d1 = (d1 + e1) * 1e-4;
             tot_d0 += d0; tot_d1 += d1;
             if (W64) { d2 = (d2 + e2) * 1e-4; d3 = (d3 + e3) * 1e-4; tot_d2 += d2; tot_d3 += d3; }
@@ -427,6 +467,29 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
 #endif
 
     // ------------------------------------------------------------------------ block partial of the aggregate
+    if constexpr (KNOT != 0) {
+        // knot tables: the waves' tables summed in wave order, the PV lanes by a fixed butterfly -> [pv, w[Kc], D[Kc], O[Kc]]
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) tot_pv += __shfl_xor(tot_pv, off, 64);
+        __syncthreads();                                   // every wave's adds have been issued and (same-CU LDS) performed
+        double* red_pv = reinterpret_cast<double*>(s_x);   // the search arrays are no longer needed
+        if (lane == 0) red_pv[wave] = tot_pv;
+        __syncthreads();
+        double* dst = out.knot_partials + static_cast<size_t>(blockIdx.x) * (1 + 3 * cv.Kc);
+        for (int i = threadIdx.x; i < NT * cv.Kc; i += kBlockThreads) {
+            double s_ = 0.0;
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; ++w) s_ += s_knot[w * (NT * cv.Kc) + i];
+            dst[1 + i] = s_;
+        }
+        if (threadIdx.x == 0) {
+            double s_ = 0.0;
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; ++w) s_ += red_pv[w];
+            dst[0] = s_;
+        }
+        return;
+    }
     if (out.block_partials) {
 #pragma unroll
         for (int off = L; off < 64; off <<= 1) {
@@ -475,7 +538,32 @@ LiteFn lite_kernel_w(bool delta, bool lindf, bool lag, bool many_segments) {
 LiteFn lite_kernel(bool delta, bool lindf, bool lag, bool many_segments, bool w64 = false) {
     return w64 ? lite_kernel_w<true>(delta, lindf, lag, many_segments) : lite_kernel_w<false>(delta, lindf, lag, many_segments);
 }
+
+// aggregate-only instantiations (KNOT = 1: first order, 2: with the second-order sums)
+template <int KNOT>
+LiteFn knot_kernel_k(bool lindf, bool many) {
+    if (lindf) return many ? &price_lite_kernel<true, true, false, kLiteSegments, false, KNOT> : &price_lite_kernel<true, true, false, 3, false, KNOT>;
+    return many ? &price_lite_kernel<true, false, false, kLiteSegments, false, KNOT> : &price_lite_kernel<true, false, false, 3, false, KNOT>;
+}
+LiteFn knot_kernel(bool gamma, bool lindf, bool many) { return gamma ? knot_kernel_k<2>(lindf, many) : knot_kernel_k<1>(lindf, many); }
 }  // namespace
+
+size_t knot_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
+    size_t bytes = sizeof(double) * static_cast<size_t>(kWavesPerBlock) * (gamma ? 3 : 1) * cv.Kc;
+    bytes += sizeof(double) * (2 * static_cast<size_t>(cv.K) + 2 * cv.Kc);
+    bytes += sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + 2 * static_cast<size_t>(cv.n_lut));
+    return (bytes + 15) & ~static_cast<size_t>(15);
+}
+
+int knot_kernel_threads() { return kBlockThreads; }
+
+hipError_t launch_price_knot(const CurveDev& cv, const LiteRowsDev& tr, const OutputsDev& out, bool want_gamma, int n_blocks,
+                             hipStream_t stream) {
+    if (tr.te_w || !out.knot_partials) return hipErrorInvalidValue;     // rows without ratio nodes only
+    const size_t lds = knot_kernel_lds_bytes(cv, want_gamma);
+    hipLaunchKernelGGL(knot_kernel(want_gamma, cv.method == 2, tr.n_seg > 3), dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out);
+    return hipGetLastError();
+}
 
 size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta) {
     const size_t pw = cv.T > 1 ? kWidePad : kPillarPad;           // more than 32 pillars: the 64-wide table (W64 instantiations)
@@ -507,6 +595,9 @@ hipError_t set_lite_kernel_lds_limit(size_t bytes) {
                         fns.push_back(reinterpret_cast<const void*>(lite_kernel(d != 0, lin != 0, lag != 0, many != 0, false)));
                         fns.push_back(reinterpret_cast<const void*>(lite_kernel(d != 0, lin != 0, lag != 0, many != 0, true)));
                     }
+    for (int g = 0; g < 2; ++g)
+        for (int lin = 0; lin < 2; ++lin)
+            for (int many = 0; many < 2; ++many) fns.push_back(reinterpret_cast<const void*>(knot_kernel(g != 0, lin != 0, many != 0)));
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
         if (e != hipSuccess) return e;
