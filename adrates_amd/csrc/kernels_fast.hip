@@ -66,6 +66,9 @@
 #ifndef ADR_FAST_ASM_ROWS
 #define ADR_FAST_ASM_ROWS 1       // 1: the convexity rows are read with single ds_read_b64 instructions (inline assembly; see lds_read_f64)
 #endif
+#ifndef ADR_GAMMA_STORE_NT
+#define ADR_GAMMA_STORE_NT 1      // the per-trade gamma matrices are written with non-temporal stores
+#endif
 #ifndef ADR_FAST_BOTH_ROWS
 #define ADR_FAST_BOTH_ROWS 2      // 0: carry the right knot's convexity weight; 1: both rows per node (plain kernels); 2: the payment-lag variant too
 #endif
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                 const int pair = (cls_a << 16) | (cls_b & 0xffff);
                 const int pair_s = quad_bcast_i<0x00>(pair), pair_e = quad_bcast_i<0x55>(pair), pair_p = quad_bcast_i<0xAA>(pair);
                 const double e_ba = quad_bcast_d<0x55>(ba), e_bb = quad_bcast_d<0x55>(bb);
-                const int null_pair = (-2 << 16) | (-2 & 0xffff);
+                const int null_pair = static_cast<int>(0xfffefffeu);
                 const double w_not = sl * N * cw;
                 const double om_r = (cin && accr) ? w_not * exp(ls - le + lp) : 0.0;
                 // accrual end and payment time a few days apart share their knots: the end weights join the payment
@@ -612,6 +615,9 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
             for (int off = L; off < 64; off <<= 1) any_row |= any_row >> off;
             any_row &= kGroupMask;
             if (!any_row) continue;
+#ifdef ADR_DEBUG_SKIP_WALK             // diagnostic build: nodes are built but not walked (ladders stay zero) - the output phase alone
+            continue;
+#endif
 #if ADR_WALK_PRIO
             if (GAMMA) __builtin_amdgcn_s_setprio(ADR_WALK_PRIO);
 #endif
@@ -1016,7 +1022,11 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                 if (lane == 0) slot[kZeroEntry] = 0.0;
                 wave_lds_sync();
                 // LDS reads of a trade in kOutParts batches: the running-total slice with the first
+#ifdef ADR_DEBUG_STORE_TO_DUMP      // diagnostic build: every gamma store goes to the 8 KB sink (L2), nothing to HBM
+                double* gm = out.dump + 2 * lane;
+#else
                 double* gm = (tt >= 0 ? out.gamma + static_cast<int64_t>(tt) * (P * P) : out.dump) + 2 * lane;
+#endif
                 double* sink = out.dump + 2 * lane;            // pairs beyond a P < 32 matrix go here
 #pragma unroll
                 for (int part = 0; part < kOutParts; ++part) {
@@ -1072,7 +1082,16 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
                             const int band = kBands * part + b;
                             // write-once output stream: non-temporal 16-byte stores (-3 % on the bench pass)
                             nt_pair pr; pr.x = gv[2 * b]; pr.y = gv[2 * b + 1];
+#if defined(ADR_GAMMA_STORE_BITS)     // diagnostic builds: the store with explicit cache-policy bits (e.g. "sc1 nt")
+                            {
+                                const double* at_ = ((beyond >> band) & 1 ? sink : gm) + band * 128;
+                                asm volatile("global_store_dwordx4 %0, %1, off " ADR_GAMMA_STORE_BITS :: "v"(at_), "v"(pr) : "memory");
+                            }
+#elif ADR_GAMMA_STORE_NT
                             __builtin_nontemporal_store(pr, reinterpret_cast<nt_pair*>(((beyond >> band) & 1 ? sink : gm) + band * 128));
+#else
+                            *reinterpret_cast<nt_pair*>(((beyond >> band) & 1 ? sink : gm) + band * 128) = pr;
+#endif
                         }
                     }
                 }

@@ -150,3 +150,26 @@ def test_bench_portfolio_at_full_size(gpu_ctx):
     worst = assert_book(only, ref, "50 000 bench trades")
     dts.close()
     print(f"bench portfolio: worst error of the 50 000-trade book {worst:.2e}")
+
+
+def test_xccy_book_ladders_aggregate_only(gpu_ctx):
+    """A book of 3 000 distinct basis swaps: the aggregate-only call (domestic legs and foreign flows in knot space, the
+    weighted foreign-rate coupons on their own kernels with the stores off) against the sums of the per-trade ladders, which
+    tests/test_gpu_xccy.py / test_gpu_mixed_book.py hold to the oracles."""
+    from adrates_amd.market.position import xccy_engine as XE
+    from adrates_amd.market.position.engine import Engine
+    from adrates_amd.trades import synthetic_xccy as SX
+    from adrates_amd.utils import RequestTypes
+    vd = F.README_VALUE_DT
+    m = SX.build_market(vd, F.GBP_PX, F.USD_PX, F.TENORS)
+    _native.set_default_context(gpu_ctx)
+    terms, _ = SX.draw_terms(vd, 3000, seed=5)
+    reqs = {RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA}
+    full = XE.price_xccy_batch(Engine(m), terms, reqs, per_trade=True, aggregate=False)
+    only = XE.price_xccy_batch(Engine(m), terms, reqs, per_trade=False, aggregate=True)
+    assert abs(only["agg_pv"] - full["pv"].sum()) <= 1e-10 * np.abs(full["pv"]).sum()
+    for key in ("delta_dom", "delta_for", "delta_basis", "gamma_dom", "gamma_for", "gamma_basis"):
+        per = np.asarray(full[key])
+        scale = float(np.max(np.abs(per).sum(0)))
+        err = float(np.max(np.abs(np.asarray(only["agg_" + key]) - per.sum(0))))
+        assert err <= 1e-10 * scale, (key, err / scale)
