@@ -58,6 +58,9 @@ _SIGNATURES = {
     "adr_price": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _dp, _dp, _dp, _dp]),
     "adr_price_dev": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
     "adr_allreduce_agg": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "adr_rccl_unique_id": (C.c_int, [_vp]),
+    "adr_rccl_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "adr_rccl_comm_destroy": (None, [_vp]),
     "adr_curve_df": (C.c_int, [_vp, _vp, C.c_int64, _dp, _dp]),
     "adr_curve_df_dev": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "adr_leg_counts_host": (C.c_int, [C.c_int64, _i64p, _i64p, _i64p, _i64p]),
@@ -465,3 +468,26 @@ def default_context(device: int | None = None) -> Context:
     if device not in _default_ctx:
         _default_ctx[device] = Context(device)
     return _default_ctx[device]
+
+
+def build_identity() -> dict:
+    """What is running: sha256 of the loaded shared library and of the sources it is built from (adrates_amd/csrc/* and
+    include/adrates.h, names and contents, sorted).  Evidence files under profiles/ carry the same two hashes
+    (tools/profile_summary.py), and bench.py reports a counter-derived figure only when the source hash matches."""
+    import glob
+    import hashlib
+    root = os.path.dirname(os.path.abspath(__file__))
+    src = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, "csrc", "*.hip")) + glob.glob(os.path.join(root, "csrc", "*.hpp")) +
+                   glob.glob(os.path.join(root, "csrc", "*.cpp")) + [os.path.join(root, "csrc", "Makefile"),
+                                                                    os.path.join(os.path.dirname(root), "include", "adrates.h")])
+    for f in files:
+        if os.path.exists(f):
+            src.update(os.path.basename(f).encode())
+            with open(f, "rb") as fh:
+                src.update(fh.read())
+    lib = None
+    if os.path.exists(_LIB_PATH):
+        with open(_LIB_PATH, "rb") as fh:
+            lib = hashlib.sha256(fh.read()).hexdigest()
+    return {"source_sha256": src.hexdigest(), "lib_sha256": lib, "lib": os.path.relpath(_LIB_PATH, os.path.dirname(root))}

@@ -1377,4 +1377,32 @@ int adr_allreduce_agg(adr_ctx* ctx, void* rccl_comm, double* agg_dev, int count,
     return ADR_OK;
 }
 
+int adr_rccl_unique_id(void* id_out) {
+    if (!id_out) return fail(ADR_ERR_INVALID, "adr_rccl_unique_id: null output");
+    static_assert(sizeof(ncclUniqueId) == ADR_RCCL_ID_BYTES, "ADR_RCCL_ID_BYTES must equal sizeof(ncclUniqueId)");
+    ncclUniqueId id;
+    const ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(ADR_ERR_RCCL, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+    std::memcpy(id_out, &id, sizeof id);
+    return ADR_OK;
+}
+
+int adr_rccl_comm_init(adr_ctx* ctx, const void* id, int n_ranks, int rank, void** comm_out) {
+    if (!ctx || !id || !comm_out || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return fail(ADR_ERR_INVALID, "adr_rccl_comm_init: bad argument");
+    *comm_out = nullptr;
+    ADR_HIP(hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = ncclCommInitRank(&comm, n_ranks, uid, rank);
+    if (r != ncclSuccess) return fail(ADR_ERR_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    *comm_out = comm;
+    return ADR_OK;
+}
+
+void adr_rccl_comm_destroy(void* rccl_comm) {
+    if (rccl_comm) ncclCommDestroy(static_cast<ncclComm_t>(rccl_comm));
+}
+
 }  // extern "C"

@@ -55,6 +55,44 @@ def allgather_sum_fixed_order(agg, group=None):
     return agg
 
 
+# Aggregates that do not depend on the number of ranks.  A sum of per-rank ladders depends, in its last bits, on where the
+# ranks' shards begin and end.  With CANONICAL chunks - the book cut once into `CANONICAL_CHUNKS` contiguous pieces of
+# near-equal cash-flow count, whatever the world size (which must divide the chunk count: 1, 2, 3, 4, 6, 8, 12, 24) - every
+# rank prices its run of chunks one by one (one aggregate ladder per chunk: a chunk's ladder is the same numbers on whichever
+# rank prices it), the chunk ladders are all-gathered and every rank adds them in chunk order: one result, bit for bit, on
+# 1, 2, 3 ... ranks.
+CANONICAL_CHUNKS = 24
+
+
+def canonical_chunks(flt_off: np.ndarray, fix_off: np.ndarray, rank: int, world_size: int, n_chunks: int = CANONICAL_CHUNKS):
+    """``[(lo, hi)]``: the trade ranges of the canonical chunks this rank prices (chunks rank * n_chunks / world ...)."""
+    if n_chunks % world_size:
+        raise ValueError(f"world size {world_size} does not divide the {n_chunks} canonical chunks")
+    per = n_chunks // world_size
+    return shard_bounds(flt_off, fix_off, n_chunks)[rank * per:(rank + 1) * per]
+
+
+def allgather_chunks_fixed_order(chunk_aggs, group=None):
+    """``chunk_aggs [chunks of this rank, L]`` (tensor) -> the book ladder ``[L]``: all ranks' chunk ladders gathered (rank
+    order = chunk order) and added one after the other, first chunk first - the same additions in the same order on every
+    rank and for every world size."""
+    import torch
+    import torch.distributed as dist
+    parts = [chunk_aggs]
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        parts = [torch.empty_like(chunk_aggs) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, chunk_aggs.contiguous(), group=group)
+    rows = torch.cat([p.reshape(-1, p.shape[-1]) for p in parts], dim=0)        # [all chunks, L], chunk order
+    if rows.is_cuda:
+        # one reduction kernel over a tensor whose shape ([CANONICAL_CHUNKS, L]) does not depend on the world size: the
+        # same additions in the same order whatever the number of ranks
+        return rows.sum(dim=0)
+    total = torch.zeros_like(rows[0])
+    for row in rows:
+        total += row
+    return total
+
+
 def shard_by_work(work, world_size: int):
     """Contiguous ranges ``[(lo, hi)] * world_size`` of a list of items with per-item ``work`` (e.g. the coupons of
     each cross-currency swap), balanced like `shard_bounds`."""

@@ -79,14 +79,21 @@ def shard_of_portfolio(value_dt, n_total, rank, world_size, kind="offgrid", seed
     ceil(months / 12) coupons per leg), so only the slice ``lo:hi`` of the terms is compiled.  Equal, bit for bit,
     to ``shard_batch(synthesize(value_dt, n_total, ...), rank, world_size)`` (tests/test_synthetic.py).
     Returns ``(batch, (lo, hi))``."""
-    from ..distributed import shard_bounds
+    from ..distributed import canonical_chunks, shard_bounds
     freq = kw.get("freq", FrequencyTypes.ANNUAL)
     if freq != FrequencyTypes.ANNUAL:
         raise ValueError("shard_of_portfolio counts coupons for annual legs only")
     months, coupon, notional, pay_fixed = draw_terms(n_total, kind, seed)
     coupons = (months + 11) // 12
     cum = np.concatenate(([0], np.cumsum(coupons))).astype(np.int64)
-    lo, hi = shard_bounds(cum, cum, world_size)[rank]
+    if kw.get("canonical_chunks"):
+        # the rank's run of CANONICAL chunks (distributed.canonical_chunks): cut points that do not depend on the world
+        # size; `chunks` (trade ranges relative to the returned batch) is handed back through kw["chunks_out"]
+        ranges = canonical_chunks(cum, cum, rank, world_size)
+        lo, hi = ranges[0][0], ranges[-1][1]
+        kw["chunks_out"].extend((a - lo, b - lo) for a, b in ranges)
+    else:
+        lo, hi = shard_bounds(cum, cum, world_size)[rank]
     dc_type = kw.get("dc_type", DayCountTypes.ACT_365F)
     curve_type = kw.get("curve_type", CurveTypes.GBP_OIS_SONIA)
     currency = kw.get("currency", CurrencyTypes.GBP)

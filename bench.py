@@ -46,6 +46,15 @@ def parse(argv=None):
                     help="keep running untimed warm-up steps beyond --warmup until this much wall time has passed: "
                          "the GPU clock needs ~100 ms of work to ramp, and W short steps (0.3 ms each for a "
                          "delta-only request) would leave the timed region on a cold clock")
+    ap.add_argument("--aggregate-only", action="store_true",
+                    help="Portfolio.compute's request: the book's ladder [pv, delta, gamma] and NO per-trade output "
+                         "(adr_price_dev with agg only: knot-space sums + one projection per launch); reported with "
+                         '"mode": "aggregate_only"')
+    ap.add_argument("--collective", default="torch", choices=["torch", "native", "allgather"],
+                    help="the one exchange step for N > 1: torch = torch.distributed all_reduce (RCCL), asynchronous and "
+                         "double-buffered; native = adr_allreduce_agg (ncclAllReduce on the launch stream, communicator from "
+                         "adr_rccl_comm_init); allgather = canonical chunks priced one by one, chunk ladders all-gathered and "
+                         "summed in chunk order: the same bits on any number of ranks (adrates_amd/distributed.py)")
     ap.add_argument("--print-spawn-command", action="store_true",
                     help="with --gpus N > 1 and no WORLD_SIZE: print the launcher command instead of running it")
     return ap.parse_args(argv)
@@ -115,6 +124,31 @@ def parity_spot_check(host_curve, interp_value, batch, pv, delta, gamma, n_sampl
                        "computed after the timed region on the timed batch's own outputs"}
 
 
+def aggregate_spot_check(ctx, dev_curve, host_curve, interp_value, batch, mask, want_delta, want_gamma, n_sample=4096):
+    """Aggregate-only mode: a contiguous book of ~4 000 trades of the timed batch priced the same way (ladder only) against
+    the sums of oracle/port.c's per-trade ladders; error relative to the sum of absolute per-trade entries."""
+    import numpy as np
+    from adrates_amd import _native
+    from oracle import port as cpu_port
+    n = batch.n_trades
+    lo = max(0, n // 2 - n_sample // 2)
+    sub = batch.slice(lo, min(n, lo + n_sample))
+    ref = cpu_port.price(interp_value, host_curve.times, host_curve.dfs, host_curve.jac, host_curve.hess, sub,
+                         want_delta=want_delta, want_gamma=want_gamma, n_threads=4)
+    dts = _native.DeviceTrades(ctx, sub)
+    got = _native.price(ctx, dev_curve, dts, want_delta=want_delta, want_gamma=want_gamma, per_trade=False, aggregate=True)
+    dts.close()
+    worst = 0.0
+    for key, r in (("agg_pv", ref["pv"]), ("agg_delta", ref.get("delta")), ("agg_gamma", ref.get("gamma"))):
+        if r is None:
+            continue
+        scale = float(np.max(np.abs(r).sum(0))) if r.ndim > 1 else float(np.abs(r).sum())
+        worst = max(worst, float(np.max(np.abs(np.asarray(got[key]) - r.sum(0)))) / max(scale, 1e-300))
+    return {"max_error": worst, "trades": sub.n_trades, "tolerance": 1e-10, "ok": bool(worst <= 1e-10),
+            "against": "sums of oracle/port.c's per-trade ladders over a contiguous book cut from the timed batch, priced "
+                       "ladder-only like the timed launches; error relative to the sum of absolute per-trade entries"}
+
+
 def measured_fp64(n, want_gamma, kind, interp, kern_ms):
     """fp64 vector-ALU figures of the dominant kernel (the gamma configuration sits within ~2x
     of the FMA bound): wave-instruction counts per trade from the committed PMC pass of this same command
@@ -129,6 +163,9 @@ def measured_fp64(n, want_gamma, kind, interp, kern_ms):
     try:
         with open(files[-1]) as f:
             c = json.load(f)
+        stale = profile_is_stale(c)
+        if stale:
+            return {"source": f"stale: profiles/{os.path.basename(files[-1])} {stale}"}
         per_trade = {k: float(c["per_trade"][k]) for k in ("fma_f64", "mul_f64", "add_f64", "trans_f64", "valu_total")}
         flops = 64.0 * (2.0 * per_trade["fma_f64"] + per_trade["mul_f64"] + per_trade["add_f64"] + per_trade["trans_f64"])
         tf = flops * n / (kern_ms * 1e-3) / 1e12
@@ -174,6 +211,20 @@ class HostStagedAllReduce:
         self.staged = False
 
 
+def profile_is_stale(summary):
+    """'' when the committed counter summary was taken on the sources the running library is built from (their sha256,
+    adrates_amd/_native.py::build_identity), else the reason: per-trade instruction and byte counts of another revision of
+    the kernel must not be multiplied into this run's time."""
+    from adrates_amd import _native
+    have = summary.get("source_sha256")
+    now = _native.build_identity()["source_sha256"]
+    if not have:
+        return "carries no source hash"
+    if have != now:
+        return f"was taken on sources {have[:12]}, the running library is built from {now[:12]}"
+    return ""
+
+
 def measured_traffic(n, want_gamma, kind, interp):
     """(HBM bytes per launch, where the figure comes from): the committed rocprofv3 PMC summary of this same
     command (tools/profile.sh + tools/profile_summary.py -> profiles/*_traffic.json), or (None, reason) when the
@@ -187,9 +238,14 @@ def measured_traffic(n, want_gamma, kind, interp):
         return None, "none: profiles/r*_final_traffic.json missing"
     try:
         with open(files[-1]) as f:
-            return float(json.load(f)["hbm_bytes_per_launch"]), (
+            c = json.load(f)
+        stale = profile_is_stale(c)
+        if stale:
+            return None, f"stale: profiles/{os.path.basename(files[-1])} {stale}"
+        return float(c["hbm_bytes_per_launch"]), (
                 f"profiles/{os.path.basename(files[-1])}: rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command on "
-                "an earlier box, read from the file - not measured in this run")
+                f"an earlier box (sources {c['source_sha256'][:12]} = the running library's), read from the file - not "
+                "measured in this run")
     except Exception as exc:
         return None, f"none: {exc}"
 
@@ -236,6 +292,12 @@ def main(argv=None):
     from adrates_amd.utils import InterpTypes
     from adrates_amd.trades.market_data import README_VALUE_DT, gbp_model
 
+    agg_only = args.aggregate_only
+    chunked = args.collective == "allgather"
+    if chunked and args.xccy_swaps > 0:
+        raise SystemExit("--collective allgather prices the OIS portfolio in canonical chunks; not with --xccy-swaps")
+    if args.collective == "native" and rehearse and world > 1:
+        raise SystemExit("--collective native needs one GPU per rank (RCCL refuses two ranks on one device)")
     reqs = {r.strip().lower() for r in args.requests.split(",")}
     want_gamma = "gamma" in reqs
     want_delta = want_gamma or "delta" in reqs
@@ -253,21 +315,30 @@ def main(argv=None):
     # ONE portfolio of world x --trades trades; this rank compiles and uploads its contiguous shard only (the cut
     # points are those of distributed.shard_batch: near-equal cash-flow counts)
     n_total = world * args.trades
-    batch, (lo, hi) = synthetic.shard_of_portfolio(README_VALUE_DT, n_total, rank, world, kind=args.kind)
+    chunks = []          # --collective allgather: this rank's canonical chunks (trade ranges of `batch`)
+    batch, (lo, hi) = synthetic.shard_of_portfolio(README_VALUE_DT, n_total, rank, world, kind=args.kind,
+                                                   **(dict(canonical_chunks=True, chunks_out=chunks) if chunked else {}))
     n = batch.n_trades
     torch.cuda.synchronize()
     t_up = time.perf_counter()
-    dev_trades = _native.DeviceTrades(ctx, batch)       # host-side row tables + H2D copies (blocking): reported apart
+    if chunked:          # one device batch (and one aggregate ladder) per canonical chunk
+        pieces = [(_native.DeviceTrades(ctx, batch.slice(a, b)), a) for a, b in chunks]
+        dev_trades = None
+        in_bytes = sum(p[0].input_bytes for p in pieces)
+    else:
+        dev_trades = _native.DeviceTrades(ctx, batch)   # host-side row tables + H2D copies (blocking): reported apart
+        pieces = [(dev_trades, 0)]
+        in_bytes = dev_trades.input_bytes
     upload_ms = (time.perf_counter() - t_up) * 1e3
-    in_bytes = dev_trades.input_bytes
-    out_bytes = 8 * n * (1 + (P if want_delta else 0) + (P * P if want_gamma else 0))
+    out_bytes = 8 * (1 + P + P * P) * len(pieces) if agg_only else \
+        8 * n * (1 + (P if want_delta else 0) + (P * P if want_gamma else 0))
     curve_bytes = 16 * host_curve.n_knots + 8 * host_curve.n_knots * P * (1 + (P if want_gamma else 0))
     algo_bytes = in_bytes + out_bytes + curve_bytes
 
     dev = torch.device("cuda", local_rank)
-    pv = torch.empty(n, dtype=torch.float64, device=dev)
-    delta = torch.empty((n, P), dtype=torch.float64, device=dev) if want_delta else None
-    gamma = torch.empty((n, P, P), dtype=torch.float64, device=dev) if want_gamma else None
+    pv = torch.empty(n, dtype=torch.float64, device=dev) if not agg_only else None
+    delta = torch.empty((n, P), dtype=torch.float64, device=dev) if (want_delta and not agg_only) else None
+    gamma = torch.empty((n, P, P), dtype=torch.float64, device=dev) if (want_gamma and not agg_only) else None
 
     # optional mixed book (BASELINE configs[4]): a cross-currency book per GPU next to the OIS portfolio
     xccy = []          # [(device trades, device curve, pv, delta, gamma, offset of its aggregate in `agg`)]
@@ -294,6 +365,28 @@ def main(argv=None):
     aggs = [torch.zeros(agg_len, dtype=torch.float64, device=dev) for _ in range(2)]
     pending = [None, None]              # the all-reduce still reading / writing aggs[j]
     step_no = [0]
+    from adrates_amd import distributed as D
+    chunk_aggs = torch.zeros((len(pieces), agg_len), dtype=torch.float64, device=dev) if chunked else None
+    gathered = torch.zeros((D.CANONICAL_CHUNKS, agg_len), dtype=torch.float64, device=dev) if chunked else None
+    native_comm = None
+    if args.collective == "native" and use_dist:
+        import ctypes as C
+        lib = _native.load()
+        uid = (C.c_ubyte * 128)()
+        if rank == 0:
+            _native._check(lib.adr_rccl_unique_id(uid), "adr_rccl_unique_id")
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0)          # the id travels over the process group that already exists
+        native_comm = C.c_void_p()
+        _native._check(lib.adr_rccl_comm_init(ctx._h, box[0], world, rank, C.byref(native_comm)), "adr_rccl_comm_init")
+
+    def ptr(t, offset_elems=0):
+        return 0 if t is None else t.data_ptr() + 8 * offset_elems
+
+    def price_pieces(agg):
+        for k, (trades_k, first) in enumerate(pieces):
+            _native.price_dev(ctx, dev_curve, trades_k, mask, ptr(pv, first), ptr(delta, first * P), ptr(gamma, first * P * P),
+                              chunk_aggs[k].data_ptr() if chunked else agg.data_ptr(), stream.cuda_stream)
 
     def price_xccy(agg):
         for trades_x, cur, pv_x, de_x, ga_x, off in xccy:
@@ -325,13 +418,26 @@ def main(argv=None):
             pending[j] = None
         if events is not None:
             events[0].record(stream)
-        _native.price_dev(ctx, dev_curve, dev_trades, mask, pv.data_ptr(),
-                          delta.data_ptr() if delta is not None else 0,
-                          gamma.data_ptr() if gamma is not None else 0, agg.data_ptr(), stream.cuda_stream)
+        price_pieces(agg)
         if events is not None:
             events[1].record(stream)
         price_xccy(agg)
-        if use_dist:
+        if chunked:
+            # chunk ladders -> the book ladder, the same additions whatever the world size (distributed.py)
+            if use_dist and rehearse:
+                host_parts = [torch.empty((len(pieces), agg_len), dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(host_parts, chunk_aggs.cpu())
+                gathered.copy_(torch.cat(host_parts, dim=0))
+            elif use_dist:
+                dist.all_gather_into_tensor(gathered, chunk_aggs)
+            else:
+                gathered.copy_(chunk_aggs)
+            torch.sum(gathered, dim=0, out=agg)
+        elif native_comm is not None:
+            # the library's own exchange step: ncclAllReduce of the ladder on the launch stream, behind this step's kernels
+            _native._check(_native.load().adr_allreduce_agg(ctx._h, native_comm, agg.data_ptr(), agg_len, stream.cuda_stream),
+                           "adr_allreduce_agg")
+        elif use_dist:
             # the one exchange step: 1 + P + P*P doubles (per curve) over RCCL/xGMI, started behind this step's kernels
             if rehearse:
                 staged[j].start()
@@ -391,11 +497,24 @@ def main(argv=None):
         reduce_small(counts)                             # units all ranks processed per step
     # the reduced ladder of the LAST timed step against the per-rank ladders, gathered once and summed in rank order
     allreduce_check = None
-    if use_dist:
+    if use_dist and chunked:
+        # every rank formed the book ladder from the same gathered chunk ladders: they must agree bit for bit
+        mine = aggs[(step_no[0] - 1) & 1].detach().cpu()
+        everyone = [torch.zeros(agg_len, dtype=torch.float64) for _ in range(world)]
+        if rehearse:
+            dist.all_gather(everyone, mine)
+        else:
+            dev_all = [torch.zeros(agg_len, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(dev_all, mine.to(dev))
+            everyone = [t.cpu() for t in dev_all]
+        same = all(torch.equal(everyone[0], t) for t in everyone[1:])
+        allreduce_check = {"status": "ok" if same else "MISMATCH", "max_rel_error": 0.0 if same else float("nan"), "ranks": world,
+                           "what": "the book ladder every rank formed from the all-gathered canonical chunk ladders, compared "
+                                   "bit for bit across the ranks"}
+    elif use_dist:
         reduced = aggs[(step_no[0] - 1) & 1].detach().cpu()
         local = torch.zeros(agg_len, dtype=torch.float64, device=dev)
-        _native.price_dev(ctx, dev_curve, dev_trades, mask, pv.data_ptr(), delta.data_ptr() if delta is not None else 0,
-                          gamma.data_ptr() if gamma is not None else 0, local.data_ptr(), stream.cuda_stream)
+        price_pieces(local)
         price_xccy(local)
         stream.synchronize()
         parts = [torch.zeros(agg_len, dtype=torch.float64) for _ in range(world)]
@@ -418,7 +537,9 @@ def main(argv=None):
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = (n_all + nx_all) * args.steps / elapsed
-        traffic, traffic_source = measured_traffic(n, want_gamma, args.kind, args.interp)
+        plain = not agg_only and not chunked           # the committed counter passes are of the plain bench command
+        traffic, traffic_source = measured_traffic(n, want_gamma, args.kind, args.interp) if plain else \
+            (None, "none: no committed PMC pass for this mode")
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "OIS trades/sec PV+delta+gamma, 32-pillar curve; achieved HBM GB/s",
@@ -432,7 +553,11 @@ def main(argv=None):
                        "trades_per_gpu": args.trades, "trades_total": n_all, "rank0_trades": n,
                        "pillars": P, "knots": host_curve.n_knots,
                        "requests": sorted(reqs), "parallelism": f"one portfolio cut into {world} contiguous shards of equal "
-                                                               f"cash-flow count, RCCL all-reduce of {agg_len} doubles"},
+                                                               f"cash-flow count, RCCL all-reduce of {agg_len} doubles",
+                       "collective": {"torch": "torch.distributed all_reduce (RCCL), asynchronous, double-buffered",
+                                      "native": "adr_allreduce_agg (ncclAllReduce on the launch stream)",
+                                      "allgather": f"{D.CANONICAL_CHUNKS} canonical chunks, {len(pieces)} priced by rank 0 one by one; "
+                                                   "chunk ladders all-gathered, summed in chunk order"}[args.collective]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
@@ -440,6 +565,18 @@ def main(argv=None):
                                     + ("each step's pricing call" if per_step else "the whole timed region, divided by steps")), "algorithmic_bytes_per_launch": algo_bytes,
                          "algorithmic_bytes_per_trade": algo_bytes / n},
         }
+        line["build"] = _native.build_identity()
+        if agg_only:
+            # Portfolio.compute's request (cavour/market/portfolio/portfolio.py:39-66): the book ladder alone.  The pass reads
+            # the trades once and writes 1 + P + P*P doubles: its HBM roofline is the input stream; what bounds it is the
+            # vector-ALU work of the lookups and exponentials, like the PV-only pass.
+            line["mode"] = "aggregate_only"
+            line["config"]["workload"] += "; AGGREGATE ONLY: the book's ladder, no per-trade output (knot-space sums, one projection per launch)"
+            line["roofline"]["note"] = ("algorithmic bytes = the trade inputs + curve tables + one ladder per launch; the kernel "
+                                        "is bound by vector-ALU issue (three lookups and exponentials per coupon), not by HBM")
+        if chunked:
+            import hashlib
+            line["aggregate_sha256"] = hashlib.sha256(aggs[(step_no[0] - 1) & 1].detach().cpu().numpy().tobytes()).hexdigest()
         if n_x > 0:
             line["metric"] = "OIS trades + XCCY swaps per second, PV+delta+gamma, aggregate ladders all-reduced"
             line["config"]["workload"] += (f" + {args.xccy_swaps} GBP/USD basis swaps per GPU with SONIA / SOFR / basis ladders "
@@ -453,11 +590,15 @@ def main(argv=None):
         if allreduce_check is not None:
             line["allreduce_check"] = allreduce_check
             spot_ok = spot_ok and allreduce_check["status"] == "ok"
-        fp64 = measured_fp64(n, want_gamma, args.kind, args.interp, kern_ms)
+        fp64 = measured_fp64(n, want_gamma, args.kind, args.interp, kern_ms) if plain else None
         if fp64 is not None:
             line["roofline"]["fp64_valu"] = fp64
-        if n_x == 0:
+        if n_x == 0 and not agg_only:
             check = parity_spot_check(host_curve, interp.value, batch, pv, delta, gamma)
+            line["parity_spot_check"] = check
+            spot_ok = spot_ok and check["ok"]
+        if n_x == 0 and agg_only:
+            check = aggregate_spot_check(ctx, dev_curve, host_curve, interp.value, batch, mask, want_delta, want_gamma)
             line["parity_spot_check"] = check
             spot_ok = spot_ok and check["ok"]
         if args.cpu_baseline_seconds > 0 and world == 1 and n_x == 0:
@@ -467,6 +608,8 @@ def main(argv=None):
                                                       min(6.0, args.cpu_baseline_seconds))
         print(json.dumps(line), flush=True)
 
+    if native_comm is not None:
+        _native.load().adr_rccl_comm_destroy(native_comm)
     if use_dist:
         dist.destroy_process_group()
     if rank == 0 and not spot_ok:

@@ -308,6 +308,18 @@ int adr_sync(adr_ctx* ctx);
  */
 int adr_allreduce_agg(adr_ctx* ctx, void* rccl_comm, double* agg_dev, int count, void* stream);
 
+/*
+ * The communicator for adr_allreduce_agg, for hosts that have no RCCL binding of their own (one rank per GPU / process):
+ * rank 0 draws a unique id (adr_rccl_unique_id: ADR_RCCL_ID_BYTES bytes, = ncclGetUniqueId), hands it to the other ranks
+ * by whatever channel the host has (a file, a socket, torch.distributed's store), and every rank calls adr_rccl_comm_init
+ * with the same id (= ncclCommInitRank on the ctx's GPU; blocks until all n_ranks have called it).  The handle is an
+ * ncclComm_t; free it with adr_rccl_comm_destroy before the ctx.
+ */
+#define ADR_RCCL_ID_BYTES 128
+int adr_rccl_unique_id(void* id_out);
+int adr_rccl_comm_init(adr_ctx* ctx, const void* id, int n_ranks, int rank, void** comm_out);
+void adr_rccl_comm_destroy(void* rccl_comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,3 +150,46 @@ def test_shard_by_work_and_book_allreduce_single_process():
     agg = dict(agg_pv=2.5, agg_delta=np.arange(4.0), tenors=("1Y",))
     same = D.allreduce_book(dict(agg))            # no process group: identity
     assert same["agg_pv"] == 2.5 and np.array_equal(same["agg_delta"], np.arange(4.0)) and same["tenors"] == ("1Y",)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Aggregates that do not depend on the world size: canonical chunks, all-gather, fixed-order sum (distributed.py).
+# ---------------------------------------------------------------------------------------------------------------
+def _chunk_ladders(rank, world, n):
+    from oracle import cavour_oracle as O
+    from oracle import port
+    curve = F.readme_model().curves.GBP_OIS_SONIA
+    cache = O.cached_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
+    batch = synthetic.synthesize(F.README_VALUE_DT, n, seed=33)
+    P = cache["jac"].shape[1]
+    rows = []
+    for lo, hi in D.canonical_chunks(batch.flt_off, batch.fix_off, rank, world):
+        r = port.price(4, cache["times"], cache["dfs"], cache["jac"], cache["hess"], batch.slice(lo, hi), n_threads=1)
+        rows.append(np.concatenate([[r["pv"].sum()], r["delta"].sum(0), r["gamma"].sum(0).reshape(-1)]))
+    return torch.from_numpy(np.stack(rows)), P
+
+
+def _chunk_worker(rank, world, port_no, n, out_path):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_no))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows, _ = _chunk_ladders(rank, world, n)
+    total = D.allgather_chunks_fixed_order(rows)
+    if rank == world - 1:            # (any rank: they all hold the same bits)
+        np.save(out_path, total.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_canonical_chunks_give_the_same_bits_on_one_two_and_three_ranks(tmp_path):
+    n = 2400
+    rows, _ = _chunk_ladders(0, 1, n)
+    assert rows.shape[0] == D.CANONICAL_CHUNKS
+    single = D.allgather_chunks_fixed_order(rows).numpy()
+    for world in (2, 3):
+        out = str(tmp_path / f"chunks{world}.npy")
+        mp.spawn(_chunk_worker, args=(world, 29500 + (os.getpid() + 7 * world) % 2000, n, out), nprocs=world, join=True)
+        assert np.array_equal(np.load(out), single), world
+    with pytest.raises(ValueError):
+        D.canonical_chunks(np.arange(10), np.arange(10), 0, 5)          # 5 does not divide 24

@@ -108,3 +108,55 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     # node) and the reduced ladder of the last step equals the sum of the two ranks' own ladders
     chk = d["allreduce_check"]
     assert chk["status"] == "ok" and chk["ranks"] == 2 and chk["max_rel_error"] <= 1e-12
+
+
+def _run_bench(extra_args, env_extra, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    if "RANK" not in env_extra:
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--min-warmup-ms", "0",
+                          "--cpu-baseline-seconds", "0"] + extra_args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_aggregate_only_mode():
+    """`bench.py --aggregate-only`: Portfolio.compute's request as its own reported mode - the ladder alone, checked in the
+    run against the sums of oracle/port.c's per-trade ladders."""
+    d = _run_bench(["--trades", "50000", "--aggregate-only"], {})
+    assert d["mode"] == "aggregate_only" and "AGGREGATE ONLY" in d["config"]["workload"]
+    assert d["parity_spot_check"]["ok"] and d["parity_spot_check"]["max_error"] <= 1e-10
+    assert d["value"] > 1e8 and d["roofline"]["traffic"] is None and len(d["build"]["source_sha256"]) == 64
+
+
+def test_bench_native_collective_single_rank():
+    """`--collective native`: the communicator from adr_rccl_unique_id / adr_rccl_comm_init (id broadcast over the process
+    group) and adr_allreduce_agg on the launch stream - with one rank, which is all a one-GPU box can give RCCL."""
+    import os
+    d = _run_bench(["--trades", "20000", "--collective", "native"],
+                   dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200), RANK="0", WORLD_SIZE="1",
+                        LOCAL_RANK="0", ADR_BENCH_FORCE_DIST="1"))
+    assert "adr_allreduce_agg" in d["config"]["collective"]
+    assert d["allreduce_check"]["status"] == "ok" and d["parity_spot_check"]["ok"]
+
+
+def test_bench_allgather_collective_is_bitwise_independent_of_the_world_size():
+    """`--collective allgather`: 24 canonical chunks priced one by one, their ladders all-gathered and summed in chunk order.
+    The SAME 60 000-trade portfolio on 1, 2 and 3 ranks (rehearsed on one GPU over gloo) gives the same bits."""
+    sums = {}
+    for world, per_rank in ((1, 60000), (2, 30000), (3, 20000)):
+        env = {"ADR_BENCH_REHEARSE_ONE_GPU": "1"} if world > 1 else {}
+        d = _run_bench(["--gpus", str(world), "--trades", str(per_rank), "--collective", "allgather", "--aggregate-only"], env)
+        assert d["config"]["trades_total"] == 60000 and d["parity_spot_check"]["ok"]
+        if world > 1:
+            assert d["allreduce_check"]["status"] == "ok" and d["allreduce_check"]["ranks"] == world
+        sums[world] = d["aggregate_sha256"]
+    assert sums[1] == sums[2] == sums[3], sums
