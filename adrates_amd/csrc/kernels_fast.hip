@@ -473,8 +473,22 @@ __global__ __launch_bounds__(LAG ? kLagThreads : kBlockThreads) void price_fast_
             double lr[CPG > 0 ? CPG : 1];
             {   // entry l + L*i of a row sits at position l + L*i (the hub layout too: curve_tables.cpp, hub_layout)
                 const double* src = c.lcc + __mul24(row, c.ec_stride) + l;
+#if ADR_FAST_ASM_ROWS
+                // single ds_read_b64 instructions (see lds_read_f64: a merged ds_read2_b64 runs at half rate)
+                const unsigned addr = static_cast<unsigned>(reinterpret_cast<size_t>(src));
+                static_for<(CPG > 0 ? CPG : 1)>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    if constexpr (i < CPG) lr[i] = lds_read_f64<8 * L * i>(addr);
+                });
+                lds_reads_wait();
+                static_for<(CPG > 0 ? CPG : 1)>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    if constexpr (i < CPG) lds_read_done(lr[i]);
+                });
+#else
 #pragma unroll
                 for (int i = 0; i < CPG; ++i) lr[i] = src[L * i];
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -54,5 +54,8 @@ rd = 2.0 * out.get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024
 wr = out.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
 out.update(read_bytes_corrected=rd, write_bytes=wr, hbm_bytes_per_launch=rd + wr,
            note="read = 2 x FETCH_SIZE x 1024 (gfx950 half-count correction), write = WRITE_SIZE x 1024")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _identity
+_identity.stamp(out, f"{base}.trace.log")       # which build was profiled, which commit the summary is filed under
 json.dump(out, open(f"profiles/{rnd}_{tag}_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -23,7 +23,7 @@ python bench.py --xccy-swaps 100000 --steps 10 --cpu-baseline-seconds 0 > gpurun
 python bench.py --interp LINEAR_FWD_RATES --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_linfwd.json 2>/dev/null || exit 1
 bash tools/profile.sh $TAG || exit 1
 bash tools/pmc.sh && python tools/pmc_summary.py > gpurun_out/pmc_$TAG.txt || exit 1
-python tools/pmc_fp64_summary.py ${RND:-r03} > gpurun_out/pmc_${TAG}_fp64.json || exit 1
+python tools/pmc_fp64_summary.py ${RND:-r04} > gpurun_out/pmc_${TAG}_fp64.json || exit 1
 bash tools/profile_paths.sh $TAG || exit 1
 bash tools/pmc_lag.sh && python tools/pmc_summary.py 200000 > gpurun_out/pmc_${TAG}_lag.txt || exit 1
 if [ -f variants_stamps.so ]; then
