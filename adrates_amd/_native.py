@@ -58,6 +58,8 @@ _SIGNATURES = {
     "adr_price": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _dp, _dp, _dp, _dp]),
     "adr_price_dev": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
     "adr_allreduce_agg": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "adr_route_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_uint32, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, _dp,
+                                 C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]),
     "adr_rccl_unique_id": (C.c_int, [_vp]),
     "adr_rccl_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "adr_rccl_comm_destroy": (None, [_vp]),
@@ -491,3 +493,31 @@ def build_identity() -> dict:
         with open(_LIB_PATH, "rb") as fh:
             lib = hashlib.sha256(fh.read()).hexdigest()
     return {"source_sha256": src.hexdigest(), "lib_sha256": lib, "lib": os.path.relpath(_LIB_PATH, os.path.dirname(root))}
+
+
+ROUTE_FAMILIES = ("lite", "lite_lag", "fast", "fast_chained", "fast_lag", "fast_lag_chained", "general", "wide", "tiled", "knot")
+ROUTE_SETS = ("lite", "lite_lag", "rows", "chained", "lagged", "lagged_chained", "general", "general_b", "rest", "nonlite",
+              "nonlite_b", "all")
+
+
+def route_host(interp_method: int, times, dfs, jac, hess, batch, req_mask: int, per_trade=True, aggregate=False, n_cu=256,
+               curve_flags=0):
+    """The launch plan adr_price_dev would replay for this curve, batch and request, and how often it prices each trade
+    (adr_route_host; no GPU needed).  Returns ``(launches, cover)``: launches = [(family, set, items, blocks)], names from
+    ROUTE_FAMILIES / ROUTE_SETS; cover [n] int32."""
+    times, dfs, jac = _f64(times), _f64(dfs), _f64(jac)
+    K, P = jac.shape
+    hess_c = None if hess is None else _f64(hess)
+    n = batch.n_trades
+    fo, lo = np.ascontiguousarray(batch.fix_off, dtype=np.int64), np.ascontiguousarray(batch.flt_off, dtype=np.int64)
+    tp, te, al = _f64(batch.flt_tp), _f64(batch.flt_te), _f64(batch.flt_alpha)
+    w = None if batch.flt_weight is None else _f64(batch.flt_weight)
+    cover = np.zeros(max(n, 1), dtype=np.int32)
+    rows = np.zeros((32, 4), dtype=np.int32)
+    got = _check(load().adr_route_host(int(interp_method), K, P, _ptr(times), _ptr(dfs), _ptr(jac), _ptr(hess_c), int(curve_flags), n,
+                                       _ptr(fo, _i64p), _ptr(lo, _i64p), _ptr(tp), _ptr(te), _ptr(al), _ptr(w), int(req_mask),
+                                       1 if per_trade else 0, 1 if aggregate else 0, int(n_cu),
+                                       cover.ctypes.data_as(C.POINTER(C.c_int32)), rows.ctypes.data_as(C.POINTER(C.c_int32)), 32),
+                 "adr_route_host")
+    launches = [(ROUTE_FAMILIES[f], ROUTE_SETS[s_], int(items), int(blocks)) for f, s_, items, blocks in rows[:min(got, 32)]]
+    return launches, cover[:n]

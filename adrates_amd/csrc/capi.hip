@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <functional>
+#include <mutex>
 #include <queue>
 #include <string>
 #include <thread>
@@ -18,6 +19,7 @@
 #include "curve_tables.hpp"
 #include "host_pool.hpp"
 #include "kernels.hpp"
+#include "route.hpp"
 
 namespace {
 
@@ -133,6 +135,36 @@ struct adr_trades {
     const int32_t* list_general_b = nullptr;
     const int32_t* list_nonlite_b = nullptr;
     std::vector<void*> allocations;
+
+    // what the launch plan needs to know about the batch (route.hpp)
+    adr::route::TradeCounts counts() const {
+        adr::route::TradeCounts c;
+        c.n = dev.n;
+        c.rows = dev.n_rows; c.chained_rows = chained.n_rows; c.lagged_rows = lagged.n_rows; c.lagged_chained_rows = lagged_chained.n_rows;
+        c.lite_units = lite.n_units; c.lite_lag_units = lite_lag.n_units;
+        c.n_general = n_general; c.n_general_b = n_general_b; c.n_rest = n_rest; c.n_nonlite = n_nonlite; c.n_nonlite_b = n_nonlite_b;
+        c.chained_blocks = chained_blocks; c.lagged_chained_blocks = lagged_chained_blocks; c.lag_blocks = lag_blocks;
+        c.lag_scratch = lag_scratch != nullptr;
+        return c;
+    }
+    // the plan of the last (curve class, request) this batch was priced with: built on first use, replayed afterwards
+    struct PlanKey { int v[20]; };
+    mutable std::mutex plan_mutex;
+    mutable PlanKey plan_key{};
+    mutable bool plan_valid = false;
+    mutable adr::route::Plan plan;
+    const adr::route::Plan& plan_for(const adr::CurveDev& cv, bool want_delta, bool want_gamma, bool per_trade, bool has_agg,
+                                     const adr_ctx& c) const {
+        const PlanKey key{{cv.K, cv.Kc, cv.P, cv.T, cv.wide_nch, cv.packed_ok, cv.method, cv.epg, cv.cpg, cv.Ec, cv.Kcore, cv.n_mini,
+                           cv.n_lut, cv.n_fringe, cv.pc_pad, cv.Eu, want_delta ? 1 : 0, want_gamma ? 1 : 0, per_trade ? 1 : 0, has_agg ? 1 : 0}};
+        std::lock_guard<std::mutex> lock(plan_mutex);
+        if (!plan_valid || std::memcmp(&key, &plan_key, sizeof key) != 0) {
+            plan = adr::route::make_plan(cv, counts(), want_delta, want_gamma, per_trade, has_agg, c.n_cu, c.max_blocks, c.knot_blocks, kKnotMaxKc);
+            plan_key = key;
+            plan_valid = true;
+        }
+        return plan;
+    }
 };
 
 // the host-only translation units (book_host.cpp) report errors through the same per-thread message
@@ -719,9 +751,8 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     // batch that contains them is a caller error: say so here instead of returning a ladder of NaNs.
     // Class of a trade: bit 0 = a coupon accrues to a date other than its payment date (payment lag: ratio terms) or
     // carries a notional multiplier != 1.
-    constexpr int64_t kMaxChain = 12, kMaxChainLag = adr::kLagScratchNodes / adr::kRowSlots;   // rows per trade in the chained tables:
-    // plain legs of up to 384 coupons (a 30Y monthly leg is 360, cavour/utils/frequency.py:46); payment-lag legs of up to
-    // 128 (the variant's per-trade stash, kLagScratchNodes)
+    // (rows per trade in the chained tables - route.hpp, kMaxChain / kMaxChainLag: plain legs of up to 384 coupons (a 30Y
+    // monthly leg is 360, cavour/utils/frequency.py:46); payment-lag legs of up to 128 (the variant's per-trade stash))
     std::vector<uint8_t> lagged_of(static_cast<size_t>(n), 0);
     {
         std::vector<char> bad(static_cast<size_t>(n_threads), 0);       // 1: not finite, 2: bad sign
@@ -775,13 +806,11 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
         for (int32_t t : list) sorted[count[64 - coupons_of(t)]++] = t;
         list.swap(sorted);
     };
-    std::vector<int32_t> list_fast, list_long, list_general, list_lagged, list_lagged_long, list_rest;
-    for (int64_t t = 0; t < n; ++t) {
-        const int64_t rows = rows_of(t);
-        const bool general = rows > kMaxChain || lagged_of[static_cast<size_t>(t)];
-        (general ? list_general : rows > 1 ? list_long : list_fast).push_back(static_cast<int32_t>(t));
-        if (general) (rows == 1 ? list_lagged : rows <= kMaxChainLag ? list_lagged_long : list_rest).push_back(static_cast<int32_t>(t));
-    }
+    // which table or list every trade lands in (route.hpp: the same classification the launch plan's test walks)
+    adr::route::TradeClasses cls;
+    adr::route::classify_trades(n, fix_off, flt_off, lagged_of.data(), cls);
+    std::vector<int32_t>&list_fast = cls.list_fast, &list_long = cls.list_long, &list_general = cls.list_general,
+                        &list_lagged = cls.list_lagged, &list_lagged_long = cls.list_lagged_long, &list_rest = cls.list_rest;
 
     ADR_HIP(hipSetDevice(ctx->device));
     adr_trades* tr = new (std::nothrow) adr_trades();
@@ -976,34 +1005,14 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     {   // lite tables (kernels.hpp, LiteRowsDev): segments of equal row count, longest coupon counts first -
         // one for the trades of the 32-slot row table, one (with accrual ends and notional multipliers) for trades with
         // payment lag or per-coupon notionals of at most 360 coupons per leg (24 rows)
-        constexpr int S = adr::kLiteSlots, C = adr::kLiteCoupons, G = 64 / adr::kLiteSlots;
+        constexpr int S = adr::kLiteSlots, G = 64 / adr::kLiteSlots;
         // rows per trade, rounded up to one of kLiteSegments row counts (the kernel keeps one segment per distinct count):
         // 1, 2, 3, 4, 6, 8, 12, 16, 24 rows = up to 360 coupons per leg; kLiteSegments = too long for the table
-        static const int64_t kRowBuckets[adr::kLiteSegments] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
-        auto lite_bucket = [&](int64_t t) {
-            const int64_t m = std::max(flt_off[t + 1] - flt_off[t], fix_off[t + 1] - fix_off[t]);
-            const int64_t rows = std::max<int64_t>(1, (m + C - 1) / C);
-            int b = 0;
-            while (b < adr::kLiteSegments && kRowBuckets[b] < rows) ++b;
-            return b;                                           // index into kRowBuckets
-        };
-        std::vector<int32_t> seg_plain[adr::kLiteSegments], seg_lag[adr::kLiteSegments], nonlite, nonlite_b, general_b;
-        std::vector<char> lite_lag(static_cast<size_t>(n), 0);
-        for (int64_t t = 0; t < n; ++t) {
-            const bool lagged = lagged_of[static_cast<size_t>(t)] != 0;
-            const int bucket = lite_bucket(t);
-            // plain: the same trades as the 32-slot row table holds (at most 32 coupons per leg, i.e. up to 3 lite
-            // rows); longer ones keep their chained rows.  (seg_*[k] holds bucket kLiteSegments - 1 - k: longest first)
-            if (!lagged && rows_of(t) == 1) { seg_plain[adr::kLiteSegments - 1 - bucket].push_back(static_cast<int32_t>(t)); continue; }
-            nonlite.push_back(static_cast<int32_t>(t));
-            if (lagged && bucket < adr::kLiteSegments) {
-                seg_lag[adr::kLiteSegments - 1 - bucket].push_back(static_cast<int32_t>(t));
-                lite_lag[static_cast<size_t>(t)] = 1;
-            } else {
-                nonlite_b.push_back(static_cast<int32_t>(t));
-            }
-        }
-        for (int32_t t : list_general) if (!lite_lag[static_cast<size_t>(t)]) general_b.push_back(t);
+        const int64_t (&kRowBuckets)[adr::kLiteSegments] = adr::route::kLiteRowBuckets;
+        // plain: the same trades as the 32-slot row table holds (at most 32 coupons per leg, i.e. up to 3 lite rows); longer
+        // ones keep their chained rows.  (seg_*[k] holds bucket kLiteSegments - 1 - k: longest first; route.hpp)
+        std::vector<int32_t> (&seg_plain)[adr::kLiteSegments] = cls.seg_plain, (&seg_lag)[adr::kLiteSegments] = cls.seg_lag;
+        std::vector<int32_t>&nonlite = cls.nonlite, &nonlite_b = cls.nonlite_b, &general_b = cls.general_b;
         tr->n_nonlite = static_cast<int64_t>(nonlite.size());
         tr->list_nonlite = put32(std::move(nonlite));
         tr->n_nonlite_b = static_cast<int64_t>(nonlite_b.size());
@@ -1092,10 +1101,11 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
     const int P = curve->dev.P;
     const int64_t n = trades->dev.n;
+    const size_t agg_bytes = sizeof(double) * (1 + P + static_cast<size_t>(P) * P);
 
     ADR_HIP(hipSetDevice(ctx->device));
     if (n == 0) {   // empty portfolio: the aggregate is all zeros, nothing else to write
-        if (agg_dev) ADR_HIP(hipMemsetAsync(agg_dev, 0, sizeof(double) * (1 + P + static_cast<size_t>(P) * P), stream));
+        if (agg_dev) ADR_HIP(hipMemsetAsync(agg_dev, 0, agg_bytes, stream));
         return ADR_OK;
     }
 
@@ -1105,237 +1115,76 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     o.pv = (req_mask & ADR_REQ_VALUE) ? pv_dev : nullptr;
     o.delta = (req_mask & ADR_REQ_DELTA) ? delta_dev : nullptr;
     o.gamma = want_gamma ? gamma_dev : nullptr;
+    o.lag_scratch = trades->lag_scratch;
+    o.knot_partials = ctx->knot_partials;
 
-    // Aggregate-only request (agg_dev and no per-trade output - Portfolio.compute's single ladder): the trades of the lite
-    // table (no payment lag, at most 32 coupons per leg) are summed in KNOT space and projected once per launch
-    // (kernels_lite.hip KNOT instantiations, kernels_knot.hip); every other trade takes its usual kernel with the stores off,
-    // and the projection adds to what their reduction wrote.
-    const bool agg_only = agg_dev && !o.pv && !o.delta && !o.gamma;
-    const bool use_knot = agg_only && want_delta && trades->lite.n_units > 0 && 1 + 3 * curve->dev.Kc <= kKnotStrideMax &&
-                          adr::knot_kernel_lds_bytes(curve->dev, want_gamma) <= kLdsBudget;
-    auto knot_pass = [&]() -> int {      // after agg_dev has been written (or zeroed): agg_dev += the lite table's trades
-        const size_t lds = adr::knot_kernel_lds_bytes(curve->dev, want_gamma);
-        const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
-        const int waves = adr::knot_kernel_threads() / 64;
-        const int64_t need = (trades->lite.n_units + waves - 1) / waves;
-        const int blocks = static_cast<int>(std::min<int64_t>({need, static_cast<int64_t>(ctx->n_cu) * per_cu, static_cast<int64_t>(ctx->knot_blocks)}));
-        adr::OutputsDev ok{};
-        ok.knot_partials = ctx->knot_partials;
-        ADR_HIP(adr::launch_price_knot(curve->dev, trades->lite, ok, want_gamma, blocks, stream));
-        ADR_HIP(adr::launch_knot_project(curve->dev, ctx->knot_partials, blocks, ctx->knot_reduced, want_delta, want_gamma, agg_dev, stream));
-        return ADR_OK;
+    // The launch plan (route.hpp): which kernel family takes which of the batch's tables / lists.  It depends on the curve's
+    // class, the batch's table sizes and the request only; the batch keeps the last one (a book is priced again and again on
+    // scenario curves of one class).
+    const bool per_trade = o.pv || o.delta || o.gamma;
+    const adr::route::Plan& plan = trades->plan_for(curve->dev, want_delta, want_gamma, per_trade, agg_dev != nullptr, *ctx);
+    if (plan.error) return fail(ADR_ERR_INVALID, std::string("adr_price: ") + plan.error);
+
+    namespace R = adr::route;
+    const int stride = plan.wide ? adr::wide_partial_doubles(curve->dev.wide_nch) : adr::kAggStride;
+    auto list_view = [&](int set) {              // the general / wide / tiled kernels walk a trade list
+        adr::TradesDev v = trades->dev;
+        v.list = nullptr; v.n_list = n;
+        switch (set) {
+            case R::S_GENERAL: v.list = trades->list_general; v.n_list = trades->n_general; break;
+            case R::S_GENERAL_B: v.list = trades->list_general_b; v.n_list = trades->n_general_b; break;
+            case R::S_REST: v.list = trades->list_rest; v.n_list = trades->n_rest; break;
+            case R::S_NONLITE: v.list = trades->list_nonlite; v.n_list = trades->n_nonlite; break;
+            case R::S_NONLITE_B: v.list = trades->list_nonlite_b; v.n_list = trades->n_nonlite_b; break;
+            default: break;                      // S_ALL: the identity list
+        }
+        return v;
     };
-    const size_t agg_bytes = sizeof(double) * (1 + P + static_cast<size_t>(P) * P);
-
-    if (curve->dev.T > 1 && curve->dev.wide_nch > 0) {
-        // More than 32 pillars, one launch for the whole ladder.  GAMMA: the wide variants of the general kernel - a
-        // wavefront of 64 lanes holds the delta ladder, the gamma matrix is accumulated on its packed upper triangle.
-        // PV / PV + delta: the lite kernel's 64-pillar instantiations take the trades of its row tables (no payment lag
-        // and at most 32 coupons per leg; with payment lag, on a log-linear scheme: up to 360), the wide general kernel
-        // the rest.
-        const int stride = adr::wide_partial_doubles(curve->dev.wide_nch);
-        const bool lite_fits = adr::lite_kernel_lds_bytes(curve->dev, want_delta) <= kLdsBudget;
-        const bool use_lite = (!want_gamma && lite_fits && trades->lite.n_units > 0) || use_knot;     // the lite table's trades are priced elsewhere
-        const bool use_lite_lag = !want_gamma && lite_fits && trades->lite_lag.n_units > 0 && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
-        adr::TradesDev rest = trades->dev;
-        rest.list = nullptr; rest.n_list = n;
-        if (use_lite) {
-            rest.list = use_lite_lag ? trades->list_nonlite_b : trades->list_nonlite;
-            rest.n_list = use_lite_lag ? trades->n_nonlite_b : trades->n_nonlite;
-        } else if (use_lite_lag) {     // no plain lite rows: no trade is outside list_nonlite
-            rest.list = trades->list_nonlite_b; rest.n_list = trades->n_nonlite_b;
-        }
-        int blocks_lite = 0, blocks_litelag = 0, blocks_wide = 0;
-        auto lite_blocks = [&](const adr::LiteRowsDev& lt) {
-            const size_t lds = adr::lite_kernel_lds_bytes(curve->dev, want_delta);
-            const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
-            const int64_t need = (lt.n_units + adr::kLiteThreads / 64 - 1) / (adr::kLiteThreads / 64);
-            return static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * per_cu));
-        };
-        if (use_lite && !use_knot) blocks_lite = lite_blocks(trades->lite);
-        if (use_lite_lag) blocks_litelag = lite_blocks(trades->lite_lag);
-        if (rest.n_list > 0) {
-            const size_t lds = adr::wide_kernel_lds_bytes(curve->dev.K, curve->dev.Kc, curve->dev.wide_nch, want_gamma);
-            const int threads = adr::wide_kernel_threads(curve->dev.wide_nch, want_gamma), waves = threads / 64;
-            const int64_t need = (rest.n_list + waves - 1) / waves;
-            blocks_wide = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * adr::wide_kernel_blocks_per_cu(lds, threads)));
-        }
-        const int blocks = blocks_lite + blocks_litelag + blocks_wide;
-        if (static_cast<size_t>(blocks) * stride > static_cast<size_t>(ctx->max_blocks) * adr::kAggStride)
-            return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
-        auto partials_at = [&](int first_block) { return agg_dev ? ctx->partials + static_cast<size_t>(first_block) * stride : nullptr; };
-        if (blocks_lite > 0) {
-            o.block_partials = partials_at(0);
-            ADR_HIP(adr::launch_price_lite(curve->dev, trades->lite, o, want_delta, blocks_lite, stream));
-        }
-        if (blocks_litelag > 0) {
-            o.block_partials = partials_at(blocks_lite);
-            ADR_HIP(adr::launch_price_lite(curve->dev, trades->lite_lag, o, want_delta, blocks_litelag, stream));
-        }
-        if (blocks_wide > 0) {
-            o.block_partials = partials_at(blocks_lite + blocks_litelag);
-            ADR_HIP(adr::launch_price_wide(curve->dev, rest, o, want_delta, want_gamma, blocks_wide, stream));
-        }
-        if (agg_dev && blocks > 0) ADR_HIP(adr::launch_reduce_wide(curve->dev, ctx->partials, blocks, want_delta, want_gamma, agg_dev, stream));
-        if (agg_dev && blocks == 0) ADR_HIP(hipMemsetAsync(agg_dev, 0, agg_bytes, stream));
-        if (use_knot) return knot_pass();
-        return ADR_OK;
-    }
-    if (curve->dev.T > 1) {
-        // ... or, when the wide tables do not fit the LDS: once per pair of pillar tiles (tile_i <= tile_j);
-        // each launch writes its tile of the ladders, its partials are reduced into its tile of the aggregate.
-        const int T = curve->dev.T;
-        const int threads = adr::kGeneralThreads;
-        const int64_t need = (n + threads / 64 - 1) / (threads / 64);
-        const int blocks = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * 4));
-        const int n_launch = want_gamma ? T * (T + 1) / 2 : (want_delta ? T : 1);
-        if (blocks * n_launch > ctx->max_blocks) return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
-        adr::TradesDev all = trades->dev;
-        all.list = nullptr; all.n_list = n;
-        if (use_knot) { all.list = trades->list_nonlite; all.n_list = trades->n_nonlite; }
-        const size_t pair_tile = static_cast<size_t>(curve->dev.Kc) * 64 * adr::kGammaPerLane;
-        int launch = 0;
-        if (agg_dev)   // tiles no launch covers (no GAMMA: the off-diagonal ones; PV alone: every delta tile) stay zero
-            ADR_HIP(hipMemsetAsync(agg_dev, 0, sizeof(double) * (1 + P + static_cast<size_t>(P) * P), stream));
-        for (int tj = 0; tj < T; ++tj)
-            for (int ti = 0; ti <= tj; ++ti) {
-                if (!want_gamma && ti != tj) continue;               // PV / delta live on the diagonal tiles
-                if (!want_delta && tj > 0) continue;                 // PV alone: tile (0, 0) has it
-                if (all.n_list == 0) continue;                       // (every trade sits in the lite table: the knot pass has them)
+    if (plan.tiled && agg_dev)   // tiles no launch covers (no GAMMA: the off-diagonal ones; PV alone: every delta tile) stay zero
+        ADR_HIP(hipMemsetAsync(agg_dev, 0, agg_bytes, stream));
+    const R::Launch* knot = nullptr;
+    for (const R::Launch& L : plan.launches) {
+        o.block_partials = agg_dev ? ctx->partials + static_cast<size_t>(L.first_block) * stride : nullptr;
+        switch (L.family) {
+            case R::F_LITE: ADR_HIP(adr::launch_price_lite(curve->dev, trades->lite, o, want_delta, L.blocks, stream)); break;
+            case R::F_LITE_LAG: ADR_HIP(adr::launch_price_lite(curve->dev, trades->lite_lag, o, want_delta, L.blocks, stream)); break;
+            case R::F_FAST: ADR_HIP(adr::launch_price_fast(curve->dev, trades->dev, o, want_delta, want_gamma, L.blocks, stream)); break;
+            case R::F_FAST_CHAINED: ADR_HIP(adr::launch_price_fast(curve->dev, trades->chained, o, want_delta, want_gamma, L.blocks, stream)); break;
+            case R::F_FAST_LAG: ADR_HIP(adr::launch_price_fast(curve->dev, trades->lagged, o, want_delta, want_gamma, L.blocks, stream)); break;
+            case R::F_FAST_LAG_CHAINED: ADR_HIP(adr::launch_price_fast(curve->dev, trades->lagged_chained, o, want_delta, want_gamma, L.blocks, stream)); break;
+            case R::F_GENERAL: ADR_HIP(adr::launch_price_general(curve->dev, list_view(L.set), o, want_delta, want_gamma, L.blocks, stream)); break;
+            case R::F_WIDE: ADR_HIP(adr::launch_price_wide(curve->dev, list_view(L.set), o, want_delta, want_gamma, L.blocks, stream)); break;
+            case R::F_TILED: {
+                // each launch writes its tile of the ladders; its partials are reduced into its tile of the aggregate
                 adr::CurveDev cv = curve->dev;
-                cv.tile_i = ti; cv.tile_j = tj;
-                if (cv.lc_lanes) cv.lc_lanes += static_cast<size_t>(adr::tile_pair(ti, tj)) * pair_tile;
-                if (cv.lc_block_mask) cv.lc_block_mask += static_cast<size_t>(adr::tile_pair(ti, tj)) * curve->dev.Kc;
-                o.block_partials = agg_dev ? ctx->partials + static_cast<size_t>(launch) * blocks * adr::kAggStride : nullptr;
-                ADR_HIP(adr::launch_price_general(cv, all, o, want_delta, want_gamma, blocks, stream));
+                cv.tile_i = L.tile_i; cv.tile_j = L.tile_j;
+                const size_t pair_tile = static_cast<size_t>(curve->dev.Kc) * 64 * adr::kGammaPerLane;
+                if (cv.lc_lanes) cv.lc_lanes += static_cast<size_t>(adr::tile_pair(L.tile_i, L.tile_j)) * pair_tile;
+                if (cv.lc_block_mask) cv.lc_block_mask += static_cast<size_t>(adr::tile_pair(L.tile_i, L.tile_j)) * curve->dev.Kc;
+                ADR_HIP(adr::launch_price_general(cv, list_view(L.set), o, want_delta, want_gamma, L.blocks, stream));
                 if (agg_dev)
-                    ADR_HIP(adr::launch_reduce_partials(o.block_partials, blocks, P, want_gamma, agg_dev, stream, ti, tj));
-                ++launch;
+                    ADR_HIP(adr::launch_reduce_partials(o.block_partials, L.blocks, P, want_gamma, agg_dev, stream, L.tile_i, L.tile_j));
+                break;
             }
-        if (use_knot) return knot_pass();
-        return ADR_OK;
-    }
-
-    // Routing.  With GAMMA: trades without payment lag go to the fast kernel when the curve has the packed layout
-    // (those with more than 32 coupons per leg as chains of rows, in a launch of their own), everything else to the
-    // general kernel.  Without GAMMA (PV / PV + delta): the lite kernel takes every trade without payment lag and
-    // with at most 32 coupons per leg (with payment lag or per-coupon notionals, on a log-linear scheme: at most 135),
-    // whatever the curve's structure or scheme; the rest goes to
-    // the chained fast kernel (packed layout) or the general kernel.
-    const bool use_fast = curve->dev.packed_ok != 0;
-    // (a large curve that uploads fine for the general kernel can still be too big for the lite kernel's LDS image,
-    // which adds per-wave record slots and 1/dx: such a curve leaves its PV / delta requests to the other kernels)
-    const bool lite_fits = adr::lite_kernel_lds_bytes(curve->dev, want_delta) <= kLdsBudget;
-    const bool use_lite = !want_gamma && lite_fits && trades->lite.n_units > 0;
-    adr::TradesDev fast = trades->dev, chained = trades->chained, general = trades->dev, lagged = trades->lagged,
-                   lagged_long = trades->lagged_chained;
-    // (the payment-lag variant's ratio nodes are single exponentials: not under LINEAR_FWD_RATES, which go to the general kernel)
-    const bool use_lag = want_gamma && use_fast && (lagged.n_rows > 0 || lagged_long.n_rows > 0) && trades->lag_scratch != nullptr &&
-                         curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES && curve->dev.P % 2 == 0 &&
-                         trades->lagged_chained_blocks <= trades->lag_blocks;
-    // (odd pillar counts: the variant's patch of the elements without a packed entry works on aligned PAIRS of one matrix row -
-    // with an odd row length a pair of the flat array can straddle two rows; such curves leave their payment-lag trades with
-    // GAMMA to the general kernel, everything else takes the fast kernels)
-    if (!use_lag) { lagged.n_rows = 0; lagged_long.n_rows = 0; }
-    // (the lite kernel's payment-lag rows: PV / PV + delta of trades with payment lag or per-coupon notionals, log-linear schemes)
-    const bool use_lite_lag = !want_gamma && lite_fits && trades->lite_lag.n_units > 0 && curve->dev.method != ADR_INTERP_LINEAR_FWD_RATES;
-    const bool lite_elsewhere = use_lite || use_knot;      // the lite table's trades: the lite kernel, or the knot pass
-    if (!want_gamma && (lite_elsewhere || use_lite_lag)) {
-        if (lite_elsewhere) fast.n_rows = 0;               // the lite table holds exactly the 32-slot row table's trades
-        if (use_fast) {                                    // long trades keep their chained rows
-            general.list = use_lite_lag ? trades->list_general_b : trades->list_general;
-            general.n_list = use_lite_lag ? trades->n_general_b : trades->n_general;
-        } else {                                           // no packed layout: long trades join the general list
-            fast.n_rows = 0; chained.n_rows = 0;
-            if (lite_elsewhere) {
-                general.list = use_lite_lag ? trades->list_nonlite_b : trades->list_nonlite;
-                general.n_list = use_lite_lag ? trades->n_nonlite_b : trades->n_nonlite;
-            } else {        // no plain lite rows means no trade is outside list_nonlite
-                general.list = trades->list_nonlite_b; general.n_list = trades->n_nonlite_b;
-            }
+            case R::F_KNOT: knot = &L; break;
+            default: return fail(ADR_ERR_INVALID, "adr_price: unknown kernel family in the launch plan");
         }
-    } else if (use_fast) {
-        general.list = use_lag ? trades->list_rest : trades->list_general;
-        general.n_list = use_lag ? trades->n_rest : trades->n_general;
-        if (use_knot) fast.n_rows = 0;
-    } else {
-        fast.n_rows = 0; chained.n_rows = 0;   // general walks all n trades through the identity list
-        if (use_knot) { general.list = trades->list_nonlite; general.n_list = trades->n_nonlite; }
     }
-    int blocks_fast = 0, blocks_chained = 0, blocks_general = 0, blocks_lite = 0, blocks_lag = 0, blocks_litelag = 0, blocks_laglong = 0;
-    if (lagged_long.n_rows > 0) blocks_laglong = trades->lagged_chained_blocks;    // the chains are laid out for this grid
-    if (lagged.n_rows > 0) {
-        const int waves = adr::fast_kernel_threads(true) / 64;
-        const int64_t units = (lagged.n_rows + adr::fast_kernel_groups() - 1) / adr::fast_kernel_groups();
-        const int64_t need = (units + waves - 1) / waves;
-        blocks_lag = static_cast<int>(std::min<int64_t>(need, std::min(trades->lag_blocks, ctx->n_cu)));
+    if (agg_dev && !plan.tiled) {
+        if (plan.total_blocks == 0) ADR_HIP(hipMemsetAsync(agg_dev, 0, agg_bytes, stream));
+        else if (plan.wide) ADR_HIP(adr::launch_reduce_wide(curve->dev, ctx->partials, plan.total_blocks, want_delta, want_gamma, agg_dev, stream));
+        else ADR_HIP(adr::launch_reduce_partials(ctx->partials, plan.total_blocks, P, want_gamma, agg_dev, stream));
     }
-    if (use_lite && !use_knot) {
-        const size_t lds = adr::lite_kernel_lds_bytes(curve->dev, want_delta);
-        const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
-        const int64_t need = (trades->lite.n_units + adr::kLiteThreads / 64 - 1) / (adr::kLiteThreads / 64);
-        blocks_lite = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * per_cu));
+    if (knot) {
+        // aggregate-only request (agg and no per-trade output - Portfolio.compute's single ladder): the lite table's trades
+        // are summed in KNOT space and projected once (kernels_lite.hip KNOT instantiations, kernels_knot.hip); the
+        // projection ADDS to what the other families' reduction wrote above
+        ADR_HIP(adr::launch_price_knot(curve->dev, trades->lite, o, want_gamma, knot->blocks, stream));
+        ADR_HIP(adr::launch_knot_project(curve->dev, ctx->knot_partials, knot->blocks, ctx->knot_reduced, want_delta, want_gamma, agg_dev, stream));
     }
-    if (use_lite_lag) {
-        const size_t lds = adr::lite_kernel_lds_bytes(curve->dev, want_delta);
-        const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
-        const int64_t need = (trades->lite_lag.n_units + adr::kLiteThreads / 64 - 1) / (adr::kLiteThreads / 64);
-        blocks_litelag = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * per_cu));
-    }
-    if (fast.n_rows > 0) {
-        const size_t lds = adr::fast_kernel_lds_bytes(curve->dev, want_gamma);
-        const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
-        const int64_t units = (fast.n_rows + adr::fast_kernel_groups() - 1) / adr::fast_kernel_groups();
-        const int64_t need = (units + adr::kFastThreads / 64 - 1) / (adr::kFastThreads / 64);
-        blocks_fast = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * per_cu));
-    }
-    if (chained.n_rows > 0) blocks_chained = trades->chained_blocks;   // the chains are laid out for this grid
-    if (general.n_list > 0) {
-        const int threads = adr::general_kernel_threads(curve->dev, want_gamma);     // 512: LDS-resident convexity rows
-        const int64_t need = (general.n_list + threads / 64 - 1) / (threads / 64);
-        blocks_general = static_cast<int>(std::min<int64_t>(need, static_cast<int64_t>(ctx->n_cu) * (threads == adr::kGeneralThreads ? 4 : 2)));
-    }
-    if (blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag + blocks_laglong > ctx->max_blocks)
-        return fail(ADR_ERR_INVALID, "adr_price: grid exceeds scratch");
-    auto partials_at = [&](int first_block) {
-        return agg_dev ? ctx->partials + static_cast<size_t>(first_block) * adr::kAggStride : nullptr;
-    };
-    if (blocks_lite > 0) {
-        o.block_partials = partials_at(0);
-        ADR_HIP(adr::launch_price_lite(curve->dev, trades->lite, o, want_delta, blocks_lite, stream));
-    }
-    if (blocks_fast > 0) {
-        o.block_partials = partials_at(blocks_lite);
-        ADR_HIP(adr::launch_price_fast(curve->dev, fast, o, want_delta, want_gamma, blocks_fast, stream));
-    }
-    if (blocks_chained > 0) {
-        o.block_partials = partials_at(blocks_lite + blocks_fast);
-        ADR_HIP(adr::launch_price_fast(curve->dev, chained, o, want_delta, want_gamma, blocks_chained, stream));
-    }
-    if (blocks_general > 0) {
-        o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained);
-        ADR_HIP(adr::launch_price_general(curve->dev, general, o, want_delta, want_gamma, blocks_general, stream));
-    }
-    if (blocks_lag > 0) {
-        o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general);
-        o.lag_scratch = trades->lag_scratch;
-        ADR_HIP(adr::launch_price_fast(curve->dev, lagged, o, want_delta, want_gamma, blocks_lag, stream));
-    }
-    if (blocks_litelag > 0) {
-        o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag);
-        ADR_HIP(adr::launch_price_lite(curve->dev, trades->lite_lag, o, want_delta, blocks_litelag, stream));
-    }
-    if (blocks_laglong > 0) {
-        o.block_partials = partials_at(blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag);
-        o.lag_scratch = trades->lag_scratch;
-        ADR_HIP(adr::launch_price_fast(curve->dev, lagged_long, o, want_delta, want_gamma, blocks_laglong, stream));
-    }
-    const int blocks_all = blocks_lite + blocks_fast + blocks_chained + blocks_general + blocks_lag + blocks_litelag + blocks_laglong;
-    if (agg_dev && blocks_all > 0) ADR_HIP(adr::launch_reduce_partials(ctx->partials, blocks_all, P, want_gamma, agg_dev, stream));
-    if (agg_dev && blocks_all == 0) ADR_HIP(hipMemsetAsync(agg_dev, 0, agg_bytes, stream));
-    if (use_knot) return knot_pass();
     return ADR_OK;
 }
+
 
 int adr_price(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades, uint32_t req_mask, double* pv,
               double* delta, double* gamma, double* agg) {
@@ -1365,6 +1214,84 @@ int adr_price(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades, ui
     cleanup();
     if (e != hipSuccess) return fail_hip(e, "adr_price: running kernels / copying results");
     return ADR_OK;
+}
+
+// ---------------------------------------------------------------------------------------- launch plan, host side
+int adr_route_host(int interp_method, int K, int P, const double* times, const double* dfs, const double* jac, const double* hess,
+                   uint32_t curve_flags, int64_t n, const int64_t* fix_off, const int64_t* flt_off, const double* flt_tp,
+                   const double* flt_te, const double* flt_alpha, const double* flt_weight, uint32_t req_mask, int per_trade,
+                   int aggregate, int n_cu, int32_t* cover, int32_t* launches, int max_launches) {
+    if (n < 0 || (n > 0 && (!fix_off || !flt_off || !cover)) || !launches || max_launches < 1 || n_cu < 1)
+        return fail(ADR_ERR_INVALID, "adr_route_host: bad argument");
+    adr::CurveTables t;
+    const std::string err = adr::build_curve_tables(K, P, times, dfs, jac, hess, t);
+    if (!err.empty()) return fail(ADR_ERR_INVALID, "adr_route_host: " + err);
+    // the curve's class, as adr_curve_upload_ex decides it (integer fields only: no table is read by the plan)
+    adr::CurveDev cv{};
+    cv.K = t.K; cv.Kc = t.Kc; cv.P = t.P; cv.method = interp_method; cv.T = t.T;
+    cv.Pc = t.Pc; cv.pc_pad = t.pc_pad; cv.Ec = t.Ec; cv.Eu = t.Eu; cv.epg = t.epg; cv.cpg = t.cpg; cv.hub = t.hub ? 1 : 0;
+    cv.Kcore = t.Kcore; cv.n_mini = t.n_mini; cv.n_fringe = t.n_fringe; cv.n_lut = static_cast<int>(t.lut.size() / 2);
+    const bool wide = t.wide_nch > 0 && t.wide_nch <= adr::kWideMaxChunks && !(curve_flags & ADR_CURVE_PILLAR_TILES) &&
+                      adr::wide_kernel_lds_bytes(t.K, t.Kc, t.wide_nch, t.has_hess) <= kLdsBudget;
+    cv.wide_nch = wide ? t.wide_nch : 0;
+    cv.packed_ok = (t.packed_ok && adr::fast_kernel_lds_bytes(cv, t.has_hess) <= kLdsBudget) ? 1 : 0;
+    if ((req_mask & ADR_REQ_GAMMA) && !t.has_hess) return fail(ADR_ERR_INVALID, "adr_route_host: GAMMA requested but hess is null");
+    // the trades' classes, as adr_trades_upload decides them
+    std::vector<uint8_t> lagged_of(static_cast<size_t>(n), 0);
+    for (int64_t tr = 0; tr < n; ++tr) {
+        bool lag = false;
+        for (int64_t j = flt_off[tr]; j < flt_off[tr + 1] && !lag; ++j)
+            lag = (flt_alpha[j] > 0.0 && flt_te[j] != flt_tp[j]) || (flt_weight && flt_weight[j] != 1.0);
+        lagged_of[static_cast<size_t>(tr)] = lag ? 1 : 0;
+    }
+    namespace R = adr::route;
+    R::TradeClasses cls;
+    R::classify_trades(n, fix_off, flt_off, lagged_of.data(), cls);
+    R::TradeCounts tc;
+    tc.n = n;
+    tc.rows = static_cast<int64_t>(cls.list_fast.size());
+    tc.chained_rows = static_cast<int64_t>(cls.list_long.size());               // (non-zero is all the plan asks of the chained tables)
+    tc.lagged_rows = static_cast<int64_t>(cls.list_lagged.size());
+    tc.lagged_chained_rows = static_cast<int64_t>(cls.list_lagged_long.size());
+    tc.lite_units = cls.lite_units; tc.lite_lag_units = cls.lite_lag_units;
+    tc.n_general = static_cast<int64_t>(cls.list_general.size()); tc.n_general_b = static_cast<int64_t>(cls.general_b.size());
+    tc.n_rest = static_cast<int64_t>(cls.list_rest.size());
+    tc.n_nonlite = static_cast<int64_t>(cls.nonlite.size()); tc.n_nonlite_b = static_cast<int64_t>(cls.nonlite_b.size());
+    tc.chained_blocks = cls.list_long.empty() ? 0 : n_cu;
+    tc.lagged_chained_blocks = cls.list_lagged_long.empty() ? 0 : n_cu;
+    tc.lag_scratch = !cls.list_lagged.empty() || !cls.list_lagged_long.empty();
+    tc.lag_blocks = tc.lag_scratch ? n_cu : 0;
+    const bool want_gamma = (req_mask & ADR_REQ_GAMMA) != 0, want_delta = want_gamma || (req_mask & ADR_REQ_DELTA) != 0;
+    const R::Plan plan = R::make_plan(cv, tc, want_delta, want_gamma, per_trade != 0, aggregate != 0, n_cu, n_cu * 16,
+                                      n_cu * adr::kLiteWavesPerSimd * 4 * 64 / adr::kLiteThreads, kKnotMaxKc);
+    if (plan.error) return fail(ADR_ERR_INVALID, std::string("adr_route_host: ") + plan.error);
+    // who is covered how often: the tile launches of one pass count once
+    for (int64_t i = 0; i < n; ++i) cover[i] = 0;
+    auto add = [&](const std::vector<int32_t>& list) { for (int32_t tr : list) ++cover[tr]; };
+    int n_out = 0;
+    for (const R::Launch& L : plan.launches) {
+        if (n_out < max_launches) {
+            int32_t* row = launches + 4 * n_out;
+            row[0] = L.family; row[1] = L.set; row[2] = static_cast<int32_t>(std::min<int64_t>(L.items, INT32_MAX)); row[3] = L.blocks;
+        }
+        ++n_out;
+        if (L.family == R::F_TILED && !(L.tile_i == 0 && L.tile_j == 0)) continue;
+        switch (L.set) {
+            case R::S_LITE: for (auto& v : cls.seg_plain) add(v); break;
+            case R::S_LITE_LAG: for (auto& v : cls.seg_lag) add(v); break;
+            case R::S_ROWS: add(cls.list_fast); break;
+            case R::S_CHAINED: add(cls.list_long); break;
+            case R::S_LAGGED: add(cls.list_lagged); break;
+            case R::S_LAGGED_CHAINED: add(cls.list_lagged_long); break;
+            case R::S_GENERAL: add(cls.list_general); break;
+            case R::S_GENERAL_B: add(cls.general_b); break;
+            case R::S_REST: add(cls.list_rest); break;
+            case R::S_NONLITE: add(cls.nonlite); break;
+            case R::S_NONLITE_B: add(cls.nonlite_b); break;
+            default: for (int64_t i = 0; i < n; ++i) ++cover[i]; break;
+        }
+    }
+    return n_out;
 }
 
 // ---------------------------------------------------------------------------------------- multi-GPU

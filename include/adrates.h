@@ -288,6 +288,20 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
                   void* stream);
 
 /*
+ * Host-side half of adr_price_dev's routing, exposed so that it can be checked without a GPU (like adr_curve_layout_host):
+ * the launch plan for a curve (arguments as adr_curve_upload_ex) and a batch (the arrays of adr_trades_upload_weighted the
+ * classification reads) under a request - req_mask, per_trade != 0: some per-trade output is wanted, aggregate != 0: agg is
+ * wanted - on a device of n_cu compute units.  launches [max_launches][4] receives {kernel family, trade set, items,
+ * blocks} per launch (enums of adrates_amd/csrc/route.hpp), cover [n] how many launches price each trade (the tile
+ * launches of one pass count once): the library's contract is cover[i] == 1 for every trade.  Returns the number of
+ * launches (possibly > max_launches) or a negative status.
+ */
+int adr_route_host(int interp_method, int K, int P, const double* times, const double* dfs, const double* jac, const double* hess,
+                   uint32_t curve_flags, int64_t n, const int64_t* fix_off, const int64_t* flt_off, const double* flt_tp,
+                   const double* flt_te, const double* flt_alpha, const double* flt_weight, uint32_t req_mask, int per_trade,
+                   int aggregate, int n_cu, int32_t* cover, int32_t* launches, int max_launches);
+
+/*
  * Discount factors at n query times off an uploaded curve: InterpolatorAd.simple_interpolate evaluated on the GPU
  * (cavour/market/curves/interpolator_ad.py:186-249; same snap / + 1e-12 / duplicate-knot semantics as the pricing
  * kernels, all three schemes).  Replaces the reference's df lookups inside the cross-currency leg function
