@@ -1004,10 +1004,10 @@ int adr_trades_upload_weighted(adr_ctx* ctx, int64_t n, const int64_t* fix_off, 
     bool too_many_rows = false;
     {   // lite tables (kernels.hpp, LiteRowsDev): segments of equal row count, longest coupon counts first -
         // one for the trades of the 32-slot row table, one (with accrual ends and notional multipliers) for trades with
-        // payment lag or per-coupon notionals of at most 360 coupons per leg (24 rows)
+        // payment lag or per-coupon notionals of at most 390 coupons per leg (26 rows)
         constexpr int S = adr::kLiteSlots, G = 64 / adr::kLiteSlots;
         // rows per trade, rounded up to one of kLiteSegments row counts (the kernel keeps one segment per distinct count):
-        // 1, 2, 3, 4, 6, 8, 12, 16, 24 rows = up to 360 coupons per leg; kLiteSegments = too long for the table
+        // 1, 2, 3, 4, 6, 8, 12, 16, 26 rows = up to 390 coupons per leg; kLiteSegments = too long for the table
         const int64_t (&kRowBuckets)[adr::kLiteSegments] = adr::route::kLiteRowBuckets;
         // plain: the same trades as the 32-slot row table holds (at most 32 coupons per leg, i.e. up to 3 lite rows); longer
         // ones keep their chained rows.  (seg_*[k] holds bucket kLiteSegments - 1 - k: longest first; route.hpp)

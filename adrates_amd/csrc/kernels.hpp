@@ -45,8 +45,8 @@ constexpr int kLiteThreads = 512;
 constexpr int kLiteWavesPerSimd = 4;                                 // 2 blocks of 8 waves per CU (105 VGPRs)
 constexpr int kLiteSlots = 16;
 constexpr int kLiteCoupons = 15;
-constexpr int kLiteSegments = 9;                                     // distinct row counts per table: 1, 2, 3, 4, 6, 8, 12, 16, 24 rows
-                                                                     // (capi.hip) = up to 360 coupons per leg
+constexpr int kLiteSegments = 9;                                     // distinct row counts per table: 1, 2, 3, 4, 6, 8, 12, 16, 26 rows
+                                                                     // (route.hpp) = up to 390 coupons per leg
 
 // Per-trade header, 32 bytes, read once per trade with scalar loads.
 struct TradeHeader {

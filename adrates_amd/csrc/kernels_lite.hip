@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
         ADR_STAMP(0);   // waiting for the step's inputs
         if (r == 0) {
             N = nx_N; spread = nx_spread; t = nx_trade; live = t >= 0;
-            n_flt = nx_meta & 0x1ff; n_fix = (nx_meta >> 9) & 0x1ff;            // (up to 360 coupons per leg: 24 rows)
+            n_flt = nx_meta & 0x1ff; n_fix = (nx_meta >> 9) & 0x1ff;            // (up to 390 coupons per leg: 26 rows)
             sl = (nx_meta & 0x40000) ? -1.0 : 1.0; sf = (nx_meta & 0x80000) ? -1.0 : 1.0;
             pv = d0 = d1 = e0 = e1 = 0.0;
             d2 = d3 = e2 = e3 = 0.0;
@@ -373,7 +373,10 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                 const bool ratio = valid && accrues;
                 Lookup qs{0, 0, 0.0, 0.0}, qe{0, 0, 0.0, 0.0}, qp{0, 0, 0.0, 0.0};
                 double ls = 0.0, le = 0.0, lp = 0.0;
-                if (valid) { qp = curve_lookup<true>(c, tp); lp = fma(qp.ba, c.log_df[qp.ka], qp.bb * c.log_df[qp.kb]); }
+                // (a coupon "paid" at the value time - the weighted coupons of a leg projected on another curve, DESIGN.md
+                // section 9 - needs no lookup: D(0) = 1 and the value-time knot carries no sensitivity)
+                const bool paid_later = valid && tp != 0.0;
+                if (paid_later) { qp = curve_lookup<true>(c, tp); lp = fma(qp.ba, c.log_df[qp.ka], qp.bb * c.log_df[qp.kb]); }
                 if (ratio) {
                     qs = curve_lookup<true>(c, ts); ls = fma(qs.ba, c.log_df[qs.ka], qs.bb * c.log_df[qs.kb]);
                     qe = curve_lookup<true>(c, te); le = fma(qe.ba, c.log_df[qe.ka], qe.bb * c.log_df[qe.kb]);
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                 if (DELTA) {
                     sweep(ratio, om_r * qs.ba, om_r * qs.bb, qs.ka, qs.kb, qs.ba, qs.bb);
                     sweep(ratio, -om_r * qe.ba, -om_r * qe.bb, qe.ka, qe.kb, qe.ba, qe.bb);
-                    sweep(valid, (om_r + om_p) * qp.ba, (om_r + om_p) * qp.bb, qp.ka, qp.kb, qp.ba, qp.bb);
+                    sweep(paid_later, (om_r + om_p) * qp.ba, (om_r + om_p) * qp.bb, qp.ka, qp.kb, qp.ba, qp.bb);
                 }
                 ADR_STAMP(3);   // entries + ladder
             }

@@ -17,7 +17,7 @@ namespace route {
 
 // kernel families
 enum Family : int {
-    F_LITE = 0,           // lite kernel: PV / PV + delta, 16-slot rows, trades without payment lag, <= 32 coupons per leg
+    F_LITE = 0,           // lite kernel: PV / PV + delta, 16-slot rows, trades without payment lag (<= 384 coupons per leg)
     F_LITE_LAG = 1,       // ... its payment-lag rows (<= 360 coupons, log-linear schemes)
     F_FAST = 2,           // fast kernel on the 32-slot row table
     F_FAST_CHAINED = 3,   // ... chains of rows (33-384 coupons per leg)
@@ -158,8 +158,8 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
     int general_set = S_ALL;
     int64_t general_n = n;
     if (!want_gamma && (lite_elsewhere || use_lite_lag)) {
-        if (lite_elsewhere) rows = 0;                         // the lite table holds exactly the 32-slot row table's trades
-        if (use_fast) {                                       // long trades keep their chained rows
+        if (lite_elsewhere) { rows = 0; chained = 0; }        // the lite table holds the trades of both 32-slot row tables
+        if (use_fast) {                                       // (without lite rows: long trades keep their chained rows)
             general_set = use_lite_lag ? S_GENERAL_B : S_GENERAL;
             general_n = use_lite_lag ? tc.n_general_b : tc.n_general;
         } else {                                              // no packed layout: long trades join the general list
@@ -170,7 +170,7 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
     } else if (use_fast) {
         general_set = use_lag ? S_REST : S_GENERAL;
         general_n = use_lag ? tc.n_rest : tc.n_general;
-        if (plan.knot) rows = 0;
+        if (plan.knot) { rows = 0; chained = 0; }
     } else {
         rows = 0; chained = 0;                                // the general kernel walks every trade
         if (plan.knot) { general_set = S_NONLITE; general_n = tc.n_nonlite; }
@@ -204,7 +204,7 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int64_t kMaxChain = 12;                                       // rows per trade in the chained table: legs of up to 384 coupons
 constexpr int64_t kMaxChainLag = kLagScratchNodes / kRowSlots;          // ... payment-lag legs: 128 (the variant's per-trade stash)
-static const int64_t kLiteRowBuckets[kLiteSegments] = {1, 2, 3, 4, 6, 8, 12, 16, 24};   // lite rows per trade, rounded up
+static const int64_t kLiteRowBuckets[kLiteSegments] = {1, 2, 3, 4, 6, 8, 12, 16, 26};   // lite rows per trade, rounded up (26 x 15 >= 384)
 
 struct TradeClasses {
     std::vector<int32_t> list_fast, list_long, list_general, list_lagged, list_lagged_long, list_rest;
@@ -232,9 +232,10 @@ inline void classify_trades(int64_t n, const int64_t* fix_off, const int64_t* fl
         const bool general = rows > kMaxChain || lagged;
         (general ? out.list_general : rows > 1 ? out.list_long : out.list_fast).push_back(static_cast<int32_t>(t));
         if (general) (rows == 1 ? out.list_lagged : rows <= kMaxChainLag ? out.list_lagged_long : out.list_rest).push_back(static_cast<int32_t>(t));
-        // lite tables: plain = the trades of the 32-slot row table (up to 3 lite rows); with payment lag / weights: up to 24 rows
+        // lite tables: plain = the trades of the 32-slot row tables, one-row and chained (legs of up to 384 coupons = 26 lite
+        // rows of 15); with payment lag / weights: as many rows as the buckets allow
         const int bucket = lite_bucket(t);
-        if (!lagged && rows == 1) { out.seg_plain[kLiteSegments - 1 - bucket].push_back(static_cast<int32_t>(t)); continue; }
+        if (!general) { out.seg_plain[kLiteSegments - 1 - bucket].push_back(static_cast<int32_t>(t)); continue; }
         out.nonlite.push_back(static_cast<int32_t>(t));
         if (lagged && bucket < kLiteSegments) {
             out.seg_lag[kLiteSegments - 1 - bucket].push_back(static_cast<int32_t>(t));
