@@ -377,10 +377,17 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                 // section 9 - needs no lookup: D(0) = 1 and the value-time knot carries no sensitivity)
                 const bool paid_later = valid && tp != 0.0;
                 if (paid_later) { qp = curve_lookup<true>(c, tp); lp = fma(qp.ba, c.log_df[qp.ka], qp.bb * c.log_df[qp.kb]); }
-                if (ratio) {
-                    qs = curve_lookup<true>(c, ts); ls = fma(qs.ba, c.log_df[qs.ka], qs.bb * c.log_df[qs.kb]);
-                    qe = curve_lookup<true>(c, te); le = fma(qe.ba, c.log_df[qe.ka], qe.bb * c.log_df[qe.kb]);
-                }
+                // Accrual periods tile a leg: coupon j starts where coupon j - 1 ends.  Such a start time IS the previous
+                // lane's end time - the same lookup - so the lane takes the previous lane's log discount factor through DPP
+                // instead of searching again, and its (+) entries join the previous lane's (-) entries on the same two knots:
+                // one lookup, one exponential and one pair of entries per coupon instead of two; only a row's first coupon
+                // (and a coupon after an accrual gap) looks its start time up and leaves start entries of its own.
+                if (ratio) { qe = curve_lookup<true>(c, te); le = fma(qe.ba, c.log_df[qe.ka], qe.bb * c.log_df[qe.kb]); }
+                // (every cross-lane move sits outside conditionals: inside one, its source lanes may be masked off)
+                const double prev_ratio = row_prev(ratio ? 1.0 : 0.0), prev_te = row_prev(te), le_prev = row_prev(le);
+                const bool chained = ratio && l > 0 && prev_ratio != 0.0 && prev_te == ts;
+                if (ratio && !chained) { qs = curve_lookup<true>(c, ts); ls = fma(qs.ba, c.log_df[qs.ka], qs.bb * c.log_df[qs.kb]); }
+                if (chained) ls = le_prev;
                 const double w_not = sl * N * cw;
                 const double om_r = ratio ? w_not * exp(ls - le + lp) : 0.0;
                 double a_q = valid ? w_not * (spread * al - (accrues ? 1.0 : 0.0)) : 0.0;
@@ -389,8 +396,12 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                 pv += om_r + om_p;
                 ADR_STAMP(2);   // lookups + exp
                 if (DELTA) {
-                    sweep(ratio, om_r * qs.ba, om_r * qs.bb, qs.ka, qs.kb, qs.ba, qs.bb);
-                    sweep(ratio, -om_r * qe.ba, -om_r * qe.bb, qe.ka, qe.kb, qe.ba, qe.bb);
+                    // the end entries carry -omega of their own coupon and +omega of the next one when that one is chained to it
+                    const double next_flag = row_next(chained ? 1.0 : 0.0), next_om = row_next(om_r);
+                    const bool next_chained = l + 1 < L && next_flag != 0.0;
+                    const double om_e = (next_chained ? next_om : 0.0) - om_r;
+                    sweep(ratio && !chained, om_r * qs.ba, om_r * qs.bb, qs.ka, qs.kb, qs.ba, qs.bb);
+                    sweep(ratio, om_e * qe.ba, om_e * qe.bb, qe.ka, qe.kb, qe.ba, qe.bb);
                     sweep(paid_later, (om_r + om_p) * qp.ba, (om_r + om_p) * qp.bb, qp.ka, qp.kb, qp.ba, qp.bb);
                 }
                 ADR_STAMP(3);   // entries + ladder
