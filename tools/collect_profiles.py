@@ -19,6 +19,8 @@ copies = {
     f"bench_{tag}_many_pillars.json": "many_pillars_bench.json", f"bench_{tag}_payment_lag_linfwd.json": "payment_lag_linfwd_bench.json",
     f"ablate_{tag}_wide.log": "wide_ablations.txt", f"pmc_{tag}_wide.txt": "wide_pmc_counters.txt",
     f"routing_audit_{tag}.txt": "routing_audit.txt",
+    f"bench_{tag}_aggregate_only.json": "aggregate_only_bench.json", f"bench_{tag}_aggregate_only_delta.json": "aggregate_only_delta_bench.json",
+    f"bench_{tag}_aggregate_tool.json": "aggregate_only_paths.json", f"ab_calls_{tag}.txt": "final_call_variants.txt",
 }
 for src, dst in copies.items():
     if os.path.exists(f"{G}/{src}"):

@@ -14,6 +14,11 @@ python bench.py --trades 100000 --requests value,delta --cpu-baseline-seconds 0 
 python bench.py --trades 1000000 --requests value,delta --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_delta_1m.json 2>/dev/null || exit 1
 python bench.py --trades 1000000 --requests value --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_value_1m.json 2>/dev/null || exit 1
 python tools/ablate.py > gpurun_out/ablate_$TAG.log 2>&1 || exit 1
+# round 4: the aggregate-only mode (Portfolio.compute's ladder alone) as its own bench lines, interleaved call timing
+python bench.py --aggregate-only --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_aggregate_only.json 2>/dev/null || exit 1
+python bench.py --aggregate-only --requests value,delta --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_aggregate_only_delta.json 2>/dev/null || exit 1
+python tools/bench_aggregate.py > gpurun_out/bench_${TAG}_aggregate_tool.json 2>/dev/null || exit 1
+python tools/ab_calls.py > gpurun_out/ab_calls_$TAG.txt 2>/dev/null || exit 1
 python tools/bench_long_legs.py > gpurun_out/bench_${TAG}_long_legs.json 2>/dev/null || exit 1
 python tools/bench_curve_build.py > gpurun_out/bench_${TAG}_curve_build.json 2>/dev/null || exit 1
 python tools/bench_long_legs.py 200000 lag > gpurun_out/bench_${TAG}_payment_lag.json 2>/dev/null || exit 1
@@ -24,6 +29,9 @@ python bench.py --interp LINEAR_FWD_RATES --cpu-baseline-seconds 0 > gpurun_out/
 bash tools/profile.sh $TAG || exit 1
 bash tools/pmc.sh && python tools/pmc_summary.py > gpurun_out/pmc_$TAG.txt || exit 1
 python tools/pmc_fp64_summary.py ${RND:-r04} > gpurun_out/pmc_${TAG}_fp64.json || exit 1
+# round 4: the PV + delta pass (lite kernel) at both sizes: kernel stats + FETCH / WRITE passes
+BENCH_ARGS="--trades 100000 --requests value,delta" bash tools/profile.sh ${TAG}_delta100k || exit 1
+BENCH_ARGS="--trades 1000000 --requests value,delta" bash tools/profile.sh ${TAG}_delta1m || exit 1
 bash tools/profile_paths.sh $TAG || exit 1
 bash tools/pmc_lag.sh && python tools/pmc_summary.py 200000 > gpurun_out/pmc_${TAG}_lag.txt || exit 1
 if [ -f variants_stamps.so ]; then
