@@ -495,7 +495,8 @@ def build_identity() -> dict:
     return {"source_sha256": src.hexdigest(), "lib_sha256": lib, "lib": os.path.relpath(_LIB_PATH, os.path.dirname(root))}
 
 
-ROUTE_FAMILIES = ("lite", "lite_lag", "fast", "fast_chained", "fast_lag", "fast_lag_chained", "general", "wide", "tiled", "knot")
+ROUTE_FAMILIES = ("lite", "lite_lag", "fast", "fast_chained", "fast_lag", "fast_lag_chained", "general", "wide", "tiled", "knot",
+                  "knot_lag")
 ROUTE_SETS = ("lite", "lite_lag", "rows", "chained", "lagged", "lagged_chained", "general", "general_b", "rest", "nonlite",
               "nonlite_b", "all")
 

@@ -65,12 +65,14 @@ struct adr_ctx {
     // aggregate-only mode (kernels_knot.hip): block records [knot_blocks][1 + 3 Kc] of the knot-space kernel and their sum
     double* knot_partials = nullptr;
     double* knot_reduced = nullptr;
+    double* knot_overflow = nullptr;        // [kKnotLagMaxKc^2] pairs of knots beyond the bands (payment-lag rows)
     int knot_blocks = 0;
 };
 
 namespace {
 constexpr int kKnotMaxKc = 640;             // reachable knots a curve can have (its dense 32-wide Jacobian must fit the LDS)
-constexpr int kKnotStrideMax = 1 + 3 * kKnotMaxKc;
+constexpr int kKnotLagMaxKc = 256;          // ... for the knot pass over payment-lag rows (16 pair bands per knot, a dense overflow matrix)
+constexpr int kKnotStrideMax = std::max(1 + 3 * kKnotMaxKc, 1 + (2 + adr::kKnotBand) * kKnotLagMaxKc);
 }
 
 struct adr_curve {
@@ -159,7 +161,8 @@ struct adr_trades {
                            cv.n_lut, cv.n_fringe, cv.pc_pad, cv.Eu, want_delta ? 1 : 0, want_gamma ? 1 : 0, per_trade ? 1 : 0, has_agg ? 1 : 0}};
         std::lock_guard<std::mutex> lock(plan_mutex);
         if (!plan_valid || std::memcmp(&key, &plan_key, sizeof key) != 0) {
-            plan = adr::route::make_plan(cv, counts(), want_delta, want_gamma, per_trade, has_agg, c.n_cu, c.max_blocks, c.knot_blocks, kKnotMaxKc);
+            plan = adr::route::make_plan(cv, counts(), want_delta, want_gamma, per_trade, has_agg, c.n_cu, c.max_blocks, c.knot_blocks,
+                                         kKnotMaxKc, kKnotLagMaxKc);
             plan_key = key;
             plan_valid = true;
         }
@@ -211,12 +214,14 @@ int adr_init(int device_ordinal, adr_ctx** out) {
         return fail_hip(e, "hipMalloc(dump)");
     }
     ctx->knot_blocks = std::max(1, ctx->n_cu) * adr::kLiteWavesPerSimd * 4 * 64 / adr::kLiteThreads;   // blocks resident at once
-    e = hipMalloc(reinterpret_cast<void**>(&ctx->knot_partials), sizeof(double) * static_cast<size_t>(ctx->knot_blocks + 1) * kKnotStrideMax);
+    e = hipMalloc(reinterpret_cast<void**>(&ctx->knot_partials),
+                  sizeof(double) * (static_cast<size_t>(ctx->knot_blocks + 1) * kKnotStrideMax + static_cast<size_t>(kKnotLagMaxKc) * kKnotLagMaxKc));
     if (e != hipSuccess) {
         hipFree(ctx->dump); hipFree(ctx->partials); hipStreamDestroy(ctx->stream); delete ctx;
         return fail_hip(e, "hipMalloc(knot partials)");
     }
     ctx->knot_reduced = ctx->knot_partials + static_cast<size_t>(ctx->knot_blocks) * kKnotStrideMax;
+    ctx->knot_overflow = ctx->knot_reduced + kKnotStrideMax;
     // Dynamic-LDS ceiling of every kernel instantiation, once per device: the whole 160 KiB of a CU.  (Setting it per
     // uploaded curve to that curve's need would LOWER it below what an earlier, larger curve's launches request.)
     e = adr::set_kernel_lds_limits(kLdsBudget, kLdsBudget);
@@ -1117,6 +1122,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     o.gamma = want_gamma ? gamma_dev : nullptr;
     o.lag_scratch = trades->lag_scratch;
     o.knot_partials = ctx->knot_partials;
+    o.knot_overflow = ctx->knot_overflow;
 
     // The launch plan (route.hpp): which kernel family takes which of the batch's tables / lists.  It depends on the curve's
     // class, the batch's table sizes and the request only; the batch keeps the last one (a book is priced again and again on
@@ -1142,7 +1148,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     };
     if (plan.tiled && agg_dev)   // tiles no launch covers (no GAMMA: the off-diagonal ones; PV alone: every delta tile) stay zero
         ADR_HIP(hipMemsetAsync(agg_dev, 0, agg_bytes, stream));
-    const R::Launch* knot = nullptr;
+    const R::Launch *knot = nullptr, *knot_lag = nullptr;
     for (const R::Launch& L : plan.launches) {
         o.block_partials = agg_dev ? ctx->partials + static_cast<size_t>(L.first_block) * stride : nullptr;
         switch (L.family) {
@@ -1167,6 +1173,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
                 break;
             }
             case R::F_KNOT: knot = &L; break;
+            case R::F_KNOT_LAG: knot_lag = &L; break;
             default: return fail(ADR_ERR_INVALID, "adr_price: unknown kernel family in the launch plan");
         }
     }
@@ -1180,7 +1187,15 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
         // are summed in KNOT space and projected once (kernels_lite.hip KNOT instantiations, kernels_knot.hip); the
         // projection ADDS to what the other families' reduction wrote above
         ADR_HIP(adr::launch_price_knot(curve->dev, trades->lite, o, want_gamma, knot->blocks, stream));
-        ADR_HIP(adr::launch_knot_project(curve->dev, ctx->knot_partials, knot->blocks, ctx->knot_reduced, want_delta, want_gamma, agg_dev, stream));
+        ADR_HIP(adr::launch_knot_project(curve->dev, ctx->knot_partials, knot->blocks, ctx->knot_reduced, want_delta, want_gamma, 1, nullptr, agg_dev, stream));
+    }
+    if (knot_lag) {
+        // ... and the payment-lag rows' ratio nodes: pair bands per wave, pairs farther apart in the launch's overflow matrix
+        const size_t kc = static_cast<size_t>(curve->dev.Kc);
+        if (want_gamma) ADR_HIP(hipMemsetAsync(ctx->knot_overflow, 0, sizeof(double) * kc * kc, stream));
+        ADR_HIP(adr::launch_price_knot(curve->dev, trades->lite_lag, o, want_gamma, knot_lag->blocks, stream));
+        ADR_HIP(adr::launch_knot_project(curve->dev, ctx->knot_partials, knot_lag->blocks, ctx->knot_reduced, want_delta, want_gamma,
+                                         adr::kKnotBand, ctx->knot_overflow, agg_dev, stream));
     }
     return ADR_OK;
 }
@@ -1263,7 +1278,7 @@ int adr_route_host(int interp_method, int K, int P, const double* times, const d
     tc.lag_blocks = tc.lag_scratch ? n_cu : 0;
     const bool want_gamma = (req_mask & ADR_REQ_GAMMA) != 0, want_delta = want_gamma || (req_mask & ADR_REQ_DELTA) != 0;
     const R::Plan plan = R::make_plan(cv, tc, want_delta, want_gamma, per_trade != 0, aggregate != 0, n_cu, n_cu * 16,
-                                      n_cu * adr::kLiteWavesPerSimd * 4 * 64 / adr::kLiteThreads, kKnotMaxKc);
+                                      n_cu * adr::kLiteWavesPerSimd * 4 * 64 / adr::kLiteThreads, kKnotMaxKc, kKnotLagMaxKc);
     if (plan.error) return fail(ADR_ERR_INVALID, std::string("adr_route_host: ") + plan.error);
     // who is covered how often: the tile launches of one pass count once
     for (int64_t i = 0; i < n; ++i) cover[i] = 0;

@@ -45,6 +45,7 @@ constexpr int kLiteThreads = 512;
 constexpr int kLiteWavesPerSimd = 4;                                 // 2 blocks of 8 waves per CU (105 VGPRs)
 constexpr int kLiteSlots = 16;
 constexpr int kLiteCoupons = 15;
+constexpr int kKnotBand = 16;                                        // aggregate-only mode, payment-lag rows: pair bands kept per wave (knots up to 16 apart)
 constexpr int kLiteSegments = 9;                                     // distinct row counts per table: 1, 2, 3, 4, 6, 8, 12, 16, 26 rows
                                                                      // (route.hpp) = up to 390 coupons per leg
 
@@ -204,7 +205,8 @@ struct OutputsDev {
     double* block_partials;  // [grid][kAggStride] or null
     double* dump;            // [32*32] sink for the gamma stores of the idle trade slot of a wave's last unit
     double* lag_scratch;     // payment-lag variant: [grid waves][2 groups][kLagScratchNodes][kLagStashDoubles]
-    double* knot_partials;   // aggregate-only mode: [grid][1 + 3 Kc] block sums {pv, w[Kc], D[Kc], O[Kc]} of the knot-space kernel
+    double* knot_partials;   // aggregate-only mode: [grid][record] block sums {pv, w[Kc], D[Kc], P[bands][Kc]} of the knot-space kernel
+    double* knot_overflow;   // ... [Kc][Kc] pairs of knots farther apart than the bands (payment-lag rows; zeroed per launch)
     unsigned long long* stamps;  // diagnostic builds only (ADR_STAMPS): [grid*waves][8] cycle sums per phase
 };
 
@@ -272,13 +274,15 @@ hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const Ou
 // Aggregate-only mode (kernels_lite.hip KNOT instantiations + kernels_knot.hip): the book's knot-space sums from the rows of
 // the lite table, reduced over the blocks in a fixed order, projected once to the pillar ladders and ADDED to agg
 // ([pv, delta[P], gamma[P*P]]; the caller has zeroed it or another kernel family's reduction has written it).
-size_t knot_kernel_lds_bytes(const CurveDev& cv, bool gamma);
+size_t knot_kernel_lds_bytes(const CurveDev& cv, bool gamma, bool lag = false);
+int knot_record_doubles(const CurveDev& cv, bool lag);      // doubles per block record
 int knot_kernel_threads();
 hipError_t launch_price_knot(const CurveDev& cv, const LiteRowsDev& tr, const OutputsDev& out, bool want_gamma, int n_blocks,
                              hipStream_t stream);
-// partials [n_blocks][1 + 3 Kc] -> reduced [1 + 3 Kc] (fixed order), then agg += projection; `reduced` is scratch
+// partials [n_blocks][record] -> reduced [record] (fixed order), then agg += projection; `reduced` is scratch; bands: 1, or
+// kKnotBand with `overflow` ([Kc][Kc], may hold pairs beyond the bands) for the payment-lag rows
 hipError_t launch_knot_project(const CurveDev& cv, const double* partials, int n_blocks, double* reduced, bool want_delta,
-                               bool want_gamma, double* agg, hipStream_t stream);
+                               bool want_gamma, int bands, const double* overflow, double* agg, hipStream_t stream);
 // has_gamma == false: the gamma part of the partials was not written (no gamma requested); agg's gamma part is zeroed
 // (tile_i, tile_j): the pillar tile pair the partials belong to (0, 0 for P <= 32); off-diagonal tiles are also written
 // transposed; pv comes from tile (0, 0), delta from the diagonal tiles

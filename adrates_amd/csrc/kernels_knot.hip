@@ -9,6 +9,9 @@
 //
 //   pv,   w_k = sum w b_k,   D_k = sum w b_k^2,   O_k = sum w b_k b_{k+1}      (nodes w = c exp(ba L[ka] + bb L[kb]))
 //
+// Ratio nodes (payment lag, weighted coupons: w exp(L(ts) - L(te) + L(tp))) couple knots of up to three intervals; their rows
+// leave pair BANDS P_d[k] = sum w u_k u_{k+d}, d = 1 .. kKnotBand, and - for pairs farther apart - a dense overflow matrix.
+//
 // Here: (1) the block records are summed in a fixed order (one wavefront per number, lanes stride over the blocks, fixed
 // butterfly - no atomics, the result does not depend on scheduling), (2) one projection per launch
 //
@@ -58,7 +61,8 @@ __device__ __forceinline__ double lc_at(const CurveDev& cv, const int* col_off, 
 }
 
 // Block p < P: row p of the gamma matrix (thread q); block P: pv and the delta ladder (thread p).
-__global__ __launch_bounds__(64) void knot_project_kernel(CurveDev cv, const double* reduced, int want_delta, int want_gamma, double* agg) {
+__global__ __launch_bounds__(64) void knot_project_kernel(CurveDev cv, const double* reduced, int want_delta, int want_gamma, int bands,
+                                                          const double* overflow, double* agg) {
     __shared__ int col_off[kWidePad + 1];
     const int P = cv.P, Kc = cv.Kc, q = threadIdx.x;
     if (threadIdx.x == 0) {
@@ -85,14 +89,22 @@ __global__ __launch_bounds__(64) void knot_project_kernel(CurveDev cv, const dou
     const int p = blockIdx.x;
     double s = 0.0;
     for (int k = 0; k < Kc; ++k) {
-        const double wk = w[k], dk = D[k], ok = k + 1 < Kc ? O[k] : 0.0;
-        if (wk == 0.0 && dk == 0.0 && ok == 0.0) continue;          // (wave-uniform: the sums are the same for every thread)
+        const double wk = w[k], dk = D[k];
         const double ap = lj_at(cv, k, p), aq = lj_at(cv, k, q);
-        s = fma(dk * ap, aq, s);
-        if (ok != 0.0) {
-            const double bp = lj_at(cv, k + 1, p), bq = lj_at(cv, k + 1, q);
+        if (dk != 0.0) s = fma(dk * ap, aq, s);                      // (wave-uniform branches: the sums are the same for every thread)
+        for (int d = 1; d <= bands && k + d < Kc; ++d) {             // pairs of knots (k, k + d): band d
+            const double ok = O[(d - 1) * Kc + k];
+            if (ok == 0.0) continue;
+            const double bp = lj_at(cv, k + d, p), bq = lj_at(cv, k + d, q);
             s = fma(ok, fma(ap, bq, bp * aq), s);
         }
+        if (overflow)                                                // ... and the pairs farther apart (payment-lag rows; mostly zeros)
+            for (int l = k + bands + 1; l < Kc; ++l) {
+                const double ok = overflow[static_cast<size_t>(k) * Kc + l];
+                if (ok == 0.0) continue;
+                const double bp = lj_at(cv, l, p), bq = lj_at(cv, l, q);
+                s = fma(ok, fma(ap, bq, bp * aq), s);
+            }
         if (wk != 0.0) s = fma(wk, lc_at(cv, col_off, k, p, q), s);
     }
     agg[1 + P + p * P + q] += s * 1e-8;
@@ -101,12 +113,13 @@ __global__ __launch_bounds__(64) void knot_project_kernel(CurveDev cv, const dou
 }  // namespace
 
 hipError_t launch_knot_project(const CurveDev& cv, const double* partials, int n_blocks, double* reduced, bool want_delta,
-                               bool want_gamma, double* agg, hipStream_t stream) {
-    const int stride = 1 + 3 * cv.Kc, n_values = want_gamma ? stride : 1 + cv.Kc;     // (without GAMMA only pv and w were written)
+                               bool want_gamma, int bands, const double* overflow, double* agg, hipStream_t stream) {
+    const int stride = 1 + (2 + bands) * cv.Kc, n_values = want_gamma ? stride : 1 + cv.Kc;     // (without GAMMA only pv and w were written)
     hipLaunchKernelGGL(knot_reduce_kernel, dim3((n_values + 3) / 4), dim3(256), 0, stream, partials, n_blocks, stride, n_values, reduced);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(knot_project_kernel, dim3(cv.P + 1), dim3(64), 0, stream, cv, reduced, want_delta ? 1 : 0, want_gamma ? 1 : 0, agg);
+    hipLaunchKernelGGL(knot_project_kernel, dim3(cv.P + 1), dim3(64), 0, stream, cv, reduced, want_delta ? 1 : 0, want_gamma ? 1 : 0, bands,
+                       want_gamma ? overflow : nullptr, agg);
     return hipGetLastError();
 }
 

@@ -121,10 +121,13 @@ template <bool DELTA, bool LINDF, bool LAG, int NSEG, bool W64 = false, int KNOT
 __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                                                                                        OutputsDev out) {
     static_assert(!(LAG && LINDF), "payment-lag trades under LINEAR_FWD_RATES go to the general kernel");
-    static_assert(KNOT == 0 || (DELTA && !LAG && !W64), "aggregate-only mode: trades without ratio nodes, any pillar count");
+    static_assert(KNOT == 0 || (DELTA && !W64), "aggregate-only mode: any pillar count (no 64-wide Jacobian table is needed)");
     constexpr int PW = W64 ? kWidePad : kPillarPad;       // pillars per row of the Jacobian table
     constexpr int PPL = PW / L;                           // pillars per lane: 2, or 4 on the 64-wide table
-    constexpr int NT = KNOT == 2 ? 3 : 1;                 // KNOT: tables per wave (w; D, O)
+    // KNOT: tables per wave - w; D and the pair bands P[d - 1][k] = sum over pairs of knots (k, k + d): one band (the old O)
+    // for rows without ratio nodes, kKnotBand for payment-lag rows, whose nodes couple knots of up to three intervals
+    constexpr int BAND = LAG ? kKnotBand : 1;
+    constexpr int NT = KNOT == 2 ? 2 + BAND : 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS carve-up: per-wave entry slots (16-byte aligned) or knot tables, doubles, int16 tables
     unsigned char* s_rec = smem_raw;
@@ -177,7 +180,20 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
     const unsigned char* lj_lane = reinterpret_cast<const unsigned char*>(s_lj) + l * (8 * PPL);    // pillars PPL l .. PPL l + PPL - 1
     double* knot_w = s_knot + wave * (NT * cv.Kc);        // KNOT: this wave's tables
     double* knot_d = knot_w + (NT > 1 ? cv.Kc : 0);
-    double* knot_o = knot_w + (NT > 1 ? 2 * cv.Kc : 0);
+    double* knot_o = knot_w + (NT > 1 ? 2 * cv.Kc : 0);      // band d at knot_o + (d - 1) Kc
+    // second-order sum of a pair of knot weights of one node: w ci cj on (ki, kj) and on (kj, ki).  Equal knots: the diagonal
+    // takes both; neighbours up to BAND apart: the pair bands; farther (a long accrual period on a dense short end): the
+    // launch's dense overflow matrix in global memory (rare; the only sum whose order depends on scheduling).  The value-time
+    // knot (0) carries no sensitivity and is left out - it is also the knot farthest from everything.
+    auto pair_add = [&](int ki, double ci, int kj, double cj, double om) {
+        if (ki == 0 || kj == 0) return;
+        const double v = om * ci * cj;
+        if (v == 0.0) return;
+        const int lo = ki < kj ? ki : kj, d = ki < kj ? kj - ki : ki - kj;
+        if (d == 0) __hip_atomic_fetch_add(knot_d + lo, 2.0 * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        else if (d <= BAND) __hip_atomic_fetch_add(knot_o + (d - 1) * cv.Kc + lo, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        else unsafeAtomicAdd(out.knot_overflow + static_cast<size_t>(lo) * cv.Kc + (lo + d), v);
+    };
 
     double tot_pv = 0.0, tot_d0 = 0.0, tot_d1 = 0.0, tot_d2 = 0.0, tot_d3 = 0.0;
 
@@ -307,14 +323,14 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
             // nodes need no flags.  (On curves whose pillar dates are runs of duplicate knots a node's right-hand knot -
             // the first of a run - is never the next node's left-hand knot - the last of that run -, so merging
             // neighbours' entries buys nothing: tried, slower.)
-            auto sweep = [&](bool on, double ca, double cb, int ka, int kb, double ba, double bb) {
+            auto sweep = [&](bool on, double ca, double cb, int ka, int kb, double ba, double bb, bool plain_node = true) {
                 if constexpr (KNOT != 0) {
                     // aggregate-only: the node's five numbers into this wave's knot tables.  (ca, cb) = w (ba, bb) - under
                     // LINEAR_FWD_RATES the two single-knot amounts, each with weight 1 on its own knot and no cross term.
                     if (on) {
                         __hip_atomic_fetch_add(knot_w + ka, ca, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         if (cb != 0.0) __hip_atomic_fetch_add(knot_w + kb, cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        if (KNOT == 2) {
+                        if (KNOT == 2 && plain_node) {          // (the parts of a ratio node leave their second-order sums together)
                             __hip_atomic_fetch_add(knot_d + ka, LINDF ? ca : ca * ba, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             if (cb != 0.0) {
                                 __hip_atomic_fetch_add(knot_d + kb, LINDF ? cb : cb * bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -395,14 +411,40 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                 const double om_p = valid ? a_q * exp(lp) : 0.0;
                 pv += om_r + om_p;
                 ADR_STAMP(2);   // lookups + exp
+                if constexpr (KNOT == 2) {
+                    // second-order sums of the ratio node omega_r exp(L(ts) - L(te) + L(tp)): u = b(ts) - b(te) + b(tp) over up to
+                    // six knots (a chained start sits on the previous lane's end knots), W += omega_r u u^T; and of the payment
+                    // node omega_p on b(tp).  Six squares and fifteen pairs at most; zero weights and the value-time knot drop out.
+                    const int pka = __shfl_up(qe.ka, 1, 64), pkb = __shfl_up(qe.kb, 1, 64);          // (outside conditionals)
+                    const double pba = row_prev(qe.ba), pbb = row_prev(qe.bb);
+                    int kk[6] = {chained ? pka : qs.ka, chained ? pkb : qs.kb, qe.ka, qe.kb, qp.ka, qp.kb};
+                    double cc[6] = {chained ? pba : qs.ba, chained ? pbb : qs.bb, -qe.ba, -qe.bb, qp.ba, qp.bb};
+                    // a payment time a few days behind the accrual end sits on the same two knots: its weights join the end's
+                    // (four terms instead of six: ten sums instead of twenty-one)
+                    if (qp.ka == qe.ka && qp.kb == qe.kb) { cc[2] += cc[4]; cc[3] += cc[5]; cc[4] = 0.0; cc[5] = 0.0; }
+                    if (ratio) {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+                            if (kk[i] != 0 && cc[i] != 0.0)
+                                __hip_atomic_fetch_add(knot_d + kk[i], om_r * cc[i] * cc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+                            for (int j = i + 1; j < 6; ++j) pair_add(kk[i], cc[i], kk[j], cc[j], om_r);
+                        }
+                    }
+                    if (paid_later) {
+                        if (qp.ka != 0) __hip_atomic_fetch_add(knot_d + qp.ka, om_p * qp.ba * qp.ba, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        if (qp.kb != 0 && qp.bb != 0.0) __hip_atomic_fetch_add(knot_d + qp.kb, om_p * qp.bb * qp.bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        pair_add(qp.ka, qp.ba, qp.kb, qp.bb, om_p);
+                    }
+                }
                 if (DELTA) {
                     // the end entries carry -omega of their own coupon and +omega of the next one when that one is chained to it
                     const double next_flag = row_next(chained ? 1.0 : 0.0), next_om = row_next(om_r);
                     const bool next_chained = l + 1 < L && next_flag != 0.0;
                     const double om_e = (next_chained ? next_om : 0.0) - om_r;
-                    sweep(ratio && !chained, om_r * qs.ba, om_r * qs.bb, qs.ka, qs.kb, qs.ba, qs.bb);
-                    sweep(ratio, om_e * qe.ba, om_e * qe.bb, qe.ka, qe.kb, qe.ba, qe.bb);
-                    sweep(paid_later, (om_r + om_p) * qp.ba, (om_r + om_p) * qp.bb, qp.ka, qp.kb, qp.ba, qp.bb);
+                    sweep(ratio && !chained, om_r * qs.ba, om_r * qs.bb, qs.ka, qs.kb, qs.ba, qs.bb, false);
+                    sweep(ratio, om_e * qe.ba, om_e * qe.bb, qe.ka, qe.kb, qe.ba, qe.bb, false);
+                    sweep(paid_later, (om_r + om_p) * qp.ba, (om_r + om_p) * qp.bb, qp.ka, qp.kb, qp.ba, qp.bb, false);
                 }
                 ADR_STAMP(3);   // entries + ladder
             }
@@ -482,14 +524,14 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
 
     // ------------------------------------------------------------------------ block partial of the aggregate
     if constexpr (KNOT != 0) {
-        // knot tables: the waves' tables summed in wave order, the PV lanes by a fixed butterfly -> [pv, w[Kc], D[Kc], O[Kc]]
+        // knot tables: the waves' tables summed in wave order, the PV lanes by a fixed butterfly -> [pv, w[Kc], D[Kc], P[BAND][Kc]]
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) tot_pv += __shfl_xor(tot_pv, off, 64);
         __syncthreads();                                   // every wave's adds have been issued and (same-CU LDS) performed
         double* red_pv = reinterpret_cast<double*>(s_x);   // the search arrays are no longer needed
         if (lane == 0) red_pv[wave] = tot_pv;
         __syncthreads();
-        double* dst = out.knot_partials + static_cast<size_t>(blockIdx.x) * (1 + 3 * cv.Kc);
+        double* dst = out.knot_partials + static_cast<size_t>(blockIdx.x) * (1 + (2 + BAND) * cv.Kc);
         for (int i = threadIdx.x; i < NT * cv.Kc; i += kBlockThreads) {
             double s_ = 0.0;
 #pragma unroll
@@ -553,17 +595,22 @@ LiteFn lite_kernel(bool delta, bool lindf, bool lag, bool many_segments, bool w6
     return w64 ? lite_kernel_w<true>(delta, lindf, lag, many_segments) : lite_kernel_w<false>(delta, lindf, lag, many_segments);
 }
 
-// aggregate-only instantiations (KNOT = 1: first order, 2: with the second-order sums)
+// aggregate-only instantiations (KNOT = 1: first order, 2: with the second-order sums); lag: the payment-lag rows
 template <int KNOT>
-LiteFn knot_kernel_k(bool lindf, bool many) {
+LiteFn knot_kernel_k(bool lindf, bool many, bool lag) {
+    if (lag) return many ? &price_lite_kernel<true, false, true, kLiteSegments, false, KNOT> : &price_lite_kernel<true, false, true, 3, false, KNOT>;
     if (lindf) return many ? &price_lite_kernel<true, true, false, kLiteSegments, false, KNOT> : &price_lite_kernel<true, true, false, 3, false, KNOT>;
     return many ? &price_lite_kernel<true, false, false, kLiteSegments, false, KNOT> : &price_lite_kernel<true, false, false, 3, false, KNOT>;
 }
-LiteFn knot_kernel(bool gamma, bool lindf, bool many) { return gamma ? knot_kernel_k<2>(lindf, many) : knot_kernel_k<1>(lindf, many); }
+LiteFn knot_kernel(bool gamma, bool lindf, bool many, bool lag) {
+    return gamma ? knot_kernel_k<2>(lindf, many, lag) : knot_kernel_k<1>(lindf, many, lag);
+}
 }  // namespace
 
-size_t knot_kernel_lds_bytes(const CurveDev& cv, bool gamma) {
-    size_t bytes = sizeof(double) * static_cast<size_t>(kWavesPerBlock) * (gamma ? 3 : 1) * cv.Kc;
+int knot_record_doubles(const CurveDev& cv, bool lag) { return 1 + (2 + (lag ? kKnotBand : 1)) * cv.Kc; }
+
+size_t knot_kernel_lds_bytes(const CurveDev& cv, bool gamma, bool lag) {
+    size_t bytes = sizeof(double) * static_cast<size_t>(kWavesPerBlock) * (gamma ? 2 + (lag ? kKnotBand : 1) : 1) * cv.Kc;
     bytes += sizeof(double) * (2 * static_cast<size_t>(cv.K) + 2 * cv.Kc);
     bytes += sizeof(int16_t) * (2 * static_cast<size_t>(cv.K) + 2 * static_cast<size_t>(cv.n_lut));
     return (bytes + 15) & ~static_cast<size_t>(15);
@@ -573,9 +620,10 @@ int knot_kernel_threads() { return kBlockThreads; }
 
 hipError_t launch_price_knot(const CurveDev& cv, const LiteRowsDev& tr, const OutputsDev& out, bool want_gamma, int n_blocks,
                              hipStream_t stream) {
-    if (tr.te_w || !out.knot_partials) return hipErrorInvalidValue;     // rows without ratio nodes only
-    const size_t lds = knot_kernel_lds_bytes(cv, want_gamma);
-    hipLaunchKernelGGL(knot_kernel(want_gamma, cv.method == 2, tr.n_seg > 3), dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out);
+    const bool lag = tr.te_w != nullptr;                                // payment-lag rows: ratio nodes, log-linear schemes
+    if (!out.knot_partials || (lag && (cv.method == 2 || (want_gamma && !out.knot_overflow)))) return hipErrorInvalidValue;
+    const size_t lds = knot_kernel_lds_bytes(cv, want_gamma, lag);
+    hipLaunchKernelGGL(knot_kernel(want_gamma, cv.method == 2, tr.n_seg > 3, lag), dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out);
     return hipGetLastError();
 }
 
@@ -611,7 +659,10 @@ hipError_t set_lite_kernel_lds_limit(size_t bytes) {
                     }
     for (int g = 0; g < 2; ++g)
         for (int lin = 0; lin < 2; ++lin)
-            for (int many = 0; many < 2; ++many) fns.push_back(reinterpret_cast<const void*>(knot_kernel(g != 0, lin != 0, many != 0)));
+            for (int many = 0; many < 2; ++many) {
+                fns.push_back(reinterpret_cast<const void*>(knot_kernel(g != 0, lin != 0, many != 0, false)));
+                if (!lin) fns.push_back(reinterpret_cast<const void*>(knot_kernel(g != 0, false, many != 0, true)));
+            }
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
         if (e != hipSuccess) return e;

@@ -26,7 +26,8 @@ enum Family : int {
     F_GENERAL = 6,        // general kernel over a trade list
     F_WIDE = 7,           // wide variants of the general kernel (33-64 pillars, one launch)
     F_TILED = 8,          // general kernel once per pair of 32-pillar tiles (curves whose wide tables do not fit / PILLAR_TILES)
-    F_KNOT = 9            // aggregate-only: knot-space sums of the lite table's trades + one projection
+    F_KNOT = 9,           // aggregate-only: knot-space sums of the lite table's trades + one projection
+    F_KNOT_LAG = 10       // ... of the lite kernel's payment-lag rows (ratio nodes: pair bands; log-linear schemes)
 };
 // trade sets (adr_trades: tables and lists built by adr_trades_upload)
 enum Set : int {
@@ -62,7 +63,7 @@ struct Plan {
     int total_blocks = 0;            // blocks that write partials (all families but F_KNOT, F_TILED keeps its own layout)
     bool wide = false;               // partials in the wide layout (launch_reduce_wide)
     bool tiled = false;              // one reduction per tile launch
-    bool knot = false;
+    bool knot = false, knot_lag = false;
     const char* error = nullptr;     // "grid exceeds scratch"
 };
 
@@ -76,7 +77,7 @@ inline int blocks_for(int64_t units, int waves, int64_t cap) {
 // cv: only its integer fields are read (a CurveDev built from CurveTables on the host serves as well); has_hess: the curve
 // carries second derivatives.  per_trade: some per-trade output pointer is non-null; has_agg: agg is requested.
 inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta, bool want_gamma, bool per_trade, bool has_agg,
-                      int n_cu, int max_blocks, int knot_blocks, int knot_kc_max) {
+                      int n_cu, int max_blocks, int knot_blocks, int knot_kc_max, int knot_lag_kc_max) {
     Plan plan;
     const int64_t n = tc.n;
     if (n == 0) return plan;
@@ -85,6 +86,12 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
     // aggregate-only request: the lite table's trades in knot space
     plan.knot = has_agg && !per_trade && want_delta && tc.lite_units > 0 && cv.Kc <= knot_kc_max &&
                 knot_kernel_lds_bytes(cv, want_gamma) <= kLds;
+    // ... and the payment-lag rows' (ratio nodes: log-linear schemes; the pair bands of 16 want more LDS and scratch per knot)
+    plan.knot_lag = has_agg && !per_trade && want_delta && tc.lite_lag_units > 0 && log_linear && cv.Kc <= knot_lag_kc_max &&
+                    (plan.knot || tc.lite_units == 0) && knot_kernel_lds_bytes(cv, want_gamma, true) <= kLds;
+    // the trades no knot pass takes: everything / outside the lite table / and outside its payment-lag rows
+    const int rest_of_knot = plan.knot_lag ? S_NONLITE_B : (plan.knot ? S_NONLITE : S_ALL);
+    const int64_t rest_of_knot_n = plan.knot_lag ? tc.n_nonlite_b : (plan.knot ? tc.n_nonlite : n);
     auto lite_blocks = [&](int64_t units) {
         const size_t lds = lite_kernel_lds_bytes(cv, want_delta);
         const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLds / lds)));
@@ -96,10 +103,14 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
         if (family != F_KNOT) plan.total_blocks += blocks;
     };
     auto knot_launch = [&]() {
-        const size_t lds = knot_kernel_lds_bytes(cv, want_gamma);
-        const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLds / lds)));
-        const int blocks = blocks_for(tc.lite_units, knot_kernel_threads() / 64, std::min<int64_t>(static_cast<int64_t>(n_cu) * per_cu, knot_blocks));
-        plan.launches.push_back(Launch{F_KNOT, S_LITE, tc.lite_units, blocks, 0, 0, 0});
+        for (int lag = 0; lag < 2; ++lag) {
+            if (!(lag ? plan.knot_lag : plan.knot)) continue;
+            const size_t lds = knot_kernel_lds_bytes(cv, want_gamma, lag != 0);
+            const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLds / lds)));
+            const int64_t units = lag ? tc.lite_lag_units : tc.lite_units;
+            const int blocks = blocks_for(units, knot_kernel_threads() / 64, std::min<int64_t>(static_cast<int64_t>(n_cu) * per_cu, knot_blocks));
+            plan.launches.push_back(Launch{lag ? F_KNOT_LAG : F_KNOT, lag ? S_LITE_LAG : S_LITE, units, blocks, 0, 0, 0});
+        }
     };
 
     if (cv.T > 1 && cv.wide_nch > 0) {
@@ -107,7 +118,7 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
         // instantiations for the trades of its tables, the wide kernel for the rest.
         plan.wide = true;
         const bool lite_elsewhere = (!want_gamma && lite_fits && tc.lite_units > 0) || plan.knot;
-        const bool use_lite_lag = !want_gamma && lite_fits && tc.lite_lag_units > 0 && log_linear;
+        const bool use_lite_lag = (!want_gamma && lite_fits && tc.lite_lag_units > 0 && log_linear) || plan.knot_lag;   // (priced elsewhere)
         int rest_set = S_ALL;
         int64_t rest_n = n;
         if (lite_elsewhere || use_lite_lag) {     // (no plain lite rows means no trade is outside list_nonlite)
@@ -115,7 +126,7 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
             rest_n = use_lite_lag ? tc.n_nonlite_b : tc.n_nonlite;
         }
         if (lite_elsewhere && !plan.knot) push(F_LITE, S_LITE, tc.lite_units, lite_blocks(tc.lite_units));
-        if (use_lite_lag) push(F_LITE_LAG, S_LITE_LAG, tc.lite_lag_units, lite_blocks(tc.lite_lag_units));
+        if (use_lite_lag && !plan.knot_lag) push(F_LITE_LAG, S_LITE_LAG, tc.lite_lag_units, lite_blocks(tc.lite_lag_units));
         if (rest_n > 0) {
             const size_t lds = wide_kernel_lds_bytes(cv.K, cv.Kc, cv.wide_nch, want_gamma);
             const int threads = wide_kernel_threads(cv.wide_nch, want_gamma);
@@ -123,15 +134,15 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
         }
         if (static_cast<size_t>(plan.total_blocks) * wide_partial_doubles(cv.wide_nch) > static_cast<size_t>(max_blocks) * kAggStride)
             plan.error = "grid exceeds scratch";
-        if (plan.knot) knot_launch();
+        knot_launch();
         return plan;
     }
     if (cv.T > 1) {
         // ... or once per pair of pillar tiles (tile_i <= tile_j): each launch writes its tile of the ladders
         plan.tiled = true;
         const int T = cv.T;
-        const int set = plan.knot ? S_NONLITE : S_ALL;
-        const int64_t items = plan.knot ? tc.n_nonlite : n;
+        const int set = rest_of_knot;
+        const int64_t items = rest_of_knot_n;
         const int blocks = blocks_for(items, kGeneralThreads / 64, static_cast<int64_t>(n_cu) * 4);
         for (int tj = 0; tj < T; ++tj)
             for (int ti = 0; ti <= tj; ++ti) {
@@ -140,7 +151,7 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
                 push(F_TILED, set, items, blocks, ti, tj);
             }
         if (plan.total_blocks > max_blocks) plan.error = "grid exceeds scratch";
-        if (plan.knot) knot_launch();
+        knot_launch();
         return plan;
     }
 
@@ -151,9 +162,9 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
     const bool use_fast = cv.packed_ok != 0;
     const bool use_lite = !want_gamma && lite_fits && tc.lite_units > 0;
     const bool lite_elsewhere = use_lite || plan.knot;
-    const bool use_lite_lag = !want_gamma && lite_fits && tc.lite_lag_units > 0 && log_linear;
+    const bool use_lite_lag = (!want_gamma && lite_fits && tc.lite_lag_units > 0 && log_linear) || plan.knot_lag;   // (priced elsewhere)
     const bool use_lag = want_gamma && use_fast && (tc.lagged_rows > 0 || tc.lagged_chained_rows > 0) && tc.lag_scratch &&
-                         log_linear && cv.P % 2 == 0 && tc.lagged_chained_blocks <= tc.lag_blocks;
+                         log_linear && cv.P % 2 == 0 && tc.lagged_chained_blocks <= tc.lag_blocks && !plan.knot_lag;
     int64_t rows = tc.rows, chained = tc.chained_rows;
     int general_set = S_ALL;
     int64_t general_n = n;
@@ -168,12 +179,12 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
             general_n = (lite_elsewhere && !use_lite_lag) ? tc.n_nonlite : tc.n_nonlite_b;
         }
     } else if (use_fast) {
-        general_set = use_lag ? S_REST : S_GENERAL;
-        general_n = use_lag ? tc.n_rest : tc.n_general;
+        general_set = plan.knot_lag ? S_GENERAL_B : (use_lag ? S_REST : S_GENERAL);
+        general_n = plan.knot_lag ? tc.n_general_b : (use_lag ? tc.n_rest : tc.n_general);
         if (plan.knot) { rows = 0; chained = 0; }
     } else {
-        rows = 0; chained = 0;                                // the general kernel walks every trade
-        if (plan.knot) { general_set = S_NONLITE; general_n = tc.n_nonlite; }
+        rows = 0; chained = 0;                                // the general kernel walks every trade no knot pass takes
+        general_set = rest_of_knot; general_n = rest_of_knot_n;
     }
     if (use_lite && !plan.knot) push(F_LITE, S_LITE, tc.lite_units, lite_blocks(tc.lite_units));
     if (rows > 0) {
@@ -192,10 +203,10 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
         const int64_t units = (tc.lagged_rows + fast_kernel_groups() - 1) / fast_kernel_groups();
         push(F_FAST_LAG, S_LAGGED, tc.lagged_rows, blocks_for(units, fast_kernel_threads(true) / 64, std::min(tc.lag_blocks, n_cu)));
     }
-    if (use_lite_lag) push(F_LITE_LAG, S_LITE_LAG, tc.lite_lag_units, lite_blocks(tc.lite_lag_units));
+    if (use_lite_lag && !plan.knot_lag) push(F_LITE_LAG, S_LITE_LAG, tc.lite_lag_units, lite_blocks(tc.lite_lag_units));
     if (use_lag && tc.lagged_chained_rows > 0) push(F_FAST_LAG_CHAINED, S_LAGGED_CHAINED, tc.lagged_chained_rows, tc.lagged_chained_blocks);
     if (plan.total_blocks > max_blocks) plan.error = "grid exceeds scratch";
-    if (plan.knot) knot_launch();
+    knot_launch();
     return plan;
 }
 

@@ -105,4 +105,5 @@ def test_the_plans_of_the_reported_configurations():
     assert r(lag, 7) == [("fast_lag", "lagged")] and r(lag, 3) == [("lite_lag", "lite_lag")]
     assert fam(_native.route_host(2, host.times, host.dfs, host.jac, host.hess, lag, 7)[0]) == [("general", "general")]   # LINEAR_FWD_RATES
     mixed, _ = _batch(vd, ALL)
-    assert r(mixed, 7, per_trade=False, aggregate=True)[-1] == ("knot", "lite")    # the projection adds last
+    assert r(mixed, 7, per_trade=False, aggregate=True)[-2:] == [("knot", "lite"), ("knot_lag", "lite_lag")]    # the projections add last
+    assert r(lag, 7, per_trade=False, aggregate=True) == [("knot_lag", "lite_lag")]

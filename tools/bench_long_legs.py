@@ -12,6 +12,7 @@ from adrates_amd.trades.market_data import README_VALUE_DT as vd, gbp_model
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 mode = sys.argv[2] if len(sys.argv) > 2 else "long"
 noagg = len(sys.argv) > 4 and sys.argv[4] == "noagg"     # per-trade outputs only (no aggregate ladder)
+aggonly = len(sys.argv) > 4 and sys.argv[4] == "aggonly"  # the ladder alone (no per-trade output: the knot-space passes)
 mask = int(sys.argv[3]) if len(sys.argv) > 3 else 7       # 1 value, 3 value+delta, 7 value+delta+gamma       # "long": quarterly 10-30Y; "lag": annual, 2-day payment lag
 curve = gbp_model().curves.GBP_OIS_SONIA
 host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
@@ -33,12 +34,12 @@ ga = torch.empty((n, P, P), dtype=torch.float64, device=dev); ag = torch.empty(1
 s = torch.cuda.Stream(dev)
 with torch.cuda.stream(s):
     for _ in range(2):
-        _native.price_dev(ctx, dc, dt, mask, pv.data_ptr(), de.data_ptr(), ga.data_ptr(), 0 if noagg else ag.data_ptr(), s.cuda_stream)
+        _native.price_dev(ctx, dc, dt, mask, 0 if aggonly else pv.data_ptr(), 0 if aggonly else de.data_ptr(), 0 if aggonly else ga.data_ptr(), 0 if noagg else ag.data_ptr(), s.cuda_stream)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(s)
     for _ in range(5):
-        _native.price_dev(ctx, dc, dt, mask, pv.data_ptr(), de.data_ptr(), ga.data_ptr(), 0 if noagg else ag.data_ptr(), s.cuda_stream)
+        _native.price_dev(ctx, dc, dt, mask, 0 if aggonly else pv.data_ptr(), 0 if aggonly else de.data_ptr(), 0 if aggonly else ga.data_ptr(), 0 if noagg else ag.data_ptr(), s.cuda_stream)
     b.record(s); s.synchronize()
 ms = a.elapsed_time(b) / 5
 print(json.dumps({"mode": mode, "mask": mask, "trades": n, "mean_float_coupons": float(np.diff(batch.flt_off).mean()), "ms": ms,
-                  "trades_per_s": n / ms * 1e3, "aggregate": not noagg, "interp": interp, "lib": os.environ.get("ADRATES_HIP_LIB", "default")}))
+                  "trades_per_s": n / ms * 1e3, "aggregate": not noagg, "aggregate_only": aggonly, "interp": interp, "lib": os.environ.get("ADRATES_HIP_LIB", "default")}))

@@ -9,6 +9,33 @@
 
 typedef double nt_pair __attribute__((ext_vector_type(2)));
 
+// "balance" experiment: the same total filler per unit, spent before ONE burst of 16 stores, before each of four bursts of 4,
+// or before each single store - does trickling the stores through the compute shorten the pass?  NOSTORE: compute alone.
+template <int BURST, bool NOSTORE>
+__global__ void balance_kernel(double* out, const int* perm, long n_units, int filler_per_unit) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * (blockDim.x >> 6);
+    lds[threadIdx.x] = 0.0;
+    double x = 1.0 + lane, y = 2.0 + lane, z = 3.0 + lane;      // three chains: three waves per SIMD keep the FMA pipe busy
+    const int per = filler_per_unit * BURST / 16;
+    for (long u = wave; u < n_units; u += stride) {
+        double* base = out + (long)perm[u] * 2048 + 2 * lane;
+#pragma unroll
+        for (int b0 = 0; b0 < 16; b0 += BURST) {
+            for (int f = 0; f < per; ++f) { x = fma(x, 1.0000001, 1e-9); y = fma(y, 0.9999999, 1e-9); z = fma(z, 1.0000002, 1e-9); }
+            nt_pair v; v.x = x + y; v.y = z;
+            if (!NOSTORE) {
+#pragma unroll
+                for (int b = 0; b < BURST; ++b)
+                    __builtin_nontemporal_store(v, reinterpret_cast<nt_pair*>(base + (b0 + b) * 128));
+            }
+        }
+    }
+    if (x + y + z == 123.456) out[0] = x;
+}
+
 template <int BURST>
 __global__ void stream_kernel(double* out, const int* perm, long n_units, int filler, int lds_touch) {
     extern __shared__ double lds[];
@@ -149,8 +176,26 @@ int main(int argc, char** argv) {
     timeit("march: 256 x 768 persistent, waves advance together, nt", [&] { hipLaunchKernelGGL((march_kernel<false>), dim3(n_cu), dim3(768), 0, 0, out, n_kb); });
     timeit("march: 256 x 768 persistent, waves advance together, plain", [&] { hipLaunchKernelGGL((march_kernel<true>), dim3(n_cu), dim3(768), 0, 0, out, n_kb); });
     timeit("march: 2048 x 256 persistent, plain", [&] { hipLaunchKernelGGL((march_kernel<true>), dim3(n_cu * 8), dim3(256), 0, 0, out, n_kb); });
+    {   // balance experiment
+        hipMemcpy(perm, h.data(), n_units * sizeof(int), hipMemcpyHostToDevice);
+        auto bal = [&](const char* label, auto kernel, int filler) {
+            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            timeit(label, [&] { hipLaunchKernelGGL(kernel, dim3(n_cu), dim3(768), big, 0, out, perm, n_units, filler); });
+        };
+        for (int filler : {160, 320, 480}) {
+            char l0[96], l1[96], l2[96], l3[96];
+            snprintf(l0, sizeof l0, "balance: filler %d per unit, compute alone", filler);
+            snprintf(l1, sizeof l1, "balance: filler %d per unit, ONE burst of 16 stores", filler);
+            snprintf(l2, sizeof l2, "balance: filler %d per unit, four bursts of 4", filler);
+            snprintf(l3, sizeof l3, "balance: filler %d per unit, sixteen single stores", filler);
+            bal(l0, balance_kernel<16, true>, filler);
+            bal(l1, balance_kernel<16, false>, filler);
+            bal(l2, balance_kernel<4, false>, filler);
+            bal(l3, balance_kernel<1, false>, filler);
+        }
+    }
     unsigned long long* counter; hipMalloc(&counter, 8);
-    for (int chunk_kb : {1, 16})
+    for (int chunk_kb : {16})
         for (int threads : {768, 256}) {
             char label[96];
             snprintf(label, sizeof label, "ticket: persistent %d-thread blocks, chunks of %d KB", threads, chunk_kb);
