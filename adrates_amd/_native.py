@@ -304,6 +304,18 @@ class DeviceTrades:
             pass
 
 
+def upload_many(ctx: Context, batches):
+    """`DeviceTrades` of several batches at once, one host thread per batch (adr_trades_upload may be called from several
+    threads on one ctx; ctypes releases the GIL): validation and classification of one batch overlap the copies and the
+    device-side table builds of the others - the three batches of a cross-currency book in about half the serial time."""
+    batches = list(batches)
+    if len(batches) <= 1:
+        return [DeviceTrades(ctx, b) for b in batches]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(batches)) as pool:
+        return list(pool.map(lambda b: DeviceTrades(ctx, b), batches))
+
+
 def price(ctx: Context, curve: DeviceCurve, trades: DeviceTrades, want_value=True, want_delta=True,
           want_gamma=True, per_trade=True, aggregate=False):
     """Blocking pricing call returning numpy arrays (adr_price).

@@ -28,7 +28,7 @@ compile_s = time.perf_counter() - t0                      # terms -> three trade
 parts = [(batches[0], dom_cur["dev"]), (batches[1], for_cur["dev"]), (batches[2], x_dev)]
 ctx = _native.default_context()
 t0 = time.perf_counter()
-book = [(_native.DeviceTrades(ctx, b), cur) for b, cur in parts]
+book = list(zip(_native.upload_many(ctx, [b for b, _ in parts]), [cur for _, cur in parts]))
 upload_s = time.perf_counter() - t0
 flows = [int(b.flt_tp.size + b.fix_tp.size) for b, _ in parts]
 
@@ -68,7 +68,7 @@ t0 = time.perf_counter()
 again = XE.book_batches(engine, terms)[6]
 compile_warm_s = time.perf_counter() - t0
 t0 = time.perf_counter()
-book2 = [_native.DeviceTrades(ctx, b) for b in again]
+book2 = _native.upload_many(ctx, again)
 upload_warm_s = time.perf_counter() - t0
 del book2
 pillars = [cur.n_pillars for _, cur in book]
