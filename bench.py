@@ -355,9 +355,9 @@ def main(argv=None):
         n_x = parts[0][0].n_trades                      # this rank's share of the world x --xccy-swaps book
         for b, cur in parts:
             Px = cur.n_pillars
-            xccy.append((_native.DeviceTrades(ctx, b), cur, torch.empty(n_x, dtype=torch.float64, device=dev),
-                         torch.empty((n_x, Px), dtype=torch.float64, device=dev) if want_delta else None,
-                         torch.empty((n_x, Px, Px), dtype=torch.float64, device=dev) if want_gamma else None, agg_len))
+            xccy.append((_native.DeviceTrades(ctx, b), cur, torch.empty(n_x, dtype=torch.float64, device=dev) if not agg_only else None,
+                         torch.empty((n_x, Px), dtype=torch.float64, device=dev) if (want_delta and not agg_only) else None,
+                         torch.empty((n_x, Px, Px), dtype=torch.float64, device=dev) if (want_gamma and not agg_only) else None, agg_len))
             agg_len += 1 + Px + Px * Px
     # one buffer for every aggregate ladder of the step: a single all-reduce whatever the book holds.  Two of them,
     # used alternately: step k's all-reduce runs on RCCL's stream while step k + 1 prices into the other buffer
@@ -390,7 +390,8 @@ def main(argv=None):
 
     def price_xccy(agg):
         for trades_x, cur, pv_x, de_x, ga_x, off in xccy:
-            _native.price_dev(ctx, cur, trades_x, mask, pv_x.data_ptr(), de_x.data_ptr() if de_x is not None else 0,
+            _native.price_dev(ctx, cur, trades_x, mask, pv_x.data_ptr() if pv_x is not None else 0,
+                              de_x.data_ptr() if de_x is not None else 0,
                               ga_x.data_ptr() if ga_x is not None else 0, agg.data_ptr() + 8 * off, stream.cuda_stream)
     # a non-default torch stream: the kernels, the HIP events that time them and the RCCL all-reduce all
     # go to this one stream (torch.cuda.Event only sees the stream it is recorded on)

@@ -32,16 +32,17 @@ for label, model, wide in (("40 pillars", gbp_model(vd, px=px, tenors=tenors), "
     P = dc.n_pillars
     pv = torch.empty(n, dtype=torch.float64, device=dev); de = torch.empty((n, P), dtype=torch.float64, device=dev)
     ga = torch.empty((n, P, P), dtype=torch.float64, device=dev); ag = torch.empty(1 + P + P * P, dtype=torch.float64, device=dev)
-    for mask in (7, 3):
+    for mask, agg_only in ((7, False), (3, False), (7, True)):      # the last: the ladder alone (knot-space sums, one projection)
+        ptrs = (0, 0, 0) if agg_only else (pv.data_ptr(), de.data_ptr(), ga.data_ptr() if mask & 4 else 0)
         for _ in range(5):
-            _native.price_dev(ctx, dc, dt, mask, pv.data_ptr(), de.data_ptr(), ga.data_ptr() if mask & 4 else 0, ag.data_ptr())
+            _native.price_dev(ctx, dc, dt, mask, ptrs[0], ptrs[1], ptrs[2], ag.data_ptr())
         ctx.sync()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); a.record()
         for _ in range(10):
-            _native.price_dev(ctx, dc, dt, mask, pv.data_ptr(), de.data_ptr(), ga.data_ptr() if mask & 4 else 0, ag.data_ptr())
+            _native.price_dev(ctx, dc, dt, mask, ptrs[0], ptrs[1], ptrs[2], ag.data_ptr())
         ctx.sync(); b.record(); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / 10
-        out_bytes = 8 * (1 + P + (P * P if mask & 4 else 0)) * n
-        print(json.dumps({"curve": label, "pillars": P, "trades": n, "mask": mask, "ms": ms, "trades_per_s": n / ms * 1e3,
-                          "output_GBps": out_bytes / ms / 1e6}))
+        out_bytes = 8 * (1 + P + P * P) if agg_only else 8 * (1 + P + (P * P if mask & 4 else 0)) * n
+        print(json.dumps({"curve": label, "pillars": P, "trades": n, "mask": mask, "aggregate_only": agg_only, "ms": ms,
+                          "trades_per_s": n / ms * 1e3, "output_GBps": out_bytes / ms / 1e6}))
