@@ -215,7 +215,7 @@ int adr_init(int device_ordinal, adr_ctx** out) {
     }
     ctx->knot_blocks = std::max(1, ctx->n_cu) * adr::kLiteWavesPerSimd * 4 * 64 / adr::kLiteThreads;   // blocks resident at once
     e = hipMalloc(reinterpret_cast<void**>(&ctx->knot_partials),
-                  sizeof(double) * (static_cast<size_t>(ctx->knot_blocks + 1) * kKnotStrideMax + static_cast<size_t>(kKnotLagMaxKc) * kKnotLagMaxKc));
+                  sizeof(double) * (static_cast<size_t>(ctx->knot_blocks + 1) * kKnotStrideMax + static_cast<size_t>(kKnotLagMaxKc) * kKnotLagMaxKc + 1));
     if (e != hipSuccess) {
         hipFree(ctx->dump); hipFree(ctx->partials); hipStreamDestroy(ctx->stream); delete ctx;
         return fail_hip(e, "hipMalloc(knot partials)");
@@ -1192,7 +1192,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
     if (knot_lag) {
         // ... and the payment-lag rows' ratio nodes: pair bands per wave, pairs farther apart in the launch's overflow matrix
         const size_t kc = static_cast<size_t>(curve->dev.Kc);
-        if (want_gamma) ADR_HIP(hipMemsetAsync(ctx->knot_overflow, 0, sizeof(double) * kc * kc, stream));
+        if (want_gamma) ADR_HIP(hipMemsetAsync(ctx->knot_overflow, 0, sizeof(double) * (kc * kc + 1), stream));   // (+ the "in use" flag)
         ADR_HIP(adr::launch_price_knot(curve->dev, trades->lite_lag, o, want_gamma, knot_lag->blocks, stream));
         ADR_HIP(adr::launch_knot_project(curve->dev, ctx->knot_partials, knot_lag->blocks, ctx->knot_reduced, want_delta, want_gamma,
                                          adr::kKnotBand, ctx->knot_overflow, agg_dev, stream));

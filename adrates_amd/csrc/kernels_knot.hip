@@ -60,21 +60,27 @@ __device__ __forceinline__ double lc_at(const CurveDev& cv, const int* col_off, 
     return cv.lc_lanes[((static_cast<size_t>(tj * (tj + 1) / 2 + ti) * cv.Kc + k) * 64 + lane) * kGammaPerLane + e];
 }
 
-// Block p < P: row p of the gamma matrix (thread q); block P: pv and the delta ladder (thread p).
+// Block p < P: row p of the gamma matrix (thread q); block P: pv and the delta ladder (thread p).  One wavefront per block.
+// The reduced sums are staged in LDS first (every thread walks all of them: as global loads behind `continue`s they were a
+// chain of ~2 000 L2 round trips per thread - 0.7 ms for a 16-band record); the overflow matrix is scanned 64 entries at a
+// time, coalesced, and only the non-zero ones (normally none) are visited.
 __global__ __launch_bounds__(64) void knot_project_kernel(CurveDev cv, const double* reduced, int want_delta, int want_gamma, int bands,
                                                           const double* overflow, double* agg) {
+    extern __shared__ double s_red[];                     // [1 + (2 + bands) Kc]
     __shared__ int col_off[kWidePad + 1];
     const int P = cv.P, Kc = cv.Kc, q = threadIdx.x;
+    const int n_values = want_gamma ? 1 + (2 + bands) * Kc : 1 + Kc;
+    for (int i = threadIdx.x; i < n_values; i += 64) s_red[i] = reduced[i];
     if (threadIdx.x == 0) {
         col_off[0] = 0;
         for (int b = 0; b < kWidePad; ++b) col_off[b + 1] = col_off[b] + 2 * ((b + 2) / 2);
     }
     __syncthreads();
-    const double* w = reduced + 1;
+    const double* w = s_red + 1;
     const double* D = w + Kc;
     const double* O = D + Kc;
     if (static_cast<int>(blockIdx.x) == P) {
-        if (q == 0) agg[0] += reduced[0];
+        if (q == 0) agg[0] += s_red[0];
         if (want_delta && q < P) {
             double s = 0.0;
             for (int k = 0; k < Kc; ++k) {
@@ -85,29 +91,37 @@ __global__ __launch_bounds__(64) void knot_project_kernel(CurveDev cv, const dou
         }
         return;
     }
-    if (!want_gamma || q >= P) return;
+    if (!want_gamma) return;
     const int p = blockIdx.x;
+    const int qq = q < P ? q : 0;                          // (lanes beyond the ladder compute a copy of column 0 and do not store)
+    const bool any_overflow = overflow && overflow[static_cast<size_t>(Kc) * Kc] != 0.0;    // set by the kernel that used the matrix
     double s = 0.0;
     for (int k = 0; k < Kc; ++k) {
         const double wk = w[k], dk = D[k];
-        const double ap = lj_at(cv, k, p), aq = lj_at(cv, k, q);
+        const double ap = lj_at(cv, k, p), aq = lj_at(cv, k, qq);
         if (dk != 0.0) s = fma(dk * ap, aq, s);                      // (wave-uniform branches: the sums are the same for every thread)
         for (int d = 1; d <= bands && k + d < Kc; ++d) {             // pairs of knots (k, k + d): band d
             const double ok = O[(d - 1) * Kc + k];
             if (ok == 0.0) continue;
-            const double bp = lj_at(cv, k + d, p), bq = lj_at(cv, k + d, q);
+            const double bp = lj_at(cv, k + d, p), bq = lj_at(cv, k + d, qq);
             s = fma(ok, fma(ap, bq, bp * aq), s);
         }
-        if (overflow)                                                // ... and the pairs farther apart (payment-lag rows; mostly zeros)
-            for (int l = k + bands + 1; l < Kc; ++l) {
-                const double ok = overflow[static_cast<size_t>(k) * Kc + l];
-                if (ok == 0.0) continue;
-                const double bp = lj_at(cv, l, p), bq = lj_at(cv, l, q);
-                s = fma(ok, fma(ap, bq, bp * aq), s);
+        if (any_overflow)                                            // ... and the pairs farther apart (payment-lag rows; rare)
+            for (int l0 = k + bands + 1; l0 < Kc; l0 += 64) {
+                const int l = l0 + static_cast<int>(threadIdx.x);
+                const double mine = l < Kc ? overflow[static_cast<size_t>(k) * Kc + l] : 0.0;
+                unsigned long long any = __ballot(mine != 0.0);
+                while (any) {
+                    const int src = __builtin_ctzll(any);
+                    any &= any - 1;
+                    const double ok = __shfl(mine, src, 64);
+                    const double bp = lj_at(cv, l0 + src, p), bq = lj_at(cv, l0 + src, qq);
+                    s = fma(ok, fma(ap, bq, bp * aq), s);
+                }
             }
-        if (wk != 0.0) s = fma(wk, lc_at(cv, col_off, k, p, q), s);
+        if (wk != 0.0) s = fma(wk, lc_at(cv, col_off, k, p, qq), s);
     }
-    agg[1 + P + p * P + q] += s * 1e-8;
+    if (q < P) agg[1 + P + p * P + q] += s * 1e-8;
 }
 
 }  // namespace
@@ -118,8 +132,8 @@ hipError_t launch_knot_project(const CurveDev& cv, const double* partials, int n
     hipLaunchKernelGGL(knot_reduce_kernel, dim3((n_values + 3) / 4), dim3(256), 0, stream, partials, n_blocks, stride, n_values, reduced);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(knot_project_kernel, dim3(cv.P + 1), dim3(64), 0, stream, cv, reduced, want_delta ? 1 : 0, want_gamma ? 1 : 0, bands,
-                       want_gamma ? overflow : nullptr, agg);
+    hipLaunchKernelGGL(knot_project_kernel, dim3(cv.P + 1), dim3(64), sizeof(double) * static_cast<size_t>(stride), stream, cv, reduced,
+                       want_delta ? 1 : 0, want_gamma ? 1 : 0, bands, want_gamma ? overflow : nullptr, agg);
     return hipGetLastError();
 }
 

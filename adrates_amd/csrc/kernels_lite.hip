@@ -186,15 +186,19 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
     // launch's dense overflow matrix in global memory (rare; the only sum whose order depends on scheduling).  The value-time
     // knot (0) carries no sensitivity and is left out - it is also the knot farthest from everything.
     auto pair_add = [&](int ki, double ci, int kj, double cj, double om) {
-        if (ki == 0 || kj == 0) return;
         const double v = om * ci * cj;
-        if (v == 0.0) return;
+        const bool on = ki != 0 && kj != 0 && v != 0.0;
         const int lo = ki < kj ? ki : kj, d = ki < kj ? kj - ki : ki - kj;
-        if (d == 0) __hip_atomic_fetch_add(knot_d + lo, 2.0 * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        else if (d <= BAND) __hip_atomic_fetch_add(knot_o + (d - 1) * cv.Kc + lo, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        else unsafeAtomicAdd(out.knot_overflow + static_cast<size_t>(lo) * cv.Kc + (lo + d), v);
+        // one predicated LDS add for the diagonal and the bands (no branch per case: the cases differ in address and factor)
+        double* at = d == 0 ? knot_d + lo : knot_o + (d - 1) * cv.Kc + lo;
+        if (on && d <= BAND) __hip_atomic_fetch_add(at, d == 0 ? 2.0 * v : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (__ballot(on && d > BAND)) {
+            if (on && d > BAND) {
+                unsafeAtomicAdd(out.knot_overflow + static_cast<size_t>(lo) * cv.Kc + (lo + d), v);
+                out.knot_overflow[static_cast<size_t>(cv.Kc) * cv.Kc] = 1.0;       // "the matrix is in use": the projection scans it only then
+            }
+        }
     };
-
     double tot_pv = 0.0, tot_d0 = 0.0, tot_d1 = 0.0, tot_d2 = 0.0, tot_d3 = 0.0;
 
     // ---------------------------------------------------------------------------------------------------

@@ -173,3 +173,29 @@ def test_xccy_book_ladders_aggregate_only(gpu_ctx):
         scale = float(np.max(np.abs(per).sum(0)))
         err = float(np.max(np.abs(np.asarray(only["agg_" + key]) - per.sum(0))))
         assert err <= 1e-10 * scale, (key, err / scale)
+
+
+def test_ratio_nodes_far_apart_take_the_overflow_matrix(gpu_ctx):
+    """Coupons that accrue from the short end over several years couple knots more than 16 apart: beyond the per-wave pair
+    bands, into the launch's dense overflow matrix (global adds), which the projection scans only when it was used."""
+    from adrates_amd.trades.compiler import TradeBatch
+    vd = F.README_VALUE_DT
+    rng = np.random.default_rng(4)
+    n = 400
+    ts = rng.uniform(0.01, 0.6, n)
+    te = ts + rng.uniform(1.5, 7.0, n)
+    tp = te + rng.choice([0.0, 0.008], size=n)           # half with payment lag, half ordinary coupons on long periods
+    off = np.arange(n + 1, dtype=np.int64)
+    batch = TradeBatch(np.zeros(n + 1, dtype=np.int64), off, np.zeros(0), np.zeros(0), tp, ts, te, te - ts,
+                       np.round(rng.uniform(1e6, 5e7, n), -5), np.zeros(n), np.ones(n), np.where(rng.random(n) < 0.5, 1.0, -1.0))
+    for interp in (InterpTypes.LINEAR_ZERO_RATES, InterpTypes.FLAT_FWD_RATES):
+        curve = F.gbp_model(vd, interp).curves.GBP_OIS_SONIA
+        host, dc = _device_curve(gpu_ctx, curve)
+        dt = _native.DeviceTrades(gpu_ctx, batch)
+        ref = port.price(interp.value, host.times, host.dfs, host.jac, host.hess, batch)
+        only = _native.price(gpu_ctx, dc, dt, per_trade=False, aggregate=True)
+        worst = assert_book(only, ref, f"far-apart ratio nodes, {interp.name}")
+        full = _native.price(gpu_ctx, dc, dt, aggregate=True)
+        assert_book(full, ref, "per-trade kernels")
+        dt.close()
+        print(f"far-apart ratio nodes, {interp.name}: worst error {worst:.2e}")
