@@ -21,6 +21,8 @@ copies = {
     f"routing_audit_{tag}.txt": "routing_audit.txt",
     f"bench_{tag}_aggregate_only.json": "aggregate_only_bench.json", f"bench_{tag}_aggregate_only_delta.json": "aggregate_only_delta_bench.json",
     f"bench_{tag}_aggregate_tool.json": "aggregate_only_paths.json", f"ab_calls_{tag}.txt": "final_call_variants.txt",
+    f"bench_{tag}_mixed_book_aggregate_only.json": "mixed_book_aggregate_only_bench.json",
+    f"bench_{tag}_aggregate_only_legs.json": "aggregate_only_legs_bench.json",
 }
 for src, dst in copies.items():
     if os.path.exists(f"{G}/{src}"):

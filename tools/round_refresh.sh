@@ -25,6 +25,8 @@ python tools/bench_long_legs.py 200000 lag > gpurun_out/bench_${TAG}_payment_lag
 python tools/bench_xccy.py 100000 3 > gpurun_out/bench_${TAG}_xccy.json 2>/dev/null || exit 1
 python tools/bench_xccy.py 100000 7 >> gpurun_out/bench_${TAG}_xccy.json 2>/dev/null || exit 1
 python bench.py --xccy-swaps 100000 --steps 10 --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_mixed_book.json 2>/dev/null || exit 1
+python bench.py --xccy-swaps 100000 --aggregate-only --steps 10 --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_mixed_book_aggregate_only.json 2>/dev/null || exit 1
+for mode in lag longlag long; do python tools/bench_long_legs.py 200000 $mode 7 aggonly 2>/dev/null; done > gpurun_out/bench_${TAG}_aggregate_only_legs.json || exit 1
 python bench.py --interp LINEAR_FWD_RATES --cpu-baseline-seconds 0 > gpurun_out/bench_${TAG}_linfwd.json 2>/dev/null || exit 1
 bash tools/profile.sh $TAG || exit 1
 bash tools/pmc.sh && python tools/pmc_summary.py > gpurun_out/pmc_$TAG.txt || exit 1
