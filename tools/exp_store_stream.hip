@@ -58,6 +58,34 @@ __global__ void stream_kernel(double* out, const int* perm, long n_units, int fi
     if (x == 123.456) out[0] = x;
 }
 
+// the stream kernel's shape (persistent, 16 KB units at random chunks) with other store instructions: 8 bytes per lane
+// (32 instructions per unit) and raw buffer stores
+template <int MODE>
+__global__ void stream_alt_kernel(double* out, const int* perm, long n_units, long n_bytes) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * (blockDim.x >> 6);
+    lds[threadIdx.x] = 0.0;
+    const double x = 1.0 + lane;
+    // buffer resource over the first 2 GB of the allocation (raw, stride 0)
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0x7fffffff, 0x00020000);
+    for (long u = wave; u < n_units; u += stride) {
+        const long chunk = perm[u];
+        if (MODE == 0) {                    // 8 bytes per lane: 32 stores of 512 B
+            double* base = out + chunk * 2048 + lane;
+#pragma unroll
+            for (int b = 0; b < 32; ++b) __builtin_nontemporal_store(x, base + b * 64);
+        } else {                            // buffer_store_dwordx4 with a 32-bit offset (chunks within the first 2 GB only)
+            typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+            v4u v; v.x = v.y = v.z = v.w = static_cast<unsigned int>(lane);
+            const int off = static_cast<int>((chunk % 131072) * 16384 + lane * 16);
+#pragma unroll
+            for (int b = 0; b < 16; ++b) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off + b * 1024, 0, 2 /* slc: streaming */);
+        }
+    }
+}
+
 // memset-like: a non-persistent grid, each thread writes VEC consecutive 16-byte pieces; PLAIN: ordinary stores
 template <int VEC, bool PLAIN>
 __global__ void fill_kernel(double* out, long n_pairs) {
@@ -176,6 +204,13 @@ int main(int argc, char** argv) {
     timeit("march: 256 x 768 persistent, waves advance together, nt", [&] { hipLaunchKernelGGL((march_kernel<false>), dim3(n_cu), dim3(768), 0, 0, out, n_kb); });
     timeit("march: 256 x 768 persistent, waves advance together, plain", [&] { hipLaunchKernelGGL((march_kernel<true>), dim3(n_cu), dim3(768), 0, 0, out, n_kb); });
     timeit("march: 2048 x 256 persistent, plain", [&] { hipLaunchKernelGGL((march_kernel<true>), dim3(n_cu * 8), dim3(256), 0, 0, out, n_kb); });
+    {
+        hipMemcpy(perm, h.data(), n_units * sizeof(int), hipMemcpyHostToDevice);
+        hipFuncSetAttribute((const void*)stream_alt_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)stream_alt_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        timeit("12 waves/CU, random chunks, 8 B per lane (32 x 512 B stores per unit), nt", [&] { hipLaunchKernelGGL(stream_alt_kernel<0>, dim3(n_cu), dim3(768), big, 0, out, perm, n_units, n_units * 16384); });
+        timeit("12 waves/CU, random chunks (first 2 GB), buffer_store_dwordx4 slc", [&] { hipLaunchKernelGGL(stream_alt_kernel<1>, dim3(n_cu), dim3(768), big, 0, out, perm, n_units, n_units * 16384); });
+    }
     {   // balance experiment
         hipMemcpy(perm, h.data(), n_units * sizeof(int), hipMemcpyHostToDevice);
         auto bal = [&](const char* label, auto kernel, int filler) {
