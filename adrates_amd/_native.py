@@ -58,6 +58,8 @@ _SIGNATURES = {
     "adr_price": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _dp, _dp, _dp, _dp]),
     "adr_price_dev": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp]),
     "adr_allreduce_agg": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "adr_price_xccy_foreign": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, _dp, _dp, _dp, _dp, _dp]),
+    "adr_price_xccy_foreign_dev": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "adr_route_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_uint32, C.c_int64, _i64p, _i64p, _dp, _dp, _dp, _dp,
                                  C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]),
     "adr_rccl_unique_id": (C.c_int, [_vp]),
@@ -343,6 +345,40 @@ def price(ctx: Context, curve: DeviceCurve, trades: DeviceTrades, want_value=Tru
         out["agg_delta"] = agg[1:1 + P].copy()
         out["agg_gamma"] = agg[1 + P:].reshape(P, P).copy()
     return out
+
+
+def price_xccy_foreign(ctx: Context, foreign_curve: DeviceCurve, xccy_curve: DeviceCurve, legs: DeviceTrades, want_value=True,
+                       want_delta=True, per_trade=True, aggregate=False):
+    """The foreign legs of a cross-currency book on two curves in one launch (adr_price_xccy_foreign): ``pv [n]``,
+    ``delta_foreign [n, P_f]``, ``delta_basis [n, P_x]`` in FOREIGN currency (per trade), ``agg_pv``, ``agg_delta_foreign``,
+    ``agg_delta_basis`` (book).  Raises `LibError` (ADR_ERR_UNSUPPORTED) for books the launch does not take."""
+    n, Pf, Px = legs.n_trades, foreign_curve.n_pillars, xccy_curve.n_pillars
+    mask = (REQ_VALUE if want_value else 0) | (REQ_DELTA if want_delta else 0)
+    pv = np.empty(n) if (per_trade and want_value) else None
+    df = np.empty((n, Pf)) if (per_trade and want_delta) else None
+    dx = np.empty((n, Px)) if (per_trade and want_delta) else None
+    af = np.empty(1 + Pf + Pf * Pf) if aggregate else None
+    ax = np.empty(1 + Px + Px * Px) if aggregate else None
+    _check(load().adr_price_xccy_foreign(ctx._h, foreign_curve._h, xccy_curve._h, legs._h, mask, _ptr(pv), _ptr(df), _ptr(dx),
+                                         _ptr(af), _ptr(ax)), "adr_price_xccy_foreign")
+    out = {}
+    if pv is not None:
+        out["pv"] = pv
+    if df is not None:
+        out["delta_foreign"], out["delta_basis"] = df, dx
+    if aggregate:
+        out["agg_pv"] = float(af[0])
+        out["agg_delta_foreign"], out["agg_delta_basis"] = af[1:1 + Pf].copy(), ax[1:1 + Px].copy()
+    return out
+
+
+def price_xccy_foreign_dev(ctx: Context, foreign_curve: DeviceCurve, xccy_curve: DeviceCurve, legs: DeviceTrades, mask: int, pv_ptr=0,
+                           delta_foreign_ptr=0, delta_basis_ptr=0, agg_foreign_ptr=0, agg_basis_ptr=0, stream=0):
+    """Non-blocking form (adr_price_xccy_foreign_dev): device pointers as integers."""
+    _check(load().adr_price_xccy_foreign_dev(ctx._h, foreign_curve._h, xccy_curve._h, legs._h, int(mask), _vp(pv_ptr or None),
+                                             _vp(delta_foreign_ptr or None), _vp(delta_basis_ptr or None),
+                                             _vp(agg_foreign_ptr or None), _vp(agg_basis_ptr or None), _vp(stream or None)),
+           "adr_price_xccy_foreign_dev")
 
 
 def price_dev(ctx: Context, curve: DeviceCurve, trades: DeviceTrades, mask: int, pv_ptr=0, delta_ptr=0,

@@ -1231,6 +1231,78 @@ int adr_price(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades, ui
     return ADR_OK;
 }
 
+// ------------------------------------------------------------------------ cross-currency foreign leg, two curves
+int adr_price_xccy_foreign_dev(adr_ctx* ctx, const adr_curve* foreign_curve, const adr_curve* xccy_curve, const adr_trades* legs,
+                               uint32_t req_mask, double* pv_dev, double* delta_foreign_dev, double* delta_basis_dev,
+                               double* agg_foreign_dev, double* agg_basis_dev, void* stream_v) {
+    if (!ctx || !foreign_curve || !xccy_curve || !legs) return fail(ADR_ERR_INVALID, "adr_price_xccy_foreign: null ctx/curve/legs");
+    if (foreign_curve->ctx != ctx || xccy_curve->ctx != ctx || legs->ctx != ctx)
+        return fail(ADR_ERR_INVALID, "adr_price_xccy_foreign: curves/legs were uploaded through another ctx");
+    if (req_mask & ADR_REQ_GAMMA)
+        return fail(ADR_ERR_UNSUPPORTED, "adr_price_xccy_foreign: GAMMA takes the three-batch route (adr_trades_upload_weighted + adr_price)");
+    const adr::CurveDev &cf = foreign_curve->dev, &cx = xccy_curve->dev;
+    if (cf.T > 1 || cx.T > 1 || cf.method == ADR_INTERP_LINEAR_FWD_RATES || cx.method == ADR_INTERP_LINEAR_FWD_RATES)
+        return fail(ADR_ERR_UNSUPPORTED, "adr_price_xccy_foreign: curves of up to 32 pillars on a log-linear scheme");
+    if (adr::lite_xc_kernel_lds_bytes(cf, cx) > kLdsBudget)
+        return fail(ADR_ERR_UNSUPPORTED, "adr_price_xccy_foreign: the two curves' tables exceed the LDS of a CU");
+    const int64_t n = legs->dev.n;
+    hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
+    ADR_HIP(hipSetDevice(ctx->device));
+    const int Pf = cf.P, Px = cx.P;
+    const size_t agg_f_bytes = sizeof(double) * (1 + Pf + static_cast<size_t>(Pf) * Pf), agg_x_bytes = sizeof(double) * (1 + Px + static_cast<size_t>(Px) * Px);
+    if (n == 0) {
+        if (agg_foreign_dev) ADR_HIP(hipMemsetAsync(agg_foreign_dev, 0, agg_f_bytes, stream));
+        if (agg_basis_dev) ADR_HIP(hipMemsetAsync(agg_basis_dev, 0, agg_x_bytes, stream));
+        return ADR_OK;
+    }
+    // every leg must sit in the lite kernel's payment-lag rows (accrual end != payment time on some coupon, <= 390 coupons)
+    if (legs->lite.n_units > 0 || legs->n_nonlite_b > 0 || legs->lite_lag.n_units == 0)
+        return fail(ADR_ERR_UNSUPPORTED, "adr_price_xccy_foreign: a leg is outside the payment-lag row table (more than 390 coupons, "
+                                         "or no coupon whose accrual end differs from its payment time)");
+    const size_t lds = adr::lite_xc_kernel_lds_bytes(cf, cx);
+    const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
+    const int blocks = adr::route::blocks_for(legs->lite_lag.n_units, adr::kLiteThreads / 64, static_cast<int64_t>(ctx->n_cu) * per_cu);
+    if (2 * blocks > ctx->max_blocks) return fail(ADR_ERR_INVALID, "adr_price_xccy_foreign: grid exceeds scratch");
+    const bool want_agg = agg_foreign_dev || agg_basis_dev;
+    adr::OutputsDev o{};
+    o.pv = (req_mask & ADR_REQ_VALUE) ? pv_dev : nullptr;
+    o.delta = (req_mask & ADR_REQ_DELTA) ? delta_foreign_dev : nullptr;
+    o.delta2 = (req_mask & ADR_REQ_DELTA) ? delta_basis_dev : nullptr;
+    o.block_partials = want_agg ? ctx->partials : nullptr;
+    o.block_partials2 = want_agg ? ctx->partials + static_cast<size_t>(blocks) * adr::kAggStride : nullptr;
+    ADR_HIP(adr::launch_price_lite_xc(cf, cx, legs->lite_lag, o, blocks, stream));
+    if (agg_foreign_dev) ADR_HIP(adr::launch_reduce_partials(o.block_partials, blocks, Pf, false, agg_foreign_dev, stream));
+    if (agg_basis_dev) ADR_HIP(adr::launch_reduce_partials(o.block_partials2, blocks, Px, false, agg_basis_dev, stream));
+    return ADR_OK;
+}
+
+int adr_price_xccy_foreign(adr_ctx* ctx, const adr_curve* foreign_curve, const adr_curve* xccy_curve, const adr_trades* legs,
+                           uint32_t req_mask, double* pv, double* delta_foreign, double* delta_basis, double* agg_foreign,
+                           double* agg_basis) {
+    if (!ctx || !foreign_curve || !xccy_curve || !legs) return fail(ADR_ERR_INVALID, "adr_price_xccy_foreign: null ctx/curve/legs");
+    const size_t n = static_cast<size_t>(legs->dev.n), Pf = foreign_curve->dev.P, Px = xccy_curve->dev.P;
+    ADR_HIP(hipSetDevice(ctx->device));
+    double *d_pv = nullptr, *d_f = nullptr, *d_x = nullptr, *d_af = nullptr, *d_ax = nullptr;
+    hipError_t e = hipSuccess;
+    auto cleanup = [&]() { hipFree(d_pv); hipFree(d_f); hipFree(d_x); hipFree(d_af); hipFree(d_ax); };
+    auto get = [&](double** p, size_t count) { if (e == hipSuccess && count) e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(double)); };
+    if (pv && (req_mask & ADR_REQ_VALUE)) get(&d_pv, n);
+    if (delta_foreign && (req_mask & ADR_REQ_DELTA)) get(&d_f, n * Pf);
+    if (delta_basis && (req_mask & ADR_REQ_DELTA)) get(&d_x, n * Px);
+    if (agg_foreign) get(&d_af, 1 + Pf + Pf * Pf);
+    if (agg_basis) get(&d_ax, 1 + Px + Px * Px);
+    if (e != hipSuccess) { cleanup(); return fail_hip(e, "adr_price_xccy_foreign: allocating outputs"); }
+    const int rc = adr_price_xccy_foreign_dev(ctx, foreign_curve, xccy_curve, legs, req_mask, d_pv, d_f, d_x, d_af, d_ax, nullptr);
+    if (rc != ADR_OK) { cleanup(); return rc; }
+    e = hipStreamSynchronize(ctx->stream);
+    auto back = [&](double* dst, double* src, size_t count) { if (e == hipSuccess && src) e = hipMemcpy(dst, src, count * sizeof(double), hipMemcpyDeviceToHost); };
+    back(pv, d_pv, n); back(delta_foreign, d_f, n * Pf); back(delta_basis, d_x, n * Px);
+    back(agg_foreign, d_af, 1 + Pf + Pf * Pf); back(agg_basis, d_ax, 1 + Px + Px * Px);
+    cleanup();
+    if (e != hipSuccess) return fail_hip(e, "adr_price_xccy_foreign: running the kernel / copying results");
+    return ADR_OK;
+}
+
 // ---------------------------------------------------------------------------------------- launch plan, host side
 int adr_route_host(int interp_method, int K, int P, const double* times, const double* dfs, const double* jac, const double* hess,
                    uint32_t curve_flags, int64_t n, const int64_t* fix_off, const int64_t* flt_off, const double* flt_tp,

@@ -203,6 +203,8 @@ struct OutputsDev {
     double* delta;           // [n*P] or null
     double* gamma;           // [n*P*P] or null
     double* block_partials;  // [grid][kAggStride] or null
+    double* block_partials2; // two-curve launch (XC): the second ladder's block records [grid][kAggStride]
+    double* delta2;          // ... its per-trade ladder [n * P2] or null
     double* dump;            // [32*32] sink for the gamma stores of the idle trade slot of a wave's last unit
     double* lag_scratch;     // payment-lag variant: [grid waves][2 groups][kLagScratchNodes][kLagStashDoubles]
     double* knot_partials;   // aggregate-only mode: [grid][record] block sums {pv, w[Kc], D[Kc], P[bands][Kc]} of the knot-space kernel
@@ -271,6 +273,11 @@ hipError_t launch_curve_df(const CurveDev& cv, int64_t n, const double* t_dev, d
 size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta);
 hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const OutputsDev& out, bool want_delta,
                              int n_blocks, hipStream_t stream);
+// the foreign leg of cross-currency swaps on two curves (payment-lag rows; cv: foreign OIS curve, cx: XCCY curve): PV and two
+// delta ladders (out.delta on cv's pillars, out.delta2 on cx's) from one read of the coupons
+size_t lite_xc_kernel_lds_bytes(const CurveDev& cv, const CurveDev& cx);
+hipError_t launch_price_lite_xc(const CurveDev& cv, const CurveDev& cx, const LiteRowsDev& tr, const OutputsDev& out, int n_blocks,
+                                hipStream_t stream);
 // Aggregate-only mode (kernels_lite.hip KNOT instantiations + kernels_knot.hip): the book's knot-space sums from the rows of
 // the lite table, reduced over the blocks in a fixed order, projected once to the pillar ladders and ADDED to agg
 // ([pv, delta[P], gamma[P*P]]; the caller has zeroed it or another kernel family's reduction has written it).

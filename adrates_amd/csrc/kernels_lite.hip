@@ -26,6 +26,14 @@
 // W64 instantiations (round 3): curves of 33-64 pillars - the 64-wide Jacobian table of the wide layout (curve_tables.hpp),
 // four pillars per lane (two b128 reads of the row and four FMAs per entry), block partials in the wide route's record.
 //
+// XC instantiation (round 4): the FOREIGN LEG of a book of cross-currency swaps in one launch (`Engine._compute_xccy`'s second
+// `_float_leg_jax` call, cavour/market/position/engine.py:1640-1733: forwards off the foreign OIS curve, discounting on the
+// XCCY curve).  The payment-lag rows carry the leg as it is - payment times in the XCCY curve's day count, accrual times in
+// the leg's own - and the kernel holds TWO curves' tables: a coupon is N ((D_f(ts) / D_f(te) - 1) + s a) D_x(tp), looked up
+// once (D_x(tp); D_f(te); D_f(ts) from the previous lane), and leaves entries for the foreign-rate ladder (N D_x R on the
+// knots of ts / te) AND for the basis ladder (the amount times D_x on the knots of tp); the notional exchanges are fixed
+// flows on the XCCY curve.  No weights from a host pre-pass, no second batch: two ladders and the PV from one read.
+//
 // KNOT instantiations (round 4): the AGGREGATE-ONLY mode - Portfolio.compute's single ladder (cavour/market/portfolio/
 // portfolio.py:39-66), no per-trade output.  The reference's chain rule, jac.T @ hess_dfs @ jac + sum_k g_k hess[k]
 // (engine.py:2551-2567), is linear in the knot-space gradient g and Hessian hess_dfs of a trade, so summed over a book it
@@ -117,10 +125,12 @@ struct CurveLds {
 // NSEG: segments of the row table the kernel looks at (3 covers tables of at most three distinct row counts - every
 // table of trades without payment lag; kLiteSegments otherwise)
 // KNOT: 0 = per-trade ladders; 1 = aggregate-only, first order (w_k); 2 = aggregate-only with the second-order sums
-template <bool DELTA, bool LINDF, bool LAG, int NSEG, bool W64 = false, int KNOT = 0>
+// XC: foreign-leg rows of cross-currency swaps on two curves (cv: the foreign OIS curve, cx: the XCCY curve)
+template <bool DELTA, bool LINDF, bool LAG, int NSEG, bool W64 = false, int KNOT = 0, bool XC = false>
 __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
-                                                                                       OutputsDev out) {
+                                                                                       OutputsDev out, CurveDev cx) {
     static_assert(!(LAG && LINDF), "payment-lag trades under LINEAR_FWD_RATES go to the general kernel");
+    static_assert(!XC || (LAG && DELTA && !W64 && KNOT == 0), "the two-curve mode works on payment-lag rows, per trade");
     static_assert(KNOT == 0 || (DELTA && !W64), "aggregate-only mode: any pillar count (no 64-wide Jacobian table is needed)");
     constexpr int PW = W64 ? kWidePad : kPillarPad;       // pillars per row of the Jacobian table
     constexpr int PPL = PW / L;                           // pillars per lane: 2, or 4 on the 64-wide table
@@ -137,9 +147,18 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
     double* s_log = s_x + cv.K;
     double* s_invx = s_log + cv.Kc;
     double* s_invdx = s_invx + cv.Kc;
-    int16_t* s_first = reinterpret_cast<int16_t*>(s_invdx + cv.K);
+    // XC: the second curve's Jacobian table and search arrays behind the first one's doubles
+    double* s_lj2 = s_invdx + cv.K;
+    double* s_x2 = s_lj2 + (XC ? cx.Kc * kPillarPad : 0);
+    double* s_log2 = s_x2 + (XC ? cx.K : 0);
+    double* s_invx2 = s_log2 + (XC ? cx.Kc : 0);
+    double* s_invdx2 = s_invx2 + (XC ? cx.Kc : 0);
+    int16_t* s_first = reinterpret_cast<int16_t*>(s_invdx2 + (XC ? cx.K : 0));
     int16_t* s_comp = s_first + cv.K;
     int16_t* s_lut = s_comp + cv.K;
+    int16_t* s_first2 = s_lut + 2 * cv.n_lut;
+    int16_t* s_comp2 = s_first2 + (XC ? cx.K : 0);
+    int16_t* s_lut2 = s_comp2 + (XC ? cx.K : 0);
 
     if (KNOT) {
         for (int i = threadIdx.x; i < kWavesPerBlock * NT * cv.Kc; i += kBlockThreads) s_knot[i] = 0.0;
@@ -161,11 +180,28 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
         s_invx[i] = cv.inv_x[i];
     }
     for (int i = threadIdx.x; i < 2 * cv.n_lut; i += kBlockThreads) s_lut[i] = cv.lut[i];
+    if (XC) {
+        for (int i = threadIdx.x; i < cx.Kc * kPillarPad; i += kBlockThreads) s_lj2[i] = cx.lj[i];
+        for (int i = threadIdx.x; i < cx.K; i += kBlockThreads) {
+            s_x2[i] = cx.x[i];
+            const double dx = i > 0 ? cx.x[i] - cx.x[i - 1] : 0.0;
+            s_invdx2[i] = fabs(dx) <= 0x1p-104 ? 0.0 : 1.0 / dx;
+            s_first2[i] = cx.first_of[i];
+            s_comp2[i] = cx.compact_of[i];
+        }
+        for (int i = threadIdx.x; i < cx.Kc; i += kBlockThreads) { s_log2[i] = cx.log_df[i]; s_invx2[i] = cx.inv_x[i]; }
+        for (int i = threadIdx.x; i < 2 * cx.n_lut; i += kBlockThreads) s_lut2[i] = cx.lut[i];
+    }
     __syncthreads();
 
     CurveLds c;
     c.x = s_x; c.log_df = s_log; c.inv_x = s_invx; c.lut = s_lut; c.n_lut = cv.n_lut;
     c.first_of = s_first; c.compact_of = s_comp; c.inv_dx = s_invdx; c.K = cv.K; c.method = cv.method;
+    CurveLds c2 = c;             // XC: the XCCY curve
+    if (XC) {
+        c2.x = s_x2; c2.log_df = s_log2; c2.inv_x = s_invx2; c2.lut = s_lut2; c2.n_lut = cx.n_lut;
+        c2.first_of = s_first2; c2.compact_of = s_comp2; c2.inv_dx = s_invdx2; c2.K = cx.K; c2.method = cx.method;
+    }
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -178,6 +214,7 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
     const unsigned char* rec_group = rec_wave + g * ((2 * L + 1) * 16);
     unsigned char* rec_mine = rec_wave + (g * (2 * L + 1) + 2 * l) * 16;
     const unsigned char* lj_lane = reinterpret_cast<const unsigned char*>(s_lj) + l * (8 * PPL);    // pillars PPL l .. PPL l + PPL - 1
+    const unsigned char* lj2_lane = reinterpret_cast<const unsigned char*>(s_lj2) + l * 16;         // XC: pillars 2l, 2l + 1 of the second ladder
     double* knot_w = s_knot + wave * (NT * cv.Kc);        // KNOT: this wave's tables
     double* knot_d = knot_w + (NT > 1 ? cv.Kc : 0);
     double* knot_o = knot_w + (NT > 1 ? 2 * cv.Kc : 0);      // band d at knot_o + (d - 1) Kc
@@ -327,7 +364,8 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
             // nodes need no flags.  (On curves whose pillar dates are runs of duplicate knots a node's right-hand knot -
             // the first of a run - is never the next node's left-hand knot - the last of that run -, so merging
             // neighbours' entries buys nothing: tried, slower.)
-            auto sweep = [&](bool on, double ca, double cb, int ka, int kb, double ba, double bb, bool plain_node = true) {
+            auto sweep = [&](bool on, double ca, double cb, int ka, int kb, double ba, double bb, bool plain_node = true,
+                             bool second = false) {
                 if constexpr (KNOT != 0) {
                     // aggregate-only: the node's five numbers into this wave's knot tables.  (ca, cb) = w (ba, bb) - under
                     // LINEAR_FWD_RATES the two single-knot amounts, each with weight 1 on its own knot and no cross term.
@@ -371,11 +409,16 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                     for (int i = 0; i < kBatch; ++i) rc[i] = *reinterpret_cast<const double2*>(rec_group + (e + i) * 16);
 #pragma unroll
                     for (int i = 0; i < kBatch; ++i) {
-                        rw[i] = *reinterpret_cast<const double2*>(lj_lane + __double2loint(rc[i].y));
+                        rw[i] = *reinterpret_cast<const double2*>((XC && second ? lj2_lane : lj_lane) + __double2loint(rc[i].y));
                         if (W64) rv[i] = *reinterpret_cast<const double2*>(lj_lane + __double2loint(rc[i].y) + 16);
                     }
 #pragma unroll
                     for (int i = 0; i < kBatch; ++i) {
+                        if (XC && second) {                       // (wave-uniform) the second curve's ladder
+                            if (i & 1) { e2 = fma(rc[i].x, rw[i].x, e2); e3 = fma(rc[i].x, rw[i].y, e3); }
+                            else { d2 = fma(rc[i].x, rw[i].x, d2); d3 = fma(rc[i].x, rw[i].y, d3); }
+                            continue;
+                        }
                         if (i & 1) { e0 = fma(rc[i].x, rw[i].x, e0); e1 = fma(rc[i].x, rw[i].y, e1); }
                         else { d0 = fma(rc[i].x, rw[i].x, d0); d1 = fma(rc[i].x, rw[i].y, d1); }
                         if (W64) {
@@ -388,7 +431,38 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                 __builtin_amdgcn_s_setprio(0);
 #endif
             };
-            if (LAG) {
+            if constexpr (XC) {
+                // ---- foreign leg of a cross-currency swap (lane = coupon): forwards off the first curve (the foreign OIS
+                // curve), discounting on the second (the XCCY curve):  N ((R - 1) + s a) D_x(tp),  R = D_f(ts) / D_f(te)
+                const bool ratio = valid && accrues;
+                Lookup qs{0, 0, 0.0, 0.0}, qe{0, 0, 0.0, 0.0}, qp{0, 0, 0.0, 0.0};
+                double ls = 0.0, le = 0.0, lp = 0.0;
+                const bool paid_later = valid && tp != 0.0;          // (paid AT the value time: D_x = 1, no basis sensitivity)
+                if (paid_later) { qp = curve_lookup<true>(c2, tp); lp = fma(qp.ba, c2.log_df[qp.ka], qp.bb * c2.log_df[qp.kb]); }
+                if (ratio) { qe = curve_lookup<true>(c, te); le = fma(qe.ba, c.log_df[qe.ka], qe.bb * c.log_df[qe.kb]); }
+                const double prev_ratio = row_prev(ratio ? 1.0 : 0.0), prev_te = row_prev(te), le_prev = row_prev(le);
+                const bool chained = ratio && l > 0 && prev_ratio != 0.0 && prev_te == ts;      // (as in the payment-lag rows below)
+                if (ratio && !chained) { qs = curve_lookup<true>(c, ts); ls = fma(qs.ba, c.log_df[qs.ka], qs.bb * c.log_df[qs.kb]); }
+                if (chained) ls = le_prev;
+                const double w_not = sl * N * cw;
+                const double dx = exp(lp);                            // D_x(tp) / D_x(0)
+                const double R = ratio ? exp(ls - le) : 1.0;
+                const double om_r = ratio ? w_not * dx * R : 0.0;     // what the foreign rates move: N D_x(tp) D_f(ts) / D_f(te)
+                double amount = valid ? w_not * ((R - 1.0) + spread * al) : 0.0;
+                if (fix_merged && xtp > 0.0) amount = fma(sf, xpay, amount);          // an exchange paid on the coupon's date
+                const double om_b = amount * dx;                      // the coupon's value; what the basis spreads move
+                pv += om_b;
+                ADR_STAMP(2);   // lookups + exp
+                {
+                    const double next_flag = row_next(chained ? 1.0 : 0.0), next_om = row_next(om_r);
+                    const bool next_chained = l + 1 < L && next_flag != 0.0;
+                    const double om_e = (next_chained ? next_om : 0.0) - om_r;
+                    sweep(ratio && !chained, om_r * qs.ba, om_r * qs.bb, qs.ka, qs.kb, qs.ba, qs.bb, false);
+                    sweep(ratio, om_e * qe.ba, om_e * qe.bb, qe.ka, qe.kb, qe.ba, qe.bb, false);
+                    sweep(paid_later, om_b * qp.ba, om_b * qp.bb, qp.ka, qp.kb, qp.ba, qp.bb, false, true);
+                }
+                ADR_STAMP(3);   // entries + ladders
+            } else if (LAG) {
                 // ---- the row's coupons: ratio node + payment node (lane = coupon); three lookups, two exponentials
                 const bool ratio = valid && accrues;
                 Lookup qs{0, 0, 0.0, 0.0}, qe{0, 0, 0.0, 0.0}, qp{0, 0, 0.0, 0.0};
@@ -463,13 +537,14 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                 double ca = 0.0, cb = 0.0, q_ba = 0.0, q_bb = 0.0;
                 int q_ka = 0, q_kb = 0;
                 if (qon) {
-                    const Lookup q = curve_lookup<true>(c, qt);
+                    const Lookup q = XC ? curve_lookup<true>(c2, qt) : curve_lookup<true>(c, qt);      // XC: the exchanges, on the XCCY curve
                     if (LINDF) {
                         ca = qa * q.ba * exp(c.log_df[q.ka]);
                         cb = q.bb != 0.0 ? qa * q.bb * exp(c.log_df[q.kb]) : 0.0;
                         pv += ca + cb;
                     } else {
-                        const double omega = qa * exp(fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]));
+                        const double* lg = XC ? c2.log_df : c.log_df;
+                        const double omega = qa * exp(fma(q.ba, lg[q.ka], q.bb * lg[q.kb]));
                         pv += omega;
                         ca = omega * q.ba; cb = omega * q.bb;
                     }
@@ -477,7 +552,7 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
                 }
                 ADR_STAMP(2);   // lookup + exp
                 if (!DELTA) continue;
-                sweep(qon, ca, cb, q_ka, q_kb, q_ba, q_bb);
+                sweep(qon, ca, cb, q_ka, q_kb, q_ba, q_bb, true, XC);
                 ADR_STAMP(3);   // entries + ladder
             }
         }
@@ -499,7 +574,16 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
         if (!KNOT && DELTA && live) {
             d0 = (d0 + e0) * 1e-4; d1 = (d1 + e1) * 1e-4;
             tot_d0 += d0; tot_d1 += d1;
-            if (W64) { d2 = (d2 + e2) * 1e-4; d3 = (d3 + e3) * 1e-4; tot_d2 += d2; tot_d3 += d3; }
+            if (W64 || XC) { d2 = (d2 + e2) * 1e-4; d3 = (d3 + e3) * 1e-4; tot_d2 += d2; tot_d3 += d3; }
+            if (XC && out.delta2) {      // the second curve's ladder (its pillar count is even: the XCCY tables are padded)
+                double* dst2 = out.delta2 + static_cast<int64_t>(t) * cx.P + 2 * l;
+                if ((cx.P & 1) == 0) {
+                    if (2 * l < cx.P) { nt_pair pr; pr.x = d2; pr.y = d3; __builtin_nontemporal_store(pr, reinterpret_cast<nt_pair*>(dst2)); }
+                } else {
+                    if (2 * l < cx.P) dst2[0] = d2;
+                    if (2 * l + 1 < cx.P) dst2[1] = d3;
+                }
+            }
             if (out.delta) {
                 double* dst = out.delta + static_cast<int64_t>(t) * P + PPL * l;
                 if ((P & 1) == 0) {
@@ -556,20 +640,32 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
             tot_pv += __shfl_xor(tot_pv, off, 64);
             tot_d0 += __shfl_xor(tot_d0, off, 64);
             tot_d1 += __shfl_xor(tot_d1, off, 64);
-            if (W64) { tot_d2 += __shfl_xor(tot_d2, off, 64); tot_d3 += __shfl_xor(tot_d3, off, 64); }
+            if (W64 || XC) { tot_d2 += __shfl_xor(tot_d2, off, 64); tot_d3 += __shfl_xor(tot_d3, off, 64); }
         }
         __syncthreads();   // every wave is done with the tables; reuse the LDS
-        constexpr int kRed = 1 + PW;
-        double* red = reinterpret_cast<double*>(smem_raw);          // [waves][1 + PW]
+        constexpr int kRed = 1 + PW + (XC ? kPillarPad : 0);        // XC: the second ladder behind the first
+        double* red = reinterpret_cast<double*>(smem_raw);          // [waves][kRed]
         if (lane == 0) red[wave * kRed] = tot_pv;
         if (g == 0) {
             red[wave * kRed + 1 + PPL * l] = tot_d0; red[wave * kRed + 2 + PPL * l] = tot_d1;
             if (W64) { red[wave * kRed + 3 + PPL * l] = tot_d2; red[wave * kRed + 4 + PPL * l] = tot_d3; }
+            if (XC) { red[wave * kRed + 1 + PW + 2 * l] = tot_d2; red[wave * kRed + 2 + PW + 2 * l] = tot_d3; }
         }
         __syncthreads();
+        if (XC) {       // the second ladder's block record: [0, delta2[32], ...] in the second partials array
+            double* dst2 = out.block_partials2 + static_cast<size_t>(blockIdx.x) * kAggStride;
+            if (threadIdx.x <= kPillarPad) {
+                double s2 = 0.0;
+                if (threadIdx.x > 0) {
+#pragma unroll
+                    for (int w = 0; w < kWavesPerBlock; ++w) s2 += red[w * kRed + PW + threadIdx.x];
+                }
+                dst2[threadIdx.x] = s2;
+            }
+        }
         // (W64: the wide route's record - pv, delta[64], then the packed gamma entries, which no delta request reads)
         double* dst = out.block_partials + static_cast<size_t>(blockIdx.x) * (W64 ? 1 + kWidePad + cv.wide_nch * kWideChunk : kAggStride);
-        if (threadIdx.x < kRed) {
+        if (threadIdx.x < 1 + PW) {
             double s = 0.0;
 #pragma unroll
             for (int w = 0; w < kWavesPerBlock; ++w) s += red[w * kRed + threadIdx.x];
@@ -581,7 +677,7 @@ __global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_k
 }  // namespace
 
 namespace {
-using LiteFn = void (*)(CurveDev, LiteRowsDev, OutputsDev);
+using LiteFn = void (*)(CurveDev, LiteRowsDev, OutputsDev, CurveDev);
 
 template <bool DELTA, bool LINDF, bool LAG, bool W64>
 LiteFn lite_kernel_nseg(bool many) {
@@ -627,7 +723,7 @@ hipError_t launch_price_knot(const CurveDev& cv, const LiteRowsDev& tr, const Ou
     const bool lag = tr.te_w != nullptr;                                // payment-lag rows: ratio nodes, log-linear schemes
     if (!out.knot_partials || (lag && (cv.method == 2 || (want_gamma && !out.knot_overflow)))) return hipErrorInvalidValue;
     const size_t lds = knot_kernel_lds_bytes(cv, want_gamma, lag);
-    hipLaunchKernelGGL(knot_kernel(want_gamma, cv.method == 2, tr.n_seg > 3, lag), dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out);
+    hipLaunchKernelGGL(knot_kernel(want_gamma, cv.method == 2, tr.n_seg > 3, lag), dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out, CurveDev{});
     return hipGetLastError();
 }
 
@@ -647,7 +743,31 @@ hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const Ou
     const dim3 grid(n_blocks), block(kBlockThreads);
     if (tr.te_w && cv.method == 2) return hipErrorInvalidValue;        // payment-lag rows: log-linear schemes only
     if (cv.T > 1 && !cv.lj64) return hipErrorInvalidValue;             // 33-64 pillars: the wide layout's table
-    hipLaunchKernelGGL(lite_kernel(want_delta, cv.method == 2, tr.te_w != nullptr, tr.n_seg > 3, cv.T > 1), grid, block, lds, stream, cv, tr, out);
+    hipLaunchKernelGGL(lite_kernel(want_delta, cv.method == 2, tr.te_w != nullptr, tr.n_seg > 3, cv.T > 1), grid, block, lds, stream, cv, tr, out, CurveDev{});
+    return hipGetLastError();
+}
+
+// the foreign leg of a cross-currency book on two curves (XC instantiations): cv = the foreign OIS curve, cx = the XCCY curve
+namespace {
+LiteFn lite_xc_kernel(bool many) {
+    return many ? &price_lite_kernel<true, false, true, kLiteSegments, false, 0, true> : &price_lite_kernel<true, false, true, 3, false, 0, true>;
+}
+}  // namespace
+
+size_t lite_xc_kernel_lds_bytes(const CurveDev& cv, const CurveDev& cx) {
+    size_t bytes = lite_kernel_lds_bytes(cv, true);
+    bytes += sizeof(double) * (static_cast<size_t>(cx.Kc) * kPillarPad + 2 * static_cast<size_t>(cx.K) + 2 * cx.Kc);
+    bytes += sizeof(int16_t) * (2 * static_cast<size_t>(cx.K) + 2 * static_cast<size_t>(cx.n_lut));
+    const size_t reduce = sizeof(double) * kWavesPerBlock * (1 + 2 * kPillarPad);
+    if (bytes < reduce) bytes = reduce;
+    return (bytes + 15) & ~static_cast<size_t>(15);
+}
+
+hipError_t launch_price_lite_xc(const CurveDev& cv, const CurveDev& cx, const LiteRowsDev& tr, const OutputsDev& out, int n_blocks,
+                                hipStream_t stream) {
+    if (!tr.te_w || cv.method == 2 || cx.method == 2 || cv.T > 1 || cx.T > 1 || !cv.lj || !cx.lj) return hipErrorInvalidValue;
+    const size_t lds = lite_xc_kernel_lds_bytes(cv, cx);
+    hipLaunchKernelGGL(lite_xc_kernel(tr.n_seg > 3), dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out, cx);
     return hipGetLastError();
 }
 
@@ -667,6 +787,8 @@ hipError_t set_lite_kernel_lds_limit(size_t bytes) {
                 fns.push_back(reinterpret_cast<const void*>(knot_kernel(g != 0, lin != 0, many != 0, false)));
                 if (!lin) fns.push_back(reinterpret_cast<const void*>(knot_kernel(g != 0, false, many != 0, true)));
             }
+    fns.push_back(reinterpret_cast<const void*>(lite_xc_kernel(false)));
+    fns.push_back(reinterpret_cast<const void*>(lite_xc_kernel(true)));
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
         if (e != hipSuccess) return e;

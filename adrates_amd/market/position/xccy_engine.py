@@ -472,6 +472,68 @@ def book_batches(engine, swaps):
     return cur + ((domestic, foreign_rates, foreign_flows), pv_const, spot, raw)
 
 
+def compile_xccy_legs(raw: RawXccy, spot):
+    """The two trade batches of the ONE-LAUNCH foreign leg (`adr_price_xccy_foreign`): the domestic legs as in `compile_xccy`,
+    and the foreign legs AS THEY ARE - payment times on the XCCY curve's day count, accrual times on the leg's own, the
+    notional exchanges as fixed flows - with no discount factor from any curve: the kernel looks D_x(tp), D_f(ts), D_f(te) up
+    itself (engine.py:1640-1733).  Returns ``(domestic, foreign_legs, pv_const)``; a batch built this way can be priced again
+    under other curves without touching the host."""
+    dfix_off, dfix_tp, dfix_pay, pv_const = _native.exchange_flows_host(raw.dom_exch_t, raw.dom_n, raw.dom_exch, raw.dom_sign, 1.0)
+    domestic = TradeBatch(dfix_off, raw.dom_off, dfix_tp, dfix_pay, raw.dom_tp, raw.dom_ts, raw.dom_te, raw.dom_al,
+                          raw.dom_n, raw.dom_spread, raw.dom_sign, raw.dom_sign)
+    e_off, e_tp, e_pay, e_const = _native.exchange_flows_host(raw.for_exch_t, raw.for_n, raw.for_exch, raw.for_sign, spot)
+    foreign_legs = TradeBatch(e_off, raw.for_off, e_tp, e_pay, raw.for_tpx, raw.for_ts, raw.for_te, raw.for_al,
+                              raw.for_n, raw.for_spread, raw.for_sign, raw.for_sign)
+    return domestic, foreign_legs, pv_const + e_const
+
+
+# VALUE / DELTA requests price the foreign leg in ONE launch on two curves (False: always the three-batch assembly)
+FUSED_FOREIGN_LEG = True
+
+
+def _price_fused(engine, swaps, want_value, want_delta, per_trade, aggregate):
+    """PV and the three delta ladders with the foreign leg in one launch; None when the launch does not take the book
+    (a leg of more than 390 coupons, a leg whose accrual ends all coincide with its payment times, curves it is not built
+    for): the caller then falls back to the three-batch assembly."""
+    if isinstance(swaps, XccyTerms):
+        one = lambda v: v[0] if isinstance(v, (list, tuple, np.ndarray)) else v
+        cur = _curves_for(engine, one(swaps.domestic_floating_index), one(swaps.foreign_floating_index),
+                          one(swaps.domestic_currency), one(swaps.foreign_currency))
+    else:
+        cur = _curves(engine, swaps)
+    dom_model, for_model, xccy, dom_cur, for_cur, x_dev = cur
+    ctx = dom_cur["ctx"]
+    raw = (raw_from_terms(swaps, engine.model.value_dt, xccy._dc_type) if isinstance(swaps, XccyTerms)
+           else raw_from_swaps(swaps, engine.model.value_dt, xccy._dc_type))
+    spot = xccy._spot_fx
+    domestic, foreign_legs, pv_const = compile_xccy_legs(raw, spot)
+    dom_tr, for_tr = _native.upload_many(ctx, [domestic, foreign_legs])
+    try:
+        try:
+            frn = _native.price_xccy_foreign(ctx, for_cur["dev"], x_dev, for_tr, want_value=want_value, want_delta=want_delta,
+                                             per_trade=per_trade, aggregate=aggregate)
+        except LibError as exc:
+            if "(-2)" in str(exc):          # ADR_ERR_UNSUPPORTED: not a book for this launch
+                return None
+            raise
+        dom = _native.price(ctx, dom_cur["dev"], dom_tr, want_value=want_value, want_delta=want_delta, want_gamma=False,
+                            per_trade=per_trade, aggregate=aggregate)
+    finally:
+        dom_tr.close(); for_tr.close()
+    n_basis = len(xccy.swap_times)
+    out = {}
+    for pre in (("",) if per_trade else ()) + (("agg_",) if aggregate else ()):
+        if want_value:
+            const = pv_const if pre == "" else float(pv_const.sum())
+            out[pre + "pv"] = dom[pre + "pv"] + frn[pre + "pv"] / spot + const
+        if want_delta:
+            out[pre + "delta_dom"] = np.asarray(dom[pre + "delta"])
+            out[pre + "delta_for"] = np.asarray(frn[pre + "delta_foreign"]) / spot
+            out[pre + "delta_basis"] = _trim(frn[pre + "delta_basis"], "delta", n_basis) / spot
+    out["tenors"] = (to_tenor(list(dom_model.swap_times)), to_tenor(list(for_model.swap_times)), to_tenor(list(xccy.swap_times)))
+    return out
+
+
 def price_xccy_batch(engine, swaps, reqs, per_trade=True, aggregate=False, cross_gamma=False):
     """VALUE / DELTA / GAMMA of a book of cross-currency basis swaps on one currency pair: three launches.
     ``swaps``: `XccyBasisSwap` objects, or `XccyTerms` (no per-swap objects: the vectorised compiler).
@@ -481,6 +543,12 @@ def price_xccy_batch(engine, swaps, reqs, per_trade=True, aggregate=False, cross
     with ``cross_gamma`` and GAMMA also ``cross_for_basis [n, P_f, P_b]`` (`cross_gamma_for_basis`);
     everything in domestic currency, per bp / bp^2."""
     reqs = set(reqs)
+    if FUSED_FOREIGN_LEG and RequestTypes.GAMMA not in reqs and (isinstance(swaps, XccyTerms) or len(list(swaps)) > 0):
+        if not isinstance(swaps, XccyTerms):
+            swaps = list(swaps)
+        fused = _price_fused(engine, swaps, RequestTypes.VALUE in reqs, RequestTypes.DELTA in reqs, per_trade, aggregate)
+        if fused is not None:
+            return fused
     (dom_model, for_model, xccy, dom_cur, for_cur, x_dev,
      (domestic, foreign_rates, foreign_flows), pv_const, spot, raw) = book_batches(engine, swaps)
     ctx = dom_cur["ctx"]

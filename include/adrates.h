@@ -288,6 +288,27 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
                   void* stream);
 
 /*
+ * The foreign leg of a book of cross-currency swaps on TWO curves, one launch: Engine._compute_xccy's second leg call
+ * (cavour/market/position/engine.py:1640-1733 - _float_leg_jax with the foreign OIS curve as index curve and the XCCY curve
+ * as discount curve) with its two first-order ladders.  `legs` is an ordinary batch (adr_trades_upload): per swap the
+ * foreign float coupons with flt_tp = payment times in the XCCY curve's day count, flt_ts / flt_te / flt_alpha in the
+ * leg's own, the notional exchanges as fixed flows (times in the XCCY curve's day count), notional, spread and signs in
+ * FOREIGN currency (the caller converts the results with 1 / spot, as the reference does at :1713, :1733).  A coupon is
+ * N ((D_f(ts) / D_f(te) - 1) + spread alpha) D_x(tp): pv [n]; delta_foreign [n * P_f] = d pv / d (foreign par rates) with the
+ * XCCY curve held fixed (:1702-1712); delta_basis [n * P_x] = d pv / d (basis spreads); per bp.  agg_foreign / agg_basis: the
+ * book sums in adr_price's layout ([pv, delta[P], zeros]; the PV total sits in agg_foreign[0]).  VALUE / DELTA only
+ * (ADR_ERR_UNSUPPORTED with GAMMA: use three batches - adr_trades_upload_weighted - and adr_price); both curves up to 32
+ * pillars on FLAT_FWD_RATES or LINEAR_ZERO_RATES; every leg at most 390 coupons with some accrual end != payment time.
+ * The _dev form enqueues on `stream` and neither allocates nor synchronises.
+ */
+int adr_price_xccy_foreign(adr_ctx* ctx, const adr_curve* foreign_curve, const adr_curve* xccy_curve, const adr_trades* legs,
+                           uint32_t req_mask, double* pv, double* delta_foreign, double* delta_basis, double* agg_foreign,
+                           double* agg_basis);
+int adr_price_xccy_foreign_dev(adr_ctx* ctx, const adr_curve* foreign_curve, const adr_curve* xccy_curve, const adr_trades* legs,
+                               uint32_t req_mask, double* pv_dev, double* delta_foreign_dev, double* delta_basis_dev,
+                               double* agg_foreign_dev, double* agg_basis_dev, void* stream);
+
+/*
  * Host-side half of adr_price_dev's routing, exposed so that it can be checked without a GPU (like adr_curve_layout_host):
  * the launch plan for a curve (arguments as adr_curve_upload_ex) and a batch (the arrays of adr_trades_upload_weighted the
  * classification reads) under a request - req_mask, per_trade != 0: some per-trade output is wanted, aggregate != 0: agg is

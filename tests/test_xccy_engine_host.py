@@ -48,8 +48,18 @@ def _host_curve_df(ctx, curve, t):
     return float(out) if np.ndim(t) == 0 else out
 
 
+def _host_no_two_curve_launch(ctx, *a, **k):
+    """The two-curve foreign-leg launch (adr_price_xccy_foreign) has no C restatement: the stand-in answers as the library
+    does for a book the launch does not take (ADR_ERR_UNSUPPORTED), so these tests run the three-batch assembly - the
+    fallback of the product path.  The one-launch path is compared with it and with the oracle on the GPU
+    (tests/test_gpu_xccy.py)."""
+    from adrates_amd.utils.error import LibError
+    raise LibError("adr_price_xccy_foreign failed (-2): no two-curve launch on the host stand-in")
+
+
 @pytest.fixture()
 def host_engine(monkeypatch):
+    monkeypatch.setattr(_native, "price_xccy_foreign", _host_no_two_curve_launch)
     monkeypatch.setattr(_native, "curve_df", _host_curve_df)
     monkeypatch.setattr(_native, "DeviceCurve", _HostCurve)
     monkeypatch.setattr(_native, "DeviceTrades", _HostTrades)

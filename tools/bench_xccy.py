@@ -79,6 +79,48 @@ t0 = time.perf_counter()
 book2 = _native.upload_many(ctx, again)
 upload_warm_s = time.perf_counter() - t0
 del book2
+# VALUE / DELTA: the foreign leg in ONE launch on two curves (adr_price_xccy_foreign) next to the domestic launch
+fused = {}
+if not mask & 4:
+    t0 = time.perf_counter()
+    raw = XE.raw_from_terms(terms, engine.model.value_dt, xccy._dc_type)
+    dom_b, for_b, _ = XE.compile_xccy_legs(raw, spot)
+    legs_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    dom_tr, for_tr = _native.upload_many(ctx, [dom_b, for_b])
+    legs_upload_s = time.perf_counter() - t0
+    Pd, Pf, Px = dom_cur["dev"].n_pillars, for_cur["dev"].n_pillars, x_dev.n_pillars
+    f_pv = torch.empty(n, dtype=torch.float64, device=dev)
+    f_df = torch.empty((n, Pf), dtype=torch.float64, device=dev)
+    f_dx = torch.empty((n, Px), dtype=torch.float64, device=dev)
+    f_af = torch.empty(1 + Pf + Pf * Pf, dtype=torch.float64, device=dev)
+    f_ax = torch.empty(1 + Px + Px * Px, dtype=torch.float64, device=dev)
+    d_pv, d_de, _, d_ag = bufs[0]
+
+    def two(per_swap=True):
+        _native.price_dev(ctx, dom_cur["dev"], dom_tr, mask, d_pv.data_ptr() if per_swap else 0, d_de.data_ptr() if per_swap else 0, 0,
+                          d_ag.data_ptr(), s.cuda_stream)
+        _native.price_xccy_foreign_dev(ctx, for_cur["dev"], x_dev, for_tr, mask, f_pv.data_ptr() if per_swap else 0,
+                                       f_df.data_ptr() if per_swap else 0, f_dx.data_ptr() if per_swap else 0,
+                                       f_af.data_ptr(), f_ax.data_ptr(), s.cuda_stream)
+
+    def foreign_only():
+        _native.price_xccy_foreign_dev(ctx, for_cur["dev"], x_dev, for_tr, mask, f_pv.data_ptr(), f_df.data_ptr(), f_dx.data_ptr(),
+                                       f_af.data_ptr(), f_ax.data_ptr(), s.cuda_stream)
+
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            two()
+        fused = {"ms_two_launches": timed(two), "ms_foreign_leg_one_launch": timed(foreign_only),
+                 "ms_two_launches_aggregate_only": timed(lambda: two(False)),
+                 "host_terms_to_legs_s": legs_s, "host_legs_upload_s": legs_upload_s}
+    # the foreign ladders of the two paths agree (three-batch: foreign rates on the OIS curve, flows on the XCCY curve)
+    with torch.cuda.stream(s):
+        step(); two()
+    s.synchronize()
+    ref_f, ref_x = bufs[1][1], bufs[2][1]
+    fused["max_rel_diff_delta_foreign"] = float((f_df - ref_f).abs().max() / ref_f.abs().max())
+    fused["max_rel_diff_delta_basis"] = float((f_dx[:, :ref_x.shape[1]] - ref_x).abs().max() / ref_x.abs().max())
 pillars = [cur.n_pillars for _, cur in book]
 out_bytes = 8 * n * sum(1 + P + (P * P if mask & 4 else 0) for P in pillars)
 print(json.dumps({"workload": "distinct GBP/USD basis swaps, 1-30Y, annual / semi-annual foreign leg, two thirds seasoned",
@@ -88,4 +130,4 @@ print(json.dumps({"workload": "distinct GBP/USD basis swaps, 1-30Y, annual / sem
                   "host_draw_terms_s": draw_s, "host_terms_to_batches_s": compile_s, "host_upload_s": upload_s,
                   "host_terms_to_batches_warm_s": compile_warm_s, "host_upload_warm_s": upload_warm_s,
                   "host_end_to_end_warm_ms": 1e3 * (compile_warm_s + upload_warm_s) + ms,
-                  "market_build_s": market_s}))
+                  "market_build_s": market_s, **fused}))
