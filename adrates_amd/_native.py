@@ -20,7 +20,7 @@ _LIB_PATH = os.environ.get("ADRATES_HIP_LIB") or os.path.join(os.path.dirname(os
 _lib = None
 
 REQ_VALUE, REQ_DELTA, REQ_GAMMA = 1, 2, 4
-MAX_PILLARS = 64
+MAX_PILLARS = 256            # ADR_MAX_PILLARS (uploaded curves); the device curve builder: 64
 
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)

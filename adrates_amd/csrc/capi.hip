@@ -329,7 +329,7 @@ int adr_curve_upload_ex(adr_ctx* ctx, int interp_method, int K, int P, const dou
         return fail(ADR_ERR_UNSUPPORTED, "adr_curve_upload: only FLAT_FWD_RATES (1), LINEAR_FWD_RATES (2) and "
                                          "LINEAR_ZERO_RATES (4) are implemented");
     if (P > ADR_MAX_PILLARS)
-        return fail(ADR_ERR_UNSUPPORTED, "adr_curve_upload: more than ADR_MAX_PILLARS (64) pillars");
+        return fail(ADR_ERR_UNSUPPORTED, "adr_curve_upload: more than ADR_MAX_PILLARS (256) pillars");
     adr::CurveTables t;
     const std::string err = adr::build_curve_tables(K, P, times, dfs, jac, hess, t);
     if (!err.empty()) return fail(ADR_ERR_INVALID, "adr_curve_upload: " + err);
@@ -472,8 +472,8 @@ int adr_curve_plan_create(adr_ctx* ctx, int interp_method, int K, int P, const d
         interp_method != ADR_INTERP_LINEAR_FWD_RATES)
         return fail(ADR_ERR_UNSUPPORTED, "adr_curve_plan_create: only FLAT_FWD_RATES (1), LINEAR_FWD_RATES (2) and "
                                          "LINEAR_ZERO_RATES (4) are implemented");
-    if (P > ADR_MAX_PILLARS)
-        return fail(ADR_ERR_UNSUPPORTED, "adr_curve_plan_create: more than ADR_MAX_PILLARS (64) pillars");
+    if (P > ADR_MAX_PLAN_PILLARS)
+        return fail(ADR_ERR_UNSUPPORTED, "adr_curve_plan_create: more than ADR_MAX_PLAN_PILLARS (64) pillars");
     if (!acc || !pillar || !prev_idx) return fail(ADR_ERR_INVALID, "adr_curve_plan_create: null scan arrays");
     for (int k = 0; k < K; ++k) {
         if (pillar[k] < 0 || pillar[k] >= P) return fail(ADR_ERR_INVALID, "adr_curve_plan_create: pillar index out of range");

@@ -105,7 +105,7 @@ std::string build_curve_tables(int K, int P, const double* times, const double* 
                 out.lc_block_mask[pair * Kc + c] = mask;
             }
     }
-    if (T > 1) {   // wide layout: the whole ladder in one launch
+    if (T > 1 && P <= kWidePad) {   // wide layout (33-64 pillars): the whole ladder in one launch; beyond, the pillar tiles above
         const int nch = out.wide_nch = wide_chunks(P), row = nch * kWideChunk;
         out.lj64.assign(static_cast<size_t>(Kc) * kWidePad, 0.0);
         for (int c = 0; c < Kc; ++c)

@@ -21,7 +21,7 @@
 namespace adr {
 
 constexpr int kPillarPad = 32;                                  // ladders are padded to this on chip (one pillar tile)
-constexpr int kMaxPillars = 64;                                 // more than 32 pillars: the wide kernel (one launch), or tiles of 32
+constexpr int kMaxPillars = 256;                                // 33-64 pillars: the wide kernel (one launch) or tiles of 32; beyond: tiles
 constexpr int kWidePad = 64;                                    // wide kernel: ladders padded to one wavefront of pillars
 constexpr int kWideChunk = 128;                                 // ... packed gamma entries per chunk: two per lane
 constexpr int kWideMaxChunks = 17;                              // ... 64 * 65 / 2 = 2080 packed entries

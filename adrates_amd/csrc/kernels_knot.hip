@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64) void knot_project_kernel(CurveDev cv, const dou
                                                           const double* overflow, double* agg) {
     extern __shared__ double s_red[];                     // [1 + (2 + bands) Kc]
     __shared__ int col_off[kWidePad + 1];
-    const int P = cv.P, Kc = cv.Kc, q = threadIdx.x;
+    const int P = cv.P, Kc = cv.Kc;
     const int n_values = want_gamma ? 1 + (2 + bands) * Kc : 1 + Kc;
     for (int i = threadIdx.x; i < n_values; i += 64) s_red[i] = reduced[i];
     if (threadIdx.x == 0) {
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(64) void knot_project_kernel(CurveDev cv, const dou
     const double* D = w + Kc;
     const double* O = D + Kc;
     if (static_cast<int>(blockIdx.x) == P) {
-        if (q == 0) agg[0] += s_red[0];
-        if (want_delta && q < P) {
+        if (threadIdx.x == 0) agg[0] += s_red[0];
+        for (int q = threadIdx.x; want_delta && q < P; q += 64) {
             double s = 0.0;
             for (int k = 0; k < Kc; ++k) {
                 const double wk = w[k];
@@ -93,35 +93,38 @@ __global__ __launch_bounds__(64) void knot_project_kernel(CurveDev cv, const dou
     }
     if (!want_gamma) return;
     const int p = blockIdx.x;
-    const int qq = q < P ? q : 0;                          // (lanes beyond the ladder compute a copy of column 0 and do not store)
     const bool any_overflow = overflow && overflow[static_cast<size_t>(Kc) * Kc] != 0.0;    // set by the kernel that used the matrix
-    double s = 0.0;
-    for (int k = 0; k < Kc; ++k) {
-        const double wk = w[k], dk = D[k];
-        const double ap = lj_at(cv, k, p), aq = lj_at(cv, k, qq);
-        if (dk != 0.0) s = fma(dk * ap, aq, s);                      // (wave-uniform branches: the sums are the same for every thread)
-        for (int d = 1; d <= bands && k + d < Kc; ++d) {             // pairs of knots (k, k + d): band d
-            const double ok = O[(d - 1) * Kc + k];
-            if (ok == 0.0) continue;
-            const double bp = lj_at(cv, k + d, p), bq = lj_at(cv, k + d, qq);
-            s = fma(ok, fma(ap, bq, bp * aq), s);
-        }
-        if (any_overflow)                                            // ... and the pairs farther apart (payment-lag rows; rare)
-            for (int l0 = k + bands + 1; l0 < Kc; l0 += 64) {
-                const int l = l0 + static_cast<int>(threadIdx.x);
-                const double mine = l < Kc ? overflow[static_cast<size_t>(k) * Kc + l] : 0.0;
-                unsigned long long any = __ballot(mine != 0.0);
-                while (any) {
-                    const int src = __builtin_ctzll(any);
-                    any &= any - 1;
-                    const double ok = __shfl(mine, src, 64);
-                    const double bp = lj_at(cv, l0 + src, p), bq = lj_at(cv, l0 + src, qq);
-                    s = fma(ok, fma(ap, bq, bp * aq), s);
-                }
+    for (int q0 = 0; q0 < P; q0 += 64) {                   // columns in blocks of one wavefront (more than 64 pillars: several)
+        const int q = q0 + static_cast<int>(threadIdx.x);
+        const int qq = q < P ? q : 0;                          // (lanes beyond the ladder compute a copy of column 0 and do not store)
+        double s = 0.0;
+        for (int k = 0; k < Kc; ++k) {
+            const double wk = w[k], dk = D[k];
+            const double ap = lj_at(cv, k, p), aq = lj_at(cv, k, qq);
+            if (dk != 0.0) s = fma(dk * ap, aq, s);                      // (wave-uniform branches: the sums are the same for every thread)
+            for (int d = 1; d <= bands && k + d < Kc; ++d) {             // pairs of knots (k, k + d): band d
+                const double ok = O[(d - 1) * Kc + k];
+                if (ok == 0.0) continue;
+                const double bp = lj_at(cv, k + d, p), bq = lj_at(cv, k + d, qq);
+                s = fma(ok, fma(ap, bq, bp * aq), s);
             }
-        if (wk != 0.0) s = fma(wk, lc_at(cv, col_off, k, p, qq), s);
+            if (any_overflow)                                            // ... and the pairs farther apart (payment-lag rows; rare)
+                for (int l0 = k + bands + 1; l0 < Kc; l0 += 64) {
+                    const int l = l0 + static_cast<int>(threadIdx.x);
+                    const double mine = l < Kc ? overflow[static_cast<size_t>(k) * Kc + l] : 0.0;
+                    unsigned long long any = __ballot(mine != 0.0);
+                    while (any) {
+                        const int src = __builtin_ctzll(any);
+                        any &= any - 1;
+                        const double ok = __shfl(mine, src, 64);
+                        const double bp = lj_at(cv, l0 + src, p), bq = lj_at(cv, l0 + src, qq);
+                        s = fma(ok, fma(ap, bq, bp * aq), s);
+                    }
+                }
+            if (wk != 0.0) s = fma(wk, lc_at(cv, col_off, k, p, qq), s);
+        }
+        if (q < P) agg[1 + P + p * P + q] += s * 1e-8;
     }
-    if (q < P) agg[1 + P + p * P + q] += s * 1e-8;
 }
 
 }  // namespace

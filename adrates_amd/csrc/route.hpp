@@ -150,6 +150,9 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
                 if (!want_delta && tj > 0) continue;                 // PV alone: tile (0, 0) has it
                 push(F_TILED, set, items, blocks, ti, tj);
             }
+        // (every tile launch is followed by its own reduction: the launches of a pass share one range of the scratch)
+        for (Launch& L : plan.launches) L.first_block = 0;
+        plan.total_blocks = plan.launches.empty() ? 0 : blocks;
         if (plan.total_blocks > max_blocks) plan.error = "grid exceeds scratch";
         knot_launch();
         return plan;

@@ -58,10 +58,14 @@ typedef enum adr_status {
 #define ADR_REQ_DELTA 2u
 #define ADR_REQ_GAMMA 4u
 
-/* Largest pillar count of a curve (the reference has no limit, cavour/market/position/engine.py:2388-2389); larger
- * curves are refused with ADR_ERR_UNSUPPORTED.  Results do not depend on the pillar count's parity or on which kernel
- * family a curve is routed to (DESIGN.md section 5 describes the routes and their measured rates). */
-#define ADR_MAX_PILLARS 64
+/* Largest pillar count of an uploaded curve (the reference has no limit, cavour/market/position/engine.py:2388-2389); larger
+ * curves are refused with ADR_ERR_UNSUPPORTED, and so is one whose knot tables do not fit the 160 KiB LDS of a CU next to two
+ * 32-pillar tiles of its Jacobian.  Up to 32 pillars: the fast / lite kernels; 33-64: one launch for the whole ladder (wide
+ * layout); 65-256: 32-pillar tiles, one launch per tile pair.  Results do not depend on the pillar count's parity or on which
+ * kernel family a curve is routed to (DESIGN.md section 5 describes the routes and their measured rates).
+ * adr_curve_plan_create (the device curve builder) takes up to ADR_MAX_PLAN_PILLARS. */
+#define ADR_MAX_PILLARS 256
+#define ADR_MAX_PLAN_PILLARS 64
 
 /* Flags of adr_curve_upload_ex. */
 #define ADR_CURVE_PILLAR_TILES 1u   /* curves of 33-64 pillars: price on 32-pillar tiles (one launch per tile pair) even when

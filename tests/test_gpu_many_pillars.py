@@ -36,10 +36,14 @@ def forty_pillar_quotes():
 
 
 def many_pillar_quotes(P):
-    """The 32 README quotes plus annual pillars up to 49Y until there are P of them (quoted off the neighbours)."""
+    """The 32 README quotes plus annual pillars up to 49Y until there are P of them (quoted off the neighbours); beyond 62:
+    monthly pillars between 1Y and 2Y, then half-year pillars (30M, 42M, ...) - up to 123."""
     base_t = np.array([_years(t) for t in F.TENORS])
     extra = [f"{y}Y" for y in range(1, 50) if f"{y}Y" not in F.TENORS]
     tenors = sorted(list(F.TENORS) + extra, key=_years)[:P]
+    if P > len(tenors):
+        more = [f"{m}M" for m in range(13, 24) if m != 18] + [f"{m}M" for m in range(30, 600, 12)]
+        tenors = sorted(tenors + more[:P - len(tenors)], key=_years)
     assert len(tenors) == P
     px = [float(np.interp(_years(t), base_t, F.GBP_PX)) if t not in F.TENORS else F.GBP_PX[F.TENORS.index(t)] for t in tenors]
     return px, tenors
@@ -127,6 +131,42 @@ def test_wide_kernel_block_counts_vs_c_oracle(gpu_ctx, P, interp):
     print(f"{P} pillars, {interp.name}: worst error {worst:.2e}")
 
 
+@pytest.mark.parametrize("P,interp", [(70, InterpTypes.FLAT_FWD_RATES), (96, InterpTypes.LINEAR_ZERO_RATES),
+                                      (96, InterpTypes.LINEAR_FWD_RATES), (123, InterpTypes.FLAT_FWD_RATES)])
+def test_more_than_64_pillars_on_tiles_vs_c_oracle(gpu_ctx, P, interp):
+    """65 pillars and more (the reference has no limit, engine.py:2388-2389): three and four 32-pillar tiles, one launch of the
+    general kernel per tile pair; payment lag and spreads in the batch, every request mask, the aggregate, and the
+    aggregate-only request (knot space, one projection over all tiles)."""
+    vd = F.README_VALUE_DT
+    px, tenors = many_pillar_quotes(P)
+    curve = F.gbp_model(vd, interp, px=px, tenors=tenors).curves.GBP_OIS_SONIA
+    host, dc = _device_curve(gpu_ctx, curve)
+    assert dc.n_pillars == P
+    batch = _mixed_batch(vd, 403, seed=P)
+    dt = _native.DeviceTrades(gpu_ctx, batch)
+    ref = port.price(interp.value, host.times, host.dfs, host.jac, host.hess, batch)
+    got = _native.price(gpu_ctx, dc, dt, aggregate=True)
+    assert got["delta"].shape == (403, P) and got["gamma"].shape == (403, P, P)
+    worst = assert_batch_parity(got, ref, batch.notional)
+    assert np.any(got["delta"][:, P - 20:] != 0.0) and np.any(got["gamma"][:, P - 20:, :40] != 0.0)       # the last tile, an off-diagonal tile
+    asym = np.max(np.abs(got["gamma"] - np.swapaxes(got["gamma"], 1, 2)), axis=(1, 2))
+    assert np.all(asym <= 1e-12 * np.max(np.abs(got["gamma"]), axis=(1, 2)) + 1e-14)
+    assert np.allclose(got["agg_pv"], ref["pv"].sum(), rtol=1e-10, atol=1e-3)
+    assert np.allclose(got["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
+    assert np.allclose(got["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+    only_d = _native.price(gpu_ctx, dc, dt, want_gamma=False, aggregate=True)
+    assert_batch_parity(only_d, dict(pv=ref["pv"], delta=ref["delta"]), batch.notional)
+    assert np.allclose(only_d["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6) and np.all(only_d["agg_gamma"] == 0.0)
+    only_v = _native.price(gpu_ctx, dc, dt, want_delta=False, want_gamma=False, aggregate=True)
+    assert_batch_parity(only_v, dict(pv=ref["pv"]), batch.notional)
+    book = _native.price(gpu_ctx, dc, dt, per_trade=False, aggregate=True)           # Portfolio.compute's request
+    assert np.allclose(book["agg_pv"], ref["pv"].sum(), rtol=1e-10, atol=1e-3)
+    assert np.allclose(book["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
+    assert np.allclose(book["agg_gamma"], ref["gamma"].sum(0), rtol=1e-10, atol=1e-9)
+    dt.close()
+    print(f"{P} pillars, {interp.name}: worst error {worst:.2e}")
+
+
 def test_tiled_route_still_serves_wide_curves(gpu_ctx):
     """ADR_CURVE_PILLAR_TILES at upload (adr_curve_upload_ex): the general kernel once per pair of 32-pillar tiles - the route
     of curves whose wide tables do not fit the LDS.  Same numbers as the wide route, to rounding."""
@@ -161,10 +201,14 @@ def test_forty_pillar_curve_through_the_public_api(gpu_ctx):
     for tenor, p in zip(tenors, px):
         v = F.make_swap(vd, tenor, p / 100, 1e6).position(model).compute([RequestTypes.VALUE]).value.amount
         assert abs(v) <= 1e-5, (tenor, v)
-    with pytest.raises(Exception, match="64|pillar"):
-        big_t = [f"{k}M" for k in range(1, 13)] + [f"{k}Y" for k in range(2, 60)]      # 70 pillars
-        big = F.gbp_model(vd, px=[4.0 + 0.001 * i for i in range(len(big_t))], tenors=big_t)
-        F.make_swap(vd, "5Y", 0.04).position(big).compute([RequestTypes.VALUE])
+    # more than 64 pillars: 32-pillar tiles (test_more_than_64_pillars_on_tiles_vs_c_oracle); the limit is ADR_MAX_PILLARS
+    big_t = [f"{k}M" for k in range(1, 13)] + [f"{k}Y" for k in range(2, 60)]      # 70 pillars
+    big = F.gbp_model(vd, px=[4.0 + 0.001 * i for i in range(len(big_t))], tenors=big_t)
+    r70 = F.make_swap(vd, "45Y", 0.04).position(big).compute([RequestTypes.VALUE, RequestTypes.DELTA, RequestTypes.GAMMA])
+    assert len(r70.risk.risk_ladder) == 70 and r70.gamma.risk_ladder.shape == (70, 70) and r70.risk.ladder.data["45Y"] != 0.0
+    K = _native.MAX_PILLARS + 2
+    with pytest.raises(Exception, match="pillar"):
+        _native.DeviceCurve(gpu_ctx, 4, np.arange(K, dtype=float), np.exp(-0.03 * np.arange(K)), np.zeros((K, K - 1)))
 
 
 def test_seventeen_pillar_curve_all_requests(gpu_ctx):

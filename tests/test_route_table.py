@@ -1,6 +1,6 @@
 """The launch plan of adr_price_dev (adrates_amd/csrc/route.hpp), enumerated on the CPU: for the cross product of trade
 classes {plain, long, very long, payment lag, long payment lag, very long payment lag, weighted} x pillar counts {32, 31,
-17, 40, 40 on tiles, 64} x the three interpolation schemes x requests {V, VD, VDG} x outputs {per trade, per trade + aggregate,
+17, 40, 40 on tiles, 64, 96 (three tiles)} x the three interpolation schemes x requests {V, VD, VDG} x outputs {per trade, per trade + aggregate,
 aggregate only}, every trade of a mixed batch is priced by exactly one launch.  The reference has a single route
 (Engine._compute_ois_natural, cavour/market/position/engine.py:153-215); here seven kernel families share the work, and
 every new route so far had cost a correctness fix in the routing - this test walks the table without a GPU."""
@@ -57,7 +57,9 @@ def _curves(vd):
     t64 = sorted(list(F.TENORS) + extra, key=years)[:64]
     base_t = [years(t) for t in F.TENORS]
     px64 = [float(np.interp(years(t), base_t, F.GBP_PX)) if t not in F.TENORS else F.GBP_PX[F.TENORS.index(t)] for t in t64]
-    sets = {32: (None, None), 31: (list(F.GBP_PX[:13]) + list(F.GBP_PX[14:]), list(F.TENORS[:13]) + list(F.TENORS[14:])),
+    from .test_gpu_many_pillars import many_pillar_quotes
+    px96, t96 = many_pillar_quotes(96)
+    sets = {32: (None, None), 96: (px96, t96), 31: (list(F.GBP_PX[:13]) + list(F.GBP_PX[14:]), list(F.TENORS[:13]) + list(F.TENORS[14:])),
             17: (list(F.GBP_PX[8:9] + F.GBP_PX[14:30]), list(F.TENORS[8:9] + F.TENORS[14:30])), 40: (px40, t40), 64: (px64, t64)}
     out = {}
     for P, (px, tenors) in sets.items():
