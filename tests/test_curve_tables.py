@@ -82,7 +82,7 @@ def test_native_table_argument_checks(native_lib):
     with pytest.raises(LibError):
         _native.curve_tables_host(good["times"], np.array([1.0, -0.1, 0.9]), good["jac"])    # DF <= 0
     with pytest.raises(LibError):
-        _native.curve_tables_host(good["times"], good["dfs"], np.zeros((3, 70)))             # too many pillars (64 at most)
+        _native.curve_tables_host(good["times"], good["dfs"], np.zeros((3, 260)))            # too many pillars (256 at most)
     with pytest.raises(LibError, match="value time"):
         _native.curve_tables_host(np.array([0.5, 1.0, 2.0]), good["dfs"], good["jac"])       # grid not anchored at t = 0
     with pytest.raises(LibError, match="value time"):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Throughput on curves of more than 32 pillars - 40 and 64 pillars on the wide variants of the general kernel (one launch),
-the 40-pillar curve again on the tiled route (ADR_CURVE_PILLAR_TILES at upload: one launch per pair of 32-pillar tiles) - and on
+the 40-pillar curve again on the tiled route (ADR_CURVE_PILLAR_TILES at upload: one launch per pair of 32-pillar tiles), a
+96-pillar curve (beyond 64 pillars the tiles are the route) - and on
 the 32-pillar curve for comparison: 100 000 benchmark trades, PV + delta + gamma and PV + delta."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,8 +23,12 @@ dev = torch.device("cuda", 0)
 extra64 = [f"{y}Y" for y in range(1, 50) if f"{y}Y" not in TENORS]
 tenors64 = sorted(list(TENORS) + extra64, key=years)[:64]
 px64 = [float(np.interp(years(t), base_t, GBP_PX)) if t not in TENORS else GBP_PX[TENORS.index(t)] for t in tenors64]
+more = [f"{m}M" for m in range(13, 24) if m != 18] + [f"{m}M" for m in range(30, 600, 12)]
+tenors96 = sorted(list(TENORS) + extra64 + more[:96 - 32 - len(extra64)], key=years)
+px96 = [float(np.interp(years(t), base_t, GBP_PX)) if t not in TENORS else GBP_PX[TENORS.index(t)] for t in tenors96]
 for label, model, wide in (("40 pillars", gbp_model(vd, px=px, tenors=tenors), "1"), ("40 pillars, tiled route", gbp_model(vd, px=px, tenors=tenors), "0"),
-                           ("64 pillars", gbp_model(vd, px=px64, tenors=tenors64), "1"), ("32 pillars", gbp_model(vd), "1"),
+                           ("64 pillars", gbp_model(vd, px=px64, tenors=tenors64), "1"),
+                           ("96 pillars (three tiles: six launches)", gbp_model(vd, px=px96, tenors=tenors96), "1"), ("32 pillars", gbp_model(vd), "1"),
                            ("31 pillars (odd count)", gbp_model(vd, px=list(GBP_PX[:13]) + list(GBP_PX[14:]), tenors=list(TENORS[:13]) + list(TENORS[14:])), "1")):
     curve = model.curves.GBP_OIS_SONIA
     host = build_engine_curve(curve.swap_rates, curve.swap_times, curve.year_fracs)
