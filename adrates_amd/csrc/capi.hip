@@ -1259,9 +1259,8 @@ int adr_price_xccy_foreign_dev(adr_ctx* ctx, const adr_curve* foreign_curve, con
     if (legs->lite.n_units > 0 || legs->n_nonlite_b > 0 || legs->lite_lag.n_units == 0)
         return fail(ADR_ERR_UNSUPPORTED, "adr_price_xccy_foreign: a leg is outside the payment-lag row table (more than 390 coupons, "
                                          "or no coupon whose accrual end differs from its payment time)");
-    const size_t lds = adr::lite_xc_kernel_lds_bytes(cf, cx);
-    const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLdsBudget / lds)));
-    const int blocks = adr::route::blocks_for(legs->lite_lag.n_units, adr::kLiteThreads / 64, static_cast<int64_t>(ctx->n_cu) * per_cu);
+    // one block per CU: its registers leave room for the block's own three waves per SIMD
+    const int blocks = adr::route::blocks_for(legs->lite_lag.n_units, adr::lite_xc_kernel_threads() / 64, static_cast<int64_t>(ctx->n_cu));
     if (2 * blocks > ctx->max_blocks) return fail(ADR_ERR_INVALID, "adr_price_xccy_foreign: grid exceeds scratch");
     const bool want_agg = agg_foreign_dev || agg_basis_dev;
     adr::OutputsDev o{};

@@ -270,11 +270,13 @@ hipError_t launch_reduce_wide(const CurveDev& cv, const double* partials, int n_
 hipError_t launch_price_fast(const CurveDev& cv, const TradesDev& tr, const OutputsDev& out, bool want_delta,
                              bool want_gamma, int n_blocks, hipStream_t stream);
 hipError_t launch_curve_df(const CurveDev& cv, int64_t n, const double* t_dev, double* df_dev, int n_cu, hipStream_t stream);
-size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta);
+size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta, bool lag = false);
+int lite_kernel_threads(const CurveDev& cv, bool delta, bool lag);
 hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const OutputsDev& out, bool want_delta,
                              int n_blocks, hipStream_t stream);
 // the foreign leg of cross-currency swaps on two curves (payment-lag rows; cv: foreign OIS curve, cx: XCCY curve): PV and two
 // delta ladders (out.delta on cv's pillars, out.delta2 on cx's) from one read of the coupons
+int lite_xc_kernel_threads();
 size_t lite_xc_kernel_lds_bytes(const CurveDev& cv, const CurveDev& cx);
 hipError_t launch_price_lite_xc(const CurveDev& cv, const CurveDev& cx, const LiteRowsDev& tr, const OutputsDev& out, int n_blocks,
                                 hipStream_t stream);

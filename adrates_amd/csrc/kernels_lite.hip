@@ -58,6 +58,14 @@ namespace {
 
 constexpr int kBlockThreads = kLiteThreads;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
+#ifndef ADR_LITE_XC_THREADS
+#define ADR_LITE_XC_THREADS 768                   // the two-curve instantiation: 167 VGPRs, three waves per SIMD in ONE block per CU
+#endif                                            // (at the 128 registers of four waves it spills 160 bytes per lane: +20 % time)
+constexpr int kXcThreads = ADR_LITE_XC_THREADS;
+#ifndef ADR_LITE_LAG_THREADS
+#define ADR_LITE_LAG_THREADS 768                  // the payment-lag rows' PV + delta instantiation likewise (145 VGPRs; 68 bytes of spills at 128: +8 %)
+#endif
+constexpr int kLagThreads = ADR_LITE_LAG_THREADS;
 constexpr int L = kLiteSlots;                 // lanes per trade
 constexpr int G = 64 / L;                     // trades per wavefront
 constexpr int kRecBytesPerWave = G * (2 * L + 2) * 16;  // per group: two 16-byte entries per lane + a pad entry
@@ -127,11 +135,15 @@ struct CurveLds {
 // KNOT: 0 = per-trade ladders; 1 = aggregate-only, first order (w_k); 2 = aggregate-only with the second-order sums
 // XC: foreign-leg rows of cross-currency swaps on two curves (cv: the foreign OIS curve, cx: the XCCY curve)
 template <bool DELTA, bool LINDF, bool LAG, int NSEG, bool W64 = false, int KNOT = 0, bool XC = false>
-__global__ __launch_bounds__(kBlockThreads, kLiteWavesPerSimd) void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
+__global__ __launch_bounds__(XC ? kXcThreads : ((LAG && DELTA && !W64 && KNOT == 0) ? kLagThreads : kBlockThreads),
+                            XC ? kXcThreads / 256 : ((LAG && DELTA && !W64 && KNOT == 0 && kLagThreads != kBlockThreads) ? kLagThreads / 256 : kLiteWavesPerSimd))
+void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                                                                                        OutputsDev out, CurveDev cx) {
     static_assert(!(LAG && LINDF), "payment-lag trades under LINEAR_FWD_RATES go to the general kernel");
     static_assert(!XC || (LAG && DELTA && !W64 && KNOT == 0), "the two-curve mode works on payment-lag rows, per trade");
     static_assert(KNOT == 0 || (DELTA && !W64), "aggregate-only mode: any pillar count (no 64-wide Jacobian table is needed)");
+    constexpr int kBlockThreads = XC ? kXcThreads : ((LAG && DELTA && !W64 && KNOT == 0) ? kLagThreads : kLiteThreads);      // (these two hide the namespace's)
+    constexpr int kWavesPerBlock = kBlockThreads / 64;
     constexpr int PW = W64 ? kWidePad : kPillarPad;       // pillars per row of the Jacobian table
     constexpr int PPL = PW / L;                           // pillars per lane: 2, or 4 on the 64-wide table
     // KNOT: tables per wave - w; D and the pair bands P[d - 1][k] = sum over pairs of knots (k, k + d): one band (the old O)
@@ -727,7 +739,10 @@ hipError_t launch_price_knot(const CurveDev& cv, const LiteRowsDev& tr, const Ou
     return hipGetLastError();
 }
 
-size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta) {
+int lite_kernel_threads(const CurveDev& cv, bool delta, bool lag) { return (lag && delta && cv.T == 1) ? kLagThreads : kBlockThreads; }
+
+size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta, bool lag) {
+    const int kWavesPerBlock = lite_kernel_threads(cv, delta, lag) / 64;
     const size_t pw = cv.T > 1 ? kWidePad : kPillarPad;           // more than 32 pillars: the 64-wide table (W64 instantiations)
     size_t bytes = delta ? static_cast<size_t>(kWavesPerBlock) * kRecBytesPerWave + sizeof(double) * cv.Kc * pw : 0;
     bytes += sizeof(double) * (2 * static_cast<size_t>(cv.K) + 2 * cv.Kc);
@@ -739,8 +754,8 @@ size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta) {
 
 hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const OutputsDev& out, bool want_delta,
                              int n_blocks, hipStream_t stream) {
-    const size_t lds = lite_kernel_lds_bytes(cv, want_delta);
-    const dim3 grid(n_blocks), block(kBlockThreads);
+    const size_t lds = lite_kernel_lds_bytes(cv, want_delta, tr.te_w != nullptr);
+    const dim3 grid(n_blocks), block(lite_kernel_threads(cv, want_delta, tr.te_w != nullptr));
     if (tr.te_w && cv.method == 2) return hipErrorInvalidValue;        // payment-lag rows: log-linear schemes only
     if (cv.T > 1 && !cv.lj64) return hipErrorInvalidValue;             // 33-64 pillars: the wide layout's table
     hipLaunchKernelGGL(lite_kernel(want_delta, cv.method == 2, tr.te_w != nullptr, tr.n_seg > 3, cv.T > 1), grid, block, lds, stream, cv, tr, out, CurveDev{});
@@ -755,19 +770,22 @@ LiteFn lite_xc_kernel(bool many) {
 }  // namespace
 
 size_t lite_xc_kernel_lds_bytes(const CurveDev& cv, const CurveDev& cx) {
-    size_t bytes = lite_kernel_lds_bytes(cv, true);
+    constexpr int waves = kXcThreads / 64;
+    size_t bytes = lite_kernel_lds_bytes(cv, true, false) + static_cast<size_t>(waves - kWavesPerBlock) * kRecBytesPerWave;
     bytes += sizeof(double) * (static_cast<size_t>(cx.Kc) * kPillarPad + 2 * static_cast<size_t>(cx.K) + 2 * cx.Kc);
     bytes += sizeof(int16_t) * (2 * static_cast<size_t>(cx.K) + 2 * static_cast<size_t>(cx.n_lut));
-    const size_t reduce = sizeof(double) * kWavesPerBlock * (1 + 2 * kPillarPad);
+    const size_t reduce = sizeof(double) * waves * (1 + 2 * kPillarPad);
     if (bytes < reduce) bytes = reduce;
     return (bytes + 15) & ~static_cast<size_t>(15);
 }
+
+int lite_xc_kernel_threads() { return kXcThreads; }
 
 hipError_t launch_price_lite_xc(const CurveDev& cv, const CurveDev& cx, const LiteRowsDev& tr, const OutputsDev& out, int n_blocks,
                                 hipStream_t stream) {
     if (!tr.te_w || cv.method == 2 || cx.method == 2 || cv.T > 1 || cx.T > 1 || !cv.lj || !cx.lj) return hipErrorInvalidValue;
     const size_t lds = lite_xc_kernel_lds_bytes(cv, cx);
-    hipLaunchKernelGGL(lite_xc_kernel(tr.n_seg > 3), dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out, cx);
+    hipLaunchKernelGGL(lite_xc_kernel(tr.n_seg > 3), dim3(n_blocks), dim3(kXcThreads), lds, stream, cv, tr, out, cx);
     return hipGetLastError();
 }
 

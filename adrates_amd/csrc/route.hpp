@@ -81,7 +81,7 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
     Plan plan;
     const int64_t n = tc.n;
     if (n == 0) return plan;
-    const bool lite_fits = lite_kernel_lds_bytes(cv, want_delta) <= kLds;
+    const bool lite_fits = lite_kernel_lds_bytes(cv, want_delta, true) <= kLds;
     const bool log_linear = cv.method != 2;
     // aggregate-only request: the lite table's trades in knot space
     plan.knot = has_agg && !per_trade && want_delta && tc.lite_units > 0 && cv.Kc <= knot_kc_max &&
@@ -92,10 +92,12 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
     // the trades no knot pass takes: everything / outside the lite table / and outside its payment-lag rows
     const int rest_of_knot = plan.knot_lag ? S_NONLITE_B : (plan.knot ? S_NONLITE : S_ALL);
     const int64_t rest_of_knot_n = plan.knot_lag ? tc.n_nonlite_b : (plan.knot ? tc.n_nonlite : n);
-    auto lite_blocks = [&](int64_t units) {
-        const size_t lds = lite_kernel_lds_bytes(cv, want_delta);
-        const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLds / lds)));
-        return blocks_for(units, kLiteThreads / 64, static_cast<int64_t>(n_cu) * per_cu);
+    auto lite_blocks = [&](int64_t units, bool lag = false) {
+        const size_t lds = lite_kernel_lds_bytes(cv, want_delta, lag);
+        const int threads = lite_kernel_threads(cv, want_delta, lag);
+        // (blocks of more than 512 threads are built for ONE per CU: their registers allow no second)
+        const int per_cu = threads > kLiteThreads ? 1 : static_cast<int>(std::max<size_t>(1, std::min<size_t>(2, kLds / lds)));
+        return blocks_for(units, threads / 64, static_cast<int64_t>(n_cu) * per_cu);
     };
     auto push = [&](int family, int set, int64_t items, int blocks, int ti = 0, int tj = 0) {
         if (items <= 0 || blocks <= 0) return;
@@ -126,7 +128,7 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
             rest_n = use_lite_lag ? tc.n_nonlite_b : tc.n_nonlite;
         }
         if (lite_elsewhere && !plan.knot) push(F_LITE, S_LITE, tc.lite_units, lite_blocks(tc.lite_units));
-        if (use_lite_lag && !plan.knot_lag) push(F_LITE_LAG, S_LITE_LAG, tc.lite_lag_units, lite_blocks(tc.lite_lag_units));
+        if (use_lite_lag && !plan.knot_lag) push(F_LITE_LAG, S_LITE_LAG, tc.lite_lag_units, lite_blocks(tc.lite_lag_units, true));
         if (rest_n > 0) {
             const size_t lds = wide_kernel_lds_bytes(cv.K, cv.Kc, cv.wide_nch, want_gamma);
             const int threads = wide_kernel_threads(cv.wide_nch, want_gamma);
@@ -206,7 +208,7 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
         const int64_t units = (tc.lagged_rows + fast_kernel_groups() - 1) / fast_kernel_groups();
         push(F_FAST_LAG, S_LAGGED, tc.lagged_rows, blocks_for(units, fast_kernel_threads(true) / 64, std::min(tc.lag_blocks, n_cu)));
     }
-    if (use_lite_lag && !plan.knot_lag) push(F_LITE_LAG, S_LITE_LAG, tc.lite_lag_units, lite_blocks(tc.lite_lag_units));
+    if (use_lite_lag && !plan.knot_lag) push(F_LITE_LAG, S_LITE_LAG, tc.lite_lag_units, lite_blocks(tc.lite_lag_units, true));
     if (use_lag && tc.lagged_chained_rows > 0) push(F_FAST_LAG_CHAINED, S_LAGGED_CHAINED, tc.lagged_chained_rows, tc.lagged_chained_blocks);
     if (plan.total_blocks > max_blocks) plan.error = "grid exceeds scratch";
     knot_launch();
