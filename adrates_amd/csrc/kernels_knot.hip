@@ -60,17 +60,23 @@ __device__ __forceinline__ double lc_at(const CurveDev& cv, const int* col_off, 
     return cv.lc_lanes[((static_cast<size_t>(tj * (tj + 1) / 2 + ti) * cv.Kc + k) * 64 + lane) * kGammaPerLane + e];
 }
 
-// Block p < P: row p of the gamma matrix (thread q); block P: pv and the delta ladder (thread p).  One wavefront per block.
+// Block p < P: row p of the gamma matrix (lane q); block P: pv and the delta ladder (lane p).  Sixteen wavefronts per block, each
+// taking every sixteenth knot; their sums are added in wave order.  (One wavefront walking all Kc knots was a chain of Kc L2
+// round trips: 85 us per aggregate-only pass of 100 k trades; 51 with four waves, 42 with sixteen.)
 // The reduced sums are staged in LDS first (every thread walks all of them: as global loads behind `continue`s they were a
 // chain of ~2 000 L2 round trips per thread - 0.7 ms for a 16-band record); the overflow matrix is scanned 64 entries at a
 // time, coalesced, and only the non-zero ones (normally none) are visited.
-__global__ __launch_bounds__(64) void knot_project_kernel(CurveDev cv, const double* reduced, int want_delta, int want_gamma, int bands,
-                                                          const double* overflow, double* agg) {
+constexpr int kProjectWaves = 16;
+
+__global__ __launch_bounds__(64 * kProjectWaves) void knot_project_kernel(CurveDev cv, const double* reduced, int want_delta, int want_gamma,
+                                                                          int bands, const double* overflow, double* agg) {
     extern __shared__ double s_red[];                     // [1 + (2 + bands) Kc]
     __shared__ int col_off[kWidePad + 1];
+    __shared__ double s_part[kProjectWaves][64];
     const int P = cv.P, Kc = cv.Kc;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_values = want_gamma ? 1 + (2 + bands) * Kc : 1 + Kc;
-    for (int i = threadIdx.x; i < n_values; i += 64) s_red[i] = reduced[i];
+    for (int i = threadIdx.x; i < n_values; i += 64 * kProjectWaves) s_red[i] = reduced[i];
     if (threadIdx.x == 0) {
         col_off[0] = 0;
         for (int b = 0; b < kWidePad; ++b) col_off[b + 1] = col_off[b] + 2 * ((b + 2) / 2);
@@ -79,15 +85,23 @@ __global__ __launch_bounds__(64) void knot_project_kernel(CurveDev cv, const dou
     const double* w = s_red + 1;
     const double* D = w + Kc;
     const double* O = D + Kc;
+    auto sum_of_waves = [&](double mine) {                // (block-uniform calls) the four waves' sums, added in wave order
+        __syncthreads();
+        s_part[wave][lane] = mine;
+        __syncthreads();
+        double t = s_part[0][lane];
+#pragma unroll
+        for (int i = 1; i < kProjectWaves; ++i) t += s_part[i][lane];
+        return t;
+    };
     if (static_cast<int>(blockIdx.x) == P) {
         if (threadIdx.x == 0) agg[0] += s_red[0];
-        for (int q = threadIdx.x; want_delta && q < P; q += 64) {
+        for (int q0 = 0; want_delta && q0 < P; q0 += 64) {
+            const int q = q0 + lane, qq = q < P ? q : 0;
             double s = 0.0;
-            for (int k = 0; k < Kc; ++k) {
-                const double wk = w[k];
-                if (wk != 0.0) s = fma(wk, lj_at(cv, k, q), s);
-            }
-            agg[1 + q] += s * 1e-4;
+            for (int k = wave; k < Kc; k += kProjectWaves) s = fma(w[k], lj_at(cv, k, qq), s);
+            s = sum_of_waves(s);
+            if (wave == 0 && q < P) agg[1 + q] += s * 1e-4;
         }
         return;
     }
@@ -95,22 +109,22 @@ __global__ __launch_bounds__(64) void knot_project_kernel(CurveDev cv, const dou
     const int p = blockIdx.x;
     const bool any_overflow = overflow && overflow[static_cast<size_t>(Kc) * Kc] != 0.0;    // set by the kernel that used the matrix
     for (int q0 = 0; q0 < P; q0 += 64) {                   // columns in blocks of one wavefront (more than 64 pillars: several)
-        const int q = q0 + static_cast<int>(threadIdx.x);
+        const int q = q0 + lane;
         const int qq = q < P ? q : 0;                          // (lanes beyond the ladder compute a copy of column 0 and do not store)
         double s = 0.0;
-        for (int k = 0; k < Kc; ++k) {
+        for (int k = wave; k < Kc; k += kProjectWaves) {
             const double wk = w[k], dk = D[k];
             const double ap = lj_at(cv, k, p), aq = lj_at(cv, k, qq);
-            if (dk != 0.0) s = fma(dk * ap, aq, s);                      // (wave-uniform branches: the sums are the same for every thread)
+            s = fma(dk * ap, aq, s);
             for (int d = 1; d <= bands && k + d < Kc; ++d) {             // pairs of knots (k, k + d): band d
                 const double ok = O[(d - 1) * Kc + k];
-                if (ok == 0.0) continue;
+                if (ok == 0.0) continue;                                 // (wave-uniform: the sums are the same for every lane)
                 const double bp = lj_at(cv, k + d, p), bq = lj_at(cv, k + d, qq);
                 s = fma(ok, fma(ap, bq, bp * aq), s);
             }
             if (any_overflow)                                            // ... and the pairs farther apart (payment-lag rows; rare)
                 for (int l0 = k + bands + 1; l0 < Kc; l0 += 64) {
-                    const int l = l0 + static_cast<int>(threadIdx.x);
+                    const int l = l0 + lane;
                     const double mine = l < Kc ? overflow[static_cast<size_t>(k) * Kc + l] : 0.0;
                     unsigned long long any = __ballot(mine != 0.0);
                     while (any) {
@@ -123,7 +137,8 @@ __global__ __launch_bounds__(64) void knot_project_kernel(CurveDev cv, const dou
                 }
             if (wk != 0.0) s = fma(wk, lc_at(cv, col_off, k, p, qq), s);
         }
-        if (q < P) agg[1 + P + p * P + q] += s * 1e-8;
+        s = sum_of_waves(s);
+        if (wave == 0 && q < P) agg[1 + P + p * P + q] += s * 1e-8;
     }
 }
 
@@ -135,7 +150,7 @@ hipError_t launch_knot_project(const CurveDev& cv, const double* partials, int n
     hipLaunchKernelGGL(knot_reduce_kernel, dim3((n_values + 3) / 4), dim3(256), 0, stream, partials, n_blocks, stride, n_values, reduced);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(knot_project_kernel, dim3(cv.P + 1), dim3(64), sizeof(double) * static_cast<size_t>(stride), stream, cv, reduced,
+    hipLaunchKernelGGL(knot_project_kernel, dim3(cv.P + 1), dim3(64 * kProjectWaves), sizeof(double) * static_cast<size_t>(stride), stream, cv, reduced,
                        want_delta ? 1 : 0, want_gamma ? 1 : 0, bands, want_gamma ? overflow : nullptr, agg);
     return hipGetLastError();
 }
