@@ -66,6 +66,14 @@ constexpr int kXcThreads = ADR_LITE_XC_THREADS;
 #define ADR_LITE_LAG_THREADS 768                  // the payment-lag rows' PV + delta instantiation likewise (145 VGPRs; 68 bytes of spills at 128: +8 %)
 #endif
 constexpr int kLagThreads = ADR_LITE_LAG_THREADS;
+#ifndef ADR_LITE_W64_THREADS
+#define ADR_LITE_W64_THREADS 768                  // the 64-wide ladders likewise (157 VGPRs; 104-176 bytes of spills at 128: 0.105 -> 0.064 ms per 100 k trades)
+#endif
+constexpr int kW64Threads = ADR_LITE_W64_THREADS;
+// threads per block of an instantiation: 512 (four waves per SIMD in two blocks per CU) unless its registers ask for more
+constexpr int lite_block_threads(bool delta, bool lag, bool w64, int knot, bool xc) {
+    return xc ? kXcThreads : ((delta && knot == 0 && w64) ? kW64Threads : ((delta && knot == 0 && lag) ? kLagThreads : kLiteThreads));
+}
 constexpr int L = kLiteSlots;                 // lanes per trade
 constexpr int G = 64 / L;                     // trades per wavefront
 constexpr int kRecBytesPerWave = G * (2 * L + 2) * 16;  // per group: two 16-byte entries per lane + a pad entry
@@ -135,14 +143,14 @@ struct CurveLds {
 // KNOT: 0 = per-trade ladders; 1 = aggregate-only, first order (w_k); 2 = aggregate-only with the second-order sums
 // XC: foreign-leg rows of cross-currency swaps on two curves (cv: the foreign OIS curve, cx: the XCCY curve)
 template <bool DELTA, bool LINDF, bool LAG, int NSEG, bool W64 = false, int KNOT = 0, bool XC = false>
-__global__ __launch_bounds__(XC ? kXcThreads : ((LAG && DELTA && !W64 && KNOT == 0) ? kLagThreads : kBlockThreads),
-                            XC ? kXcThreads / 256 : ((LAG && DELTA && !W64 && KNOT == 0 && kLagThreads != kBlockThreads) ? kLagThreads / 256 : kLiteWavesPerSimd))
+__global__ __launch_bounds__(lite_block_threads(DELTA, LAG, W64, KNOT, XC), lite_block_threads(DELTA, LAG, W64, KNOT, XC) == kBlockThreads
+                                                                                  ? kLiteWavesPerSimd : lite_block_threads(DELTA, LAG, W64, KNOT, XC) / 256)
 void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                                                                                        OutputsDev out, CurveDev cx) {
     static_assert(!(LAG && LINDF), "payment-lag trades under LINEAR_FWD_RATES go to the general kernel");
     static_assert(!XC || (LAG && DELTA && !W64 && KNOT == 0), "the two-curve mode works on payment-lag rows, per trade");
     static_assert(KNOT == 0 || (DELTA && !W64), "aggregate-only mode: any pillar count (no 64-wide Jacobian table is needed)");
-    constexpr int kBlockThreads = XC ? kXcThreads : ((LAG && DELTA && !W64 && KNOT == 0) ? kLagThreads : kLiteThreads);      // (these two hide the namespace's)
+    constexpr int kBlockThreads = lite_block_threads(DELTA, LAG, W64, KNOT, XC);      // (these two hide the namespace's)
     constexpr int kWavesPerBlock = kBlockThreads / 64;
     constexpr int PW = W64 ? kWidePad : kPillarPad;       // pillars per row of the Jacobian table
     constexpr int PPL = PW / L;                           // pillars per lane: 2, or 4 on the 64-wide table
@@ -739,7 +747,7 @@ hipError_t launch_price_knot(const CurveDev& cv, const LiteRowsDev& tr, const Ou
     return hipGetLastError();
 }
 
-int lite_kernel_threads(const CurveDev& cv, bool delta, bool lag) { return (lag && delta && cv.T == 1) ? kLagThreads : kBlockThreads; }
+int lite_kernel_threads(const CurveDev& cv, bool delta, bool lag) { return lite_block_threads(delta, lag, cv.T > 1, 0, false); }
 
 size_t lite_kernel_lds_bytes(const CurveDev& cv, bool delta, bool lag) {
     const int kWavesPerBlock = lite_kernel_threads(cv, delta, lag) / 64;
