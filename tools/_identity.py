@@ -20,7 +20,9 @@ def from_log(path):
 def git_head():
     try:
         head = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
-        dirty = subprocess.run(["git", "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True).stdout.strip()
+        # (the summaries themselves are being rewritten while this runs: profiles/ does not count)
+        dirty = subprocess.run(["git", "status", "--porcelain", "--untracked-files=no", "--", ".", ":!profiles"],
+                               capture_output=True, text=True).stdout.strip()
         return head + ("+dirty" if dirty else "")
     except Exception:
         return None
