@@ -14,7 +14,7 @@ copies = {
     f"bench_{tag}_long_legs.json": "long_legs_bench.json", f"bench_{tag}_payment_lag.json": "payment_lag_bench.json",
     f"bench_{tag}_xccy.json": "xccy_bench.json", f"bench_{tag}_mixed_book.json": "mixed_book_bench.json",
     f"bench_{tag}_curve_build.json": "curve_build_bench.json", f"ablate_{tag}.log": "final_ablations.txt",
-    f"pmc_{tag}.txt": "final_pmc_counters.txt", f"pmc_{tag}_lag.txt": "payment_lag_pmc_counters.txt",
+    f"pmc_{tag}.txt": "final_pmc_counters.txt", f"pmc_{tag}_lag.txt": "payment_lag_pmc_counters.txt", f"pmc_{tag}_fp64.json": "final_fp64.json",
     f"stamps_{tag}.txt": "final_phase_stamps.txt", f"stamps_{tag}_lag.txt": "payment_lag_phase_stamps.txt",
     f"bench_{tag}_many_pillars.json": "many_pillars_bench.json", f"bench_{tag}_payment_lag_linfwd.json": "payment_lag_linfwd_bench.json",
     f"ablate_{tag}_wide.log": "wide_ablations.txt", f"pmc_{tag}_wide.txt": "wide_pmc_counters.txt",
