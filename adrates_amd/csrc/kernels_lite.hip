@@ -132,6 +132,7 @@ struct CurveLds {
     int K, method;
 };
 
+
 // LINDF: LINEAR_FWD_RATES - D = ba d_a + bb d_b, a node is two single-knot exponentials and its two entries carry the
 // two amounts (kernels_fast.hip, `lindf`)
 // LAG: the rows hold trades whose coupons accrue to a date other than their payment date and / or carry a per-coupon
@@ -459,10 +460,18 @@ void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                 double ls = 0.0, le = 0.0, lp = 0.0;
                 const bool paid_later = valid && tp != 0.0;          // (paid AT the value time: D_x = 1, no basis sensitivity)
                 if (paid_later) { qp = curve_lookup<true>(c2, tp); lp = fma(qp.ba, c2.log_df[qp.ka], qp.bb * c2.log_df[qp.kb]); }
-                if (ratio) { qe = curve_lookup<true>(c, te); le = fma(qe.ba, c.log_df[qe.ka], qe.bb * c.log_df[qe.kb]); }
-                const double prev_ratio = row_prev(ratio ? 1.0 : 0.0), prev_te = row_prev(te), le_prev = row_prev(le);
+                const double prev_ratio = row_prev(ratio ? 1.0 : 0.0), prev_te = row_prev(te);
                 const bool chained = ratio && l > 0 && prev_ratio != 0.0 && prev_te == ts;      // (as in the payment-lag rows below)
-                if (ratio && !chained) { qs = curve_lookup<true>(c, ts); ls = fma(qs.ba, c.log_df[qs.ka], qs.bb * c.log_df[qs.kb]); }
+                bool own_ts = ratio && !chained;
+                const unsigned starts = static_cast<unsigned>(__ballot(own_ts) >> gbase) & 0xffffu;
+                const int src = gbase + (starts ? __builtin_ctz(starts) : 0);
+                const double st = __shfl(ts, src, 64);
+                const bool spare = starts != 0 && l == m_flt;                                   // (the spare-lane pass of the rows below)
+                if (starts != 0 && lane == src) own_ts = false;
+                if (ratio || spare) { qe = curve_lookup<true>(c, spare ? st : te); le = fma(qe.ba, c.log_df[qe.ka], qe.bb * c.log_df[qe.kb]); }
+                const double le_prev = row_prev(le), ls_spare = __shfl(le, gbase + m_flt, 64);
+                if (starts != 0 && lane == src) ls = ls_spare;
+                if (own_ts) { qs = curve_lookup<true>(c, ts); ls = fma(qs.ba, c.log_df[qs.ka], qs.bb * c.log_df[qs.kb]); }
                 if (chained) ls = le_prev;
                 const double w_not = sl * N * cw;
                 const double dx = exp(lp);                            // D_x(tp) / D_x(0)
@@ -476,9 +485,11 @@ void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                 {
                     const double next_flag = row_next(chained ? 1.0 : 0.0), next_om = row_next(om_r);
                     const bool next_chained = l + 1 < L && next_flag != 0.0;
-                    const double om_e = (next_chained ? next_om : 0.0) - om_r;
-                    sweep(ratio && !chained, om_r * qs.ba, om_r * qs.bb, qs.ka, qs.kb, qs.ba, qs.bb, false);
-                    sweep(ratio, om_e * qe.ba, om_e * qe.bb, qe.ka, qe.kb, qe.ba, qe.bb, false);
+                    double om_e = (next_chained ? next_om : 0.0) - om_r;
+                    const double om_src = __shfl(om_r, src, 64);
+                    if (spare) om_e = om_src;                         // the spare lane's entries: the start of coupon `src`
+                    if (__ballot(own_ts)) sweep(own_ts, om_r * qs.ba, om_r * qs.bb, qs.ka, qs.kb, qs.ba, qs.bb, false);
+                    sweep(ratio || spare, om_e * qe.ba, om_e * qe.bb, qe.ka, qe.kb, qe.ba, qe.bb, false);
                     sweep(paid_later, om_b * qp.ba, om_b * qp.bb, qp.ka, qp.kb, qp.ba, qp.bb, false, true);
                 }
                 ADR_STAMP(3);   // entries + ladders
@@ -496,11 +507,27 @@ void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                 // instead of searching again, and its (+) entries join the previous lane's (-) entries on the same two knots:
                 // one lookup, one exponential and one pair of entries per coupon instead of two; only a row's first coupon
                 // (and a coupon after an accrual gap) looks its start time up and leaves start entries of its own.
-                if (ratio) { qe = curve_lookup<true>(c, te); le = fma(qe.ba, c.log_df[qe.ka], qe.bb * c.log_df[qe.kb]); }
+                // The row's first start of its own (the leg's first coupon, as a rule) is looked up by the row's SPARE lane
+                // (rows hold 15 coupons) in the same pass as the accrual ends, and leaves its entries from there in the same
+                // sweep: a pass of its own cost a whole lookup and a whole hand-off for one lane in sixteen.
                 // (every cross-lane move sits outside conditionals: inside one, its source lanes may be masked off)
-                const double prev_ratio = row_prev(ratio ? 1.0 : 0.0), prev_te = row_prev(te), le_prev = row_prev(le);
+                const double prev_ratio = row_prev(ratio ? 1.0 : 0.0), prev_te = row_prev(te);
                 const bool chained = ratio && l > 0 && prev_ratio != 0.0 && prev_te == ts;
-                if (ratio && !chained) { qs = curve_lookup<true>(c, ts); ls = fma(qs.ba, c.log_df[qs.ka], qs.bb * c.log_df[qs.kb]); }
+                bool own_ts = ratio && !chained;
+                const unsigned starts = static_cast<unsigned>(__ballot(own_ts) >> gbase) & 0xffffu;
+                const int src = gbase + (starts ? __builtin_ctz(starts) : 0);
+                const double st = __shfl(ts, src, 64);
+                const bool spare = starts != 0 && l == m_flt;
+                if (starts != 0 && lane == src) own_ts = false;
+                if (ratio || spare) { qe = curve_lookup<true>(c, spare ? st : te); le = fma(qe.ba, c.log_df[qe.ka], qe.bb * c.log_df[qe.kb]); }
+                const double le_prev = row_prev(le), ls_spare = __shfl(le, gbase + m_flt, 64);
+                if (starts != 0 && lane == src) ls = ls_spare;
+                if constexpr (KNOT == 2) {          // the second-order sums below want the start's knots and weights in the coupon's lane
+                    const int ska = __shfl(qe.ka, gbase + m_flt, 64), skb = __shfl(qe.kb, gbase + m_flt, 64);
+                    const double sba = __shfl(qe.ba, gbase + m_flt, 64), sbb = __shfl(qe.bb, gbase + m_flt, 64);
+                    if (starts != 0 && lane == src) { qs.ka = ska; qs.kb = skb; qs.ba = sba; qs.bb = sbb; }
+                }
+                if (own_ts) { qs = curve_lookup<true>(c, ts); ls = fma(qs.ba, c.log_df[qs.ka], qs.bb * c.log_df[qs.kb]); }    // (after an accrual gap: rare)
                 if (chained) ls = le_prev;
                 const double w_not = sl * N * cw;
                 const double om_r = ratio ? w_not * exp(ls - le + lp) : 0.0;
@@ -539,9 +566,11 @@ void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                     // the end entries carry -omega of their own coupon and +omega of the next one when that one is chained to it
                     const double next_flag = row_next(chained ? 1.0 : 0.0), next_om = row_next(om_r);
                     const bool next_chained = l + 1 < L && next_flag != 0.0;
-                    const double om_e = (next_chained ? next_om : 0.0) - om_r;
-                    sweep(ratio && !chained, om_r * qs.ba, om_r * qs.bb, qs.ka, qs.kb, qs.ba, qs.bb, false);
-                    sweep(ratio, om_e * qe.ba, om_e * qe.bb, qe.ka, qe.kb, qe.ba, qe.bb, false);
+                    double om_e = (next_chained ? next_om : 0.0) - om_r;
+                    const double om_src = __shfl(om_r, src, 64);
+                    if (spare) om_e = om_src;                         // the spare lane's entries: the start of coupon `src`
+                    if (__ballot(own_ts)) sweep(own_ts, om_r * qs.ba, om_r * qs.bb, qs.ka, qs.kb, qs.ba, qs.bb, false);
+                    sweep(ratio || spare, om_e * qe.ba, om_e * qe.bb, qe.ka, qe.kb, qe.ba, qe.bb, false);
                     sweep(paid_later, (om_r + om_p) * qp.ba, (om_r + om_p) * qp.bb, qp.ka, qp.kb, qp.ba, qp.bb, false);
                 }
                 ADR_STAMP(3);   // entries + ladder
