@@ -562,11 +562,11 @@ def route_host(interp_method: int, times, dfs, jac, hess, batch, req_mask: int, 
     tp, te, al = _f64(batch.flt_tp), _f64(batch.flt_te), _f64(batch.flt_alpha)
     w = None if batch.flt_weight is None else _f64(batch.flt_weight)
     cover = np.zeros(max(n, 1), dtype=np.int32)
-    rows = np.zeros((32, 4), dtype=np.int32)
+    rows = np.zeros((64, 4), dtype=np.int32)          # (a 256-pillar curve with GAMMA: 36 tile-pair launches + the knot passes)
     got = _check(load().adr_route_host(int(interp_method), K, P, _ptr(times), _ptr(dfs), _ptr(jac), _ptr(hess_c), int(curve_flags), n,
                                        _ptr(fo, _i64p), _ptr(lo, _i64p), _ptr(tp), _ptr(te), _ptr(al), _ptr(w), int(req_mask),
                                        1 if per_trade else 0, 1 if aggregate else 0, int(n_cu),
-                                       cover.ctypes.data_as(C.POINTER(C.c_int32)), rows.ctypes.data_as(C.POINTER(C.c_int32)), 32),
+                                       cover.ctypes.data_as(C.POINTER(C.c_int32)), rows.ctypes.data_as(C.POINTER(C.c_int32)), 64),
                  "adr_route_host")
-    launches = [(ROUTE_FAMILIES[f], ROUTE_SETS[s_], int(items), int(blocks)) for f, s_, items, blocks in rows[:min(got, 32)]]
+    launches = [(ROUTE_FAMILIES[f], ROUTE_SETS[s_], int(items), int(blocks)) for f, s_, items, blocks in rows[:min(got, 64)]]
     return launches, cover[:n]
