@@ -148,7 +148,7 @@ __global__ __launch_bounds__(lite_block_threads(DELTA, LAG, W64, KNOT, XC), lite
                                                                                   ? kLiteWavesPerSimd : lite_block_threads(DELTA, LAG, W64, KNOT, XC) / 256)
 void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                                                                                        OutputsDev out, CurveDev cx) {
-    static_assert(!(LAG && LINDF), "payment-lag trades under LINEAR_FWD_RATES go to the general kernel");
+    static_assert(!(XC && LINDF), "the two-curve mode: log-linear schemes");
     static_assert(!XC || (LAG && DELTA && !W64 && KNOT == 0), "the two-curve mode works on payment-lag rows, per trade");
     static_assert(KNOT == 0 || (DELTA && !W64), "aggregate-only mode: any pillar count (no 64-wide Jacobian table is needed)");
     constexpr int kBlockThreads = lite_block_threads(DELTA, LAG, W64, KNOT, XC);      // (these two hide the namespace's)
@@ -497,11 +497,26 @@ void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                 // ---- the row's coupons: ratio node + payment node (lane = coupon); three lookups, two exponentials
                 const bool ratio = valid && accrues;
                 Lookup qs{0, 0, 0.0, 0.0}, qe{0, 0, 0.0, 0.0}, qp{0, 0, 0.0, 0.0};
-                double ls = 0.0, le = 0.0, lp = 0.0;
+                // A factor's value: its LOG discount factor (log-linear schemes: the node is one exponential of their signed sum), or
+                // under LINEAR_FWD_RATES the discount factor F = ba D_a + bb D_b itself, with the lookup's weights replaced by the
+                // factor's effective log weights g = (ba D_a, bb D_b) / F = d ln F / d ln D - what every first-order sum below uses.
+                constexpr double kNone = LINDF ? 1.0 : 0.0;           // a factor that is not there: D = 1
+                auto factor = [&](Lookup& q) {
+                    if constexpr (LINDF) {
+                        const double da = q.ba * exp(c.log_df[q.ka]);
+                        const double db = q.bb != 0.0 ? q.bb * exp(c.log_df[q.kb]) : 0.0;
+                        const double f = da + db, inv = 1.0 / f;
+                        q.ba = da * inv; q.bb = db * inv;
+                        return f;
+                    } else {
+                        return fma(q.ba, c.log_df[q.ka], q.bb * c.log_df[q.kb]);
+                    }
+                };
+                double ls = kNone, le = kNone, lp = kNone;
                 // (a coupon "paid" at the value time - the weighted coupons of a leg projected on another curve, DESIGN.md
                 // section 9 - needs no lookup: D(0) = 1 and the value-time knot carries no sensitivity)
                 const bool paid_later = valid && tp != 0.0;
-                if (paid_later) { qp = curve_lookup<true>(c, tp); lp = fma(qp.ba, c.log_df[qp.ka], qp.bb * c.log_df[qp.kb]); }
+                if (paid_later) { qp = curve_lookup<true>(c, tp); lp = factor(qp); }
                 // Accrual periods tile a leg: coupon j starts where coupon j - 1 ends.  Such a start time IS the previous
                 // lane's end time - the same lookup - so the lane takes the previous lane's log discount factor through DPP
                 // instead of searching again, and its (+) entries join the previous lane's (-) entries on the same two knots:
@@ -519,7 +534,7 @@ void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                 const double st = __shfl(ts, src, 64);
                 const bool spare = starts != 0 && l == m_flt;
                 if (starts != 0 && lane == src) own_ts = false;
-                if (ratio || spare) { qe = curve_lookup<true>(c, spare ? st : te); le = fma(qe.ba, c.log_df[qe.ka], qe.bb * c.log_df[qe.kb]); }
+                if (ratio || spare) { qe = curve_lookup<true>(c, spare ? st : te); le = factor(qe); }
                 const double le_prev = row_prev(le), ls_spare = __shfl(le, gbase + m_flt, 64);
                 if (starts != 0 && lane == src) ls = ls_spare;
                 if constexpr (KNOT == 2) {          // the second-order sums below want the start's knots and weights in the coupon's lane
@@ -527,13 +542,13 @@ void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                     const double sba = __shfl(qe.ba, gbase + m_flt, 64), sbb = __shfl(qe.bb, gbase + m_flt, 64);
                     if (starts != 0 && lane == src) { qs.ka = ska; qs.kb = skb; qs.ba = sba; qs.bb = sbb; }
                 }
-                if (own_ts) { qs = curve_lookup<true>(c, ts); ls = fma(qs.ba, c.log_df[qs.ka], qs.bb * c.log_df[qs.kb]); }    // (after an accrual gap: rare)
+                if (own_ts) { qs = curve_lookup<true>(c, ts); ls = factor(qs); }    // (after an accrual gap: rare)
                 if (chained) ls = le_prev;
                 const double w_not = sl * N * cw;
-                const double om_r = ratio ? w_not * exp(ls - le + lp) : 0.0;
+                const double om_r = ratio ? (LINDF ? w_not * ls * lp / le : w_not * exp(ls - le + lp)) : 0.0;
                 double a_q = valid ? w_not * (spread * al - (accrues ? 1.0 : 0.0)) : 0.0;
                 if (fix_merged && xtp > 0.0) a_q = fma(sf, xpay, a_q);
-                const double om_p = valid ? a_q * exp(lp) : 0.0;
+                const double om_p = valid ? a_q * (LINDF ? lp : exp(lp)) : 0.0;
                 pv += om_r + om_p;
                 ADR_STAMP(2);   // lookups + exp
                 if constexpr (KNOT == 2) {
@@ -546,6 +561,20 @@ void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                     double cc[6] = {chained ? pba : qs.ba, chained ? pbb : qs.bb, -qe.ba, -qe.bb, qp.ba, qp.bb};
                     // a payment time a few days behind the accrual end sits on the same two knots: its weights join the end's
                     // (four terms instead of six: ten sums instead of twenty-one)
+                    // LINEAR_FWD_RATES: a factor F = ba D_a + bb D_b is not an exponential of a linear form; its logarithm has the
+                    // Hessian g_a g_b (e_a - e_b)(e_a - e_b)^T (g: the effective weights), so every factor of a node of value omega
+                    // adds +- omega g_a g_b of that matrix (-: the accrual end, which divides)
+                    auto factor_curvature = [&](int ka, int kb, double ga, double gb, double om) {
+                        const double w = om * ga * gb;
+                        if (ka != 0 && w != 0.0) __hip_atomic_fetch_add(knot_d + ka, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        if (kb != 0 && w != 0.0) __hip_atomic_fetch_add(knot_d + kb, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        pair_add(ka, 1.0, kb, -1.0, w);
+                    };
+                    if constexpr (LINDF) {
+                        factor_curvature(kk[0], kk[1], cc[0], cc[1], om_r);
+                        factor_curvature(qe.ka, qe.kb, qe.ba, qe.bb, -om_r);
+                        factor_curvature(qp.ka, qp.kb, qp.ba, qp.bb, om_r + om_p);        // the ratio node's and the payment node's
+                    }
                     if (qp.ka == qe.ka && qp.kb == qe.kb) { cc[2] += cc[4]; cc[3] += cc[5]; cc[4] = 0.0; cc[5] = 0.0; }
                     if (ratio) {
 #pragma unroll
@@ -735,6 +764,7 @@ LiteFn lite_kernel_nseg(bool many) {
 
 template <bool W64>
 LiteFn lite_kernel_w(bool delta, bool lindf, bool lag, bool many_segments) {
+    if (lag && lindf) return delta ? lite_kernel_nseg<true, true, true, W64>(many_segments) : lite_kernel_nseg<false, true, true, W64>(many_segments);
     if (lag) return delta ? lite_kernel_nseg<true, false, true, W64>(many_segments) : lite_kernel_nseg<false, false, true, W64>(many_segments);
     if (lindf) return delta ? lite_kernel_nseg<true, true, false, W64>(many_segments) : lite_kernel_nseg<false, true, false, W64>(many_segments);
     return delta ? lite_kernel_nseg<true, false, false, W64>(many_segments) : lite_kernel_nseg<false, false, false, W64>(many_segments);
@@ -747,6 +777,7 @@ LiteFn lite_kernel(bool delta, bool lindf, bool lag, bool many_segments, bool w6
 // aggregate-only instantiations (KNOT = 1: first order, 2: with the second-order sums); lag: the payment-lag rows
 template <int KNOT>
 LiteFn knot_kernel_k(bool lindf, bool many, bool lag) {
+    if (lag && lindf) return many ? &price_lite_kernel<true, true, true, kLiteSegments, false, KNOT> : &price_lite_kernel<true, true, true, 3, false, KNOT>;
     if (lag) return many ? &price_lite_kernel<true, false, true, kLiteSegments, false, KNOT> : &price_lite_kernel<true, false, true, 3, false, KNOT>;
     if (lindf) return many ? &price_lite_kernel<true, true, false, kLiteSegments, false, KNOT> : &price_lite_kernel<true, true, false, 3, false, KNOT>;
     return many ? &price_lite_kernel<true, false, false, kLiteSegments, false, KNOT> : &price_lite_kernel<true, false, false, 3, false, KNOT>;
@@ -770,7 +801,7 @@ int knot_kernel_threads() { return kBlockThreads; }
 hipError_t launch_price_knot(const CurveDev& cv, const LiteRowsDev& tr, const OutputsDev& out, bool want_gamma, int n_blocks,
                              hipStream_t stream) {
     const bool lag = tr.te_w != nullptr;                                // payment-lag rows: ratio nodes, log-linear schemes
-    if (!out.knot_partials || (lag && (cv.method == 2 || (want_gamma && !out.knot_overflow)))) return hipErrorInvalidValue;
+    if (!out.knot_partials || (lag && want_gamma && !out.knot_overflow)) return hipErrorInvalidValue;
     const size_t lds = knot_kernel_lds_bytes(cv, want_gamma, lag);
     hipLaunchKernelGGL(knot_kernel(want_gamma, cv.method == 2, tr.n_seg > 3, lag), dim3(n_blocks), dim3(kBlockThreads), lds, stream, cv, tr, out, CurveDev{});
     return hipGetLastError();
@@ -793,7 +824,6 @@ hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const Ou
                              int n_blocks, hipStream_t stream) {
     const size_t lds = lite_kernel_lds_bytes(cv, want_delta, tr.te_w != nullptr);
     const dim3 grid(n_blocks), block(lite_kernel_threads(cv, want_delta, tr.te_w != nullptr));
-    if (tr.te_w && cv.method == 2) return hipErrorInvalidValue;        // payment-lag rows: log-linear schemes only
     if (cv.T > 1 && !cv.lj64) return hipErrorInvalidValue;             // 33-64 pillars: the wide layout's table
     hipLaunchKernelGGL(lite_kernel(want_delta, cv.method == 2, tr.te_w != nullptr, tr.n_seg > 3, cv.T > 1), grid, block, lds, stream, cv, tr, out, CurveDev{});
     return hipGetLastError();
@@ -832,15 +862,15 @@ hipError_t set_lite_kernel_lds_limit(size_t bytes) {
         for (int lin = 0; lin < 2; ++lin)
             for (int lag = 0; lag < 2; ++lag)
                 for (int many = 0; many < 2; ++many)
-                    if (!(lin && lag)) {
-                        fns.push_back(reinterpret_cast<const void*>(lite_kernel(d != 0, lin != 0, lag != 0, many != 0, false)));
-                        fns.push_back(reinterpret_cast<const void*>(lite_kernel(d != 0, lin != 0, lag != 0, many != 0, true)));
-                    }
+                {
+                    fns.push_back(reinterpret_cast<const void*>(lite_kernel(d != 0, lin != 0, lag != 0, many != 0, false)));
+                    fns.push_back(reinterpret_cast<const void*>(lite_kernel(d != 0, lin != 0, lag != 0, many != 0, true)));
+                }
     for (int g = 0; g < 2; ++g)
         for (int lin = 0; lin < 2; ++lin)
             for (int many = 0; many < 2; ++many) {
                 fns.push_back(reinterpret_cast<const void*>(knot_kernel(g != 0, lin != 0, many != 0, false)));
-                if (!lin) fns.push_back(reinterpret_cast<const void*>(knot_kernel(g != 0, false, many != 0, true)));
+                fns.push_back(reinterpret_cast<const void*>(knot_kernel(g != 0, lin != 0, many != 0, true)));
             }
     fns.push_back(reinterpret_cast<const void*>(lite_xc_kernel(false)));
     fns.push_back(reinterpret_cast<const void*>(lite_xc_kernel(true)));

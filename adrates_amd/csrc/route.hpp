@@ -86,8 +86,8 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
     // aggregate-only request: the lite table's trades in knot space
     plan.knot = has_agg && !per_trade && want_delta && tc.lite_units > 0 && cv.Kc <= knot_kc_max &&
                 knot_kernel_lds_bytes(cv, want_gamma) <= kLds;
-    // ... and the payment-lag rows' (ratio nodes: log-linear schemes; the pair bands of 16 want more LDS and scratch per knot)
-    plan.knot_lag = has_agg && !per_trade && want_delta && tc.lite_lag_units > 0 && log_linear && cv.Kc <= knot_lag_kc_max &&
+    // ... and the payment-lag rows' (ratio nodes, any scheme; the pair bands of 16 want more LDS and scratch per knot)
+    plan.knot_lag = has_agg && !per_trade && want_delta && tc.lite_lag_units > 0 && cv.Kc <= knot_lag_kc_max &&
                     (plan.knot || tc.lite_units == 0) && knot_kernel_lds_bytes(cv, want_gamma, true) <= kLds;
     // the trades no knot pass takes: everything / outside the lite table / and outside its payment-lag rows
     const int rest_of_knot = plan.knot_lag ? S_NONLITE_B : (plan.knot ? S_NONLITE : S_ALL);
@@ -120,7 +120,7 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
         // instantiations for the trades of its tables, the wide kernel for the rest.
         plan.wide = true;
         const bool lite_elsewhere = (!want_gamma && lite_fits && tc.lite_units > 0) || plan.knot;
-        const bool use_lite_lag = (!want_gamma && lite_fits && tc.lite_lag_units > 0 && log_linear) || plan.knot_lag;   // (priced elsewhere)
+        const bool use_lite_lag = (!want_gamma && lite_fits && tc.lite_lag_units > 0) || plan.knot_lag;   // (priced elsewhere)
         int rest_set = S_ALL;
         int64_t rest_n = n;
         if (lite_elsewhere || use_lite_lag) {     // (no plain lite rows means no trade is outside list_nonlite)
@@ -167,7 +167,7 @@ inline Plan make_plan(const CurveDev& cv, const TradeCounts& tc, bool want_delta
     const bool use_fast = cv.packed_ok != 0;
     const bool use_lite = !want_gamma && lite_fits && tc.lite_units > 0;
     const bool lite_elsewhere = use_lite || plan.knot;
-    const bool use_lite_lag = (!want_gamma && lite_fits && tc.lite_lag_units > 0 && log_linear) || plan.knot_lag;   // (priced elsewhere)
+    const bool use_lite_lag = (!want_gamma && lite_fits && tc.lite_lag_units > 0) || plan.knot_lag;   // (priced elsewhere)
     const bool use_lag = want_gamma && use_fast && (tc.lagged_rows > 0 || tc.lagged_chained_rows > 0) && tc.lag_scratch &&
                          log_linear && cv.P % 2 == 0 && tc.lagged_chained_blocks <= tc.lag_blocks && !plan.knot_lag;
     int64_t rows = tc.rows, chained = tc.chained_rows;

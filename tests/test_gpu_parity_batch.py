@@ -247,6 +247,15 @@ def test_payment_lag_portfolio_vs_c_oracle(gpu_ctx, interp):
     # value-only request (lite kernel for the trades without payment lag): same PVs up to summation order
     only_v = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), want_delta=False, want_gamma=False)
     assert_batch_parity(only_v, ref, batch.notional)
+    # PV + delta (the lite kernel's payment-lag rows; under LINEAR_FWD_RATES with the factors' effective log weights) and the
+    # book's ladder alone (the same rows in knot space, the factors' curvature terms included)
+    only_d = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), want_gamma=False, aggregate=True)
+    assert_batch_parity(only_d, dict(pv=ref["pv"], delta=ref["delta"]), batch.notional)
+    assert np.allclose(only_d["agg_delta"], ref["delta"].sum(0), rtol=1e-10, atol=1e-6)
+    book = _native.price(gpu_ctx, dc, _native.DeviceTrades(gpu_ctx, batch), per_trade=False, aggregate=True)
+    assert np.max(np.abs(book["agg_gamma"] - ref["gamma"].sum(0))) <= 1e-10 * np.abs(ref["gamma"]).sum(0).max()
+    assert np.max(np.abs(book["agg_delta"] - ref["delta"].sum(0))) <= 1e-10 * np.abs(ref["delta"]).sum(0).max()
+    assert abs(book["agg_pv"] - ref["pv"].sum()) <= 1e-10 * np.abs(ref["pv"]).sum()
     print(f"{interp.name}: worst error {worst:.2e}")
 
 
