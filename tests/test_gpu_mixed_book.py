@@ -88,6 +88,36 @@ def test_terms_book_against_the_autodiff_restatement(gpu_ctx):
 
 
 @pytest.mark.slow
+def test_cross_currency_book_100k_swaps_two_launches_vs_three(gpu_ctx, monkeypatch):
+    """BASELINE configs[3] at its stated size through `price_xccy_batch`: VALUE + DELTA requests take two launches (the foreign
+    leg on two curves, adr_price_xccy_foreign); the three-batch assembly - swept against the C port above - gives the same
+    ladders per swap and as book sums, and the aggregate-only request the same book sums again."""
+    vd = F.README_VALUE_DT
+    m = SX.build_market(vd, F.GBP_PX, F.USD_PX, F.TENORS)
+    _native.set_default_context(gpu_ctx)
+    terms, _ = SX.draw_terms(vd, 100_000)
+    reqs = {RequestTypes.VALUE, RequestTypes.DELTA}
+    calls = []
+    real = _native.price_xccy_foreign
+    monkeypatch.setattr(XE._native, "price_xccy_foreign", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    two = XE.price_xccy_batch(Engine(m), terms, reqs, per_trade=True, aggregate=True)
+    book = XE.price_xccy_batch(Engine(m), terms, reqs, per_trade=False, aggregate=True)
+    assert len(calls) == 2
+    monkeypatch.setattr(XE, "FUSED_FOREIGN_LEG", False)
+    three = XE.price_xccy_batch(Engine(m), terms, reqs, per_trade=True, aggregate=True)
+    assert len(calls) == 2
+    assert np.max(np.abs(two["pv"] - three["pv"])) <= TOL * np.max(np.abs(three["pv"]))
+    for key in ("delta_dom", "delta_for", "delta_basis"):
+        a, b = np.asarray(two[key]), np.asarray(three[key])
+        scale = np.max(np.abs(b), axis=1) + 1e-8 * np.abs(np.asarray(terms.domestic_notional))
+        assert np.max(np.max(np.abs(a - b), axis=1) / scale) <= TOL, key
+        tot = np.abs(b).sum(0).max()
+        assert np.max(np.abs(two["agg_" + key] - three["agg_" + key])) <= TOL * tot, key
+        assert np.max(np.abs(book["agg_" + key] - three["agg_" + key])) <= TOL * tot, key
+    assert abs(book["agg_pv"] - three["agg_pv"]) <= TOL * np.abs(three["pv"]).sum()
+
+
+@pytest.mark.slow
 def test_mixed_book_one_step_one_aggregate_buffer(gpu_ctx):
     """configs[4], the slice of one rank: four launches (OIS; domestic, foreign-rates and foreign-flows pieces of the
     cross-currency book) write their aggregate ladders into ONE device buffer - the buffer the ranks all-reduce."""
