@@ -1241,8 +1241,8 @@ int adr_price_xccy_foreign_dev(adr_ctx* ctx, const adr_curve* foreign_curve, con
     if (req_mask & ADR_REQ_GAMMA)
         return fail(ADR_ERR_UNSUPPORTED, "adr_price_xccy_foreign: GAMMA takes the three-batch route (adr_trades_upload_weighted + adr_price)");
     const adr::CurveDev &cf = foreign_curve->dev, &cx = xccy_curve->dev;
-    if (cf.T > 1 || cx.T > 1 || cf.method == ADR_INTERP_LINEAR_FWD_RATES || cx.method == ADR_INTERP_LINEAR_FWD_RATES)
-        return fail(ADR_ERR_UNSUPPORTED, "adr_price_xccy_foreign: curves of up to 32 pillars on a log-linear scheme");
+    if (cf.T > 1 || cx.T > 1 || (cf.method == ADR_INTERP_LINEAR_FWD_RATES) != (cx.method == ADR_INTERP_LINEAR_FWD_RATES))
+        return fail(ADR_ERR_UNSUPPORTED, "adr_price_xccy_foreign: curves of up to 32 pillars, both on LINEAR_FWD_RATES or neither");
     if (adr::lite_xc_kernel_lds_bytes(cf, cx) > kLdsBudget)
         return fail(ADR_ERR_UNSUPPORTED, "adr_price_xccy_foreign: the two curves' tables exceed the LDS of a CU");
     const int64_t n = legs->dev.n;

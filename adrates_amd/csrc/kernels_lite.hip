@@ -148,7 +148,6 @@ __global__ __launch_bounds__(lite_block_threads(DELTA, LAG, W64, KNOT, XC), lite
                                                                                   ? kLiteWavesPerSimd : lite_block_threads(DELTA, LAG, W64, KNOT, XC) / 256)
 void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                                                                                        OutputsDev out, CurveDev cx) {
-    static_assert(!(XC && LINDF), "the two-curve mode: log-linear schemes");
     static_assert(!XC || (LAG && DELTA && !W64 && KNOT == 0), "the two-curve mode works on payment-lag rows, per trade");
     static_assert(KNOT == 0 || (DELTA && !W64), "aggregate-only mode: any pillar count (no 64-wide Jacobian table is needed)");
     constexpr int kBlockThreads = lite_block_threads(DELTA, LAG, W64, KNOT, XC);      // (these two hide the namespace's)
@@ -457,9 +456,22 @@ void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                 // curve), discounting on the second (the XCCY curve):  N ((R - 1) + s a) D_x(tp),  R = D_f(ts) / D_f(te)
                 const bool ratio = valid && accrues;
                 Lookup qs{0, 0, 0.0, 0.0}, qe{0, 0, 0.0, 0.0}, qp{0, 0, 0.0, 0.0};
-                double ls = 0.0, le = 0.0, lp = 0.0;
+                // (a factor's value and weights under LINEAR_FWD_RATES: as in the payment-lag rows below)
+                constexpr double kNone = LINDF ? 1.0 : 0.0;
+                auto factor = [&](const CurveLds& cc, Lookup& q) {
+                    if constexpr (LINDF) {
+                        const double da = q.ba * exp(cc.log_df[q.ka]);
+                        const double db = q.bb != 0.0 ? q.bb * exp(cc.log_df[q.kb]) : 0.0;
+                        const double f = da + db, inv = 1.0 / f;
+                        q.ba = da * inv; q.bb = db * inv;
+                        return f;
+                    } else {
+                        return fma(q.ba, cc.log_df[q.ka], q.bb * cc.log_df[q.kb]);
+                    }
+                };
+                double ls = kNone, le = kNone, lp = kNone;
                 const bool paid_later = valid && tp != 0.0;          // (paid AT the value time: D_x = 1, no basis sensitivity)
-                if (paid_later) { qp = curve_lookup<true>(c2, tp); lp = fma(qp.ba, c2.log_df[qp.ka], qp.bb * c2.log_df[qp.kb]); }
+                if (paid_later) { qp = curve_lookup<true>(c2, tp); lp = factor(c2, qp); }
                 const double prev_ratio = row_prev(ratio ? 1.0 : 0.0), prev_te = row_prev(te);
                 const bool chained = ratio && l > 0 && prev_ratio != 0.0 && prev_te == ts;      // (as in the payment-lag rows below)
                 bool own_ts = ratio && !chained;
@@ -468,14 +480,14 @@ void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                 const double st = __shfl(ts, src, 64);
                 const bool spare = starts != 0 && l == m_flt;                                   // (the spare-lane pass of the rows below)
                 if (starts != 0 && lane == src) own_ts = false;
-                if (ratio || spare) { qe = curve_lookup<true>(c, spare ? st : te); le = fma(qe.ba, c.log_df[qe.ka], qe.bb * c.log_df[qe.kb]); }
+                if (ratio || spare) { qe = curve_lookup<true>(c, spare ? st : te); le = factor(c, qe); }
                 const double le_prev = row_prev(le), ls_spare = __shfl(le, gbase + m_flt, 64);
                 if (starts != 0 && lane == src) ls = ls_spare;
-                if (own_ts) { qs = curve_lookup<true>(c, ts); ls = fma(qs.ba, c.log_df[qs.ka], qs.bb * c.log_df[qs.kb]); }
+                if (own_ts) { qs = curve_lookup<true>(c, ts); ls = factor(c, qs); }
                 if (chained) ls = le_prev;
                 const double w_not = sl * N * cw;
-                const double dx = exp(lp);                            // D_x(tp) / D_x(0)
-                const double R = ratio ? exp(ls - le) : 1.0;
+                const double dx = LINDF ? lp : exp(lp);               // D_x(tp) / D_x(0)
+                const double R = ratio ? (LINDF ? ls / le : exp(ls - le)) : 1.0;
                 const double om_r = ratio ? w_not * dx * R : 0.0;     // what the foreign rates move: N D_x(tp) D_f(ts) / D_f(te)
                 double amount = valid ? w_not * ((R - 1.0) + spread * al) : 0.0;
                 if (fix_merged && xtp > 0.0) amount = fma(sf, xpay, amount);          // an exchange paid on the coupon's date
@@ -616,12 +628,12 @@ void price_lite_kernel(CurveDev cv, LiteRowsDev tr,
                 int q_ka = 0, q_kb = 0;
                 if (qon) {
                     const Lookup q = XC ? curve_lookup<true>(c2, qt) : curve_lookup<true>(c, qt);      // XC: the exchanges, on the XCCY curve
+                    const double* lg = XC ? c2.log_df : c.log_df;
                     if (LINDF) {
-                        ca = qa * q.ba * exp(c.log_df[q.ka]);
-                        cb = q.bb != 0.0 ? qa * q.bb * exp(c.log_df[q.kb]) : 0.0;
+                        ca = qa * q.ba * exp(lg[q.ka]);
+                        cb = q.bb != 0.0 ? qa * q.bb * exp(lg[q.kb]) : 0.0;
                         pv += ca + cb;
                     } else {
-                        const double* lg = XC ? c2.log_df : c.log_df;
                         const double omega = qa * exp(fma(q.ba, lg[q.ka], q.bb * lg[q.kb]));
                         pv += omega;
                         ca = omega * q.ba; cb = omega * q.bb;
@@ -831,7 +843,8 @@ hipError_t launch_price_lite(const CurveDev& cv, const LiteRowsDev& tr, const Ou
 
 // the foreign leg of a cross-currency book on two curves (XC instantiations): cv = the foreign OIS curve, cx = the XCCY curve
 namespace {
-LiteFn lite_xc_kernel(bool many) {
+LiteFn lite_xc_kernel(bool many, bool lindf = false) {
+    if (lindf) return many ? &price_lite_kernel<true, true, true, kLiteSegments, false, 0, true> : &price_lite_kernel<true, true, true, 3, false, 0, true>;
     return many ? &price_lite_kernel<true, false, true, kLiteSegments, false, 0, true> : &price_lite_kernel<true, false, true, 3, false, 0, true>;
 }
 }  // namespace
@@ -850,9 +863,10 @@ int lite_xc_kernel_threads() { return kXcThreads; }
 
 hipError_t launch_price_lite_xc(const CurveDev& cv, const CurveDev& cx, const LiteRowsDev& tr, const OutputsDev& out, int n_blocks,
                                 hipStream_t stream) {
-    if (!tr.te_w || cv.method == 2 || cx.method == 2 || cv.T > 1 || cx.T > 1 || !cv.lj || !cx.lj) return hipErrorInvalidValue;
+    // (both curves on LINEAR_FWD_RATES, or both on a log-linear scheme: the kernel is built for one kind of factor)
+    if (!tr.te_w || (cv.method == 2) != (cx.method == 2) || cv.T > 1 || cx.T > 1 || !cv.lj || !cx.lj) return hipErrorInvalidValue;
     const size_t lds = lite_xc_kernel_lds_bytes(cv, cx);
-    hipLaunchKernelGGL(lite_xc_kernel(tr.n_seg > 3), dim3(n_blocks), dim3(kXcThreads), lds, stream, cv, tr, out, cx);
+    hipLaunchKernelGGL(lite_xc_kernel(tr.n_seg > 3, cv.method == 2), dim3(n_blocks), dim3(kXcThreads), lds, stream, cv, tr, out, cx);
     return hipGetLastError();
 }
 
@@ -872,8 +886,10 @@ hipError_t set_lite_kernel_lds_limit(size_t bytes) {
                 fns.push_back(reinterpret_cast<const void*>(knot_kernel(g != 0, lin != 0, many != 0, false)));
                 fns.push_back(reinterpret_cast<const void*>(knot_kernel(g != 0, lin != 0, many != 0, true)));
             }
-    fns.push_back(reinterpret_cast<const void*>(lite_xc_kernel(false)));
-    fns.push_back(reinterpret_cast<const void*>(lite_xc_kernel(true)));
+    for (int lin = 0; lin < 2; ++lin) {
+        fns.push_back(reinterpret_cast<const void*>(lite_xc_kernel(false, lin != 0)));
+        fns.push_back(reinterpret_cast<const void*>(lite_xc_kernel(true, lin != 0)));
+    }
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
         if (e != hipSuccess) return e;

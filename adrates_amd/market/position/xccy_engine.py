@@ -494,7 +494,7 @@ FUSED_FOREIGN_LEG = True
 def _price_fused(engine, swaps, want_value, want_delta, per_trade, aggregate):
     """PV and the three delta ladders with the foreign leg in one launch; None when the launch does not take the book
     (a leg of more than 390 coupons, a leg whose accrual ends all coincide with its payment times, curves it is not built
-    for): the caller then falls back to the three-batch assembly."""
+    for: more than 32 pillars, one of the two on LINEAR_FWD_RATES and the other not): the caller then falls back to the three-batch assembly."""
     if isinstance(swaps, XccyTerms):
         one = lambda v: v[0] if isinstance(v, (list, tuple, np.ndarray)) else v
         cur = _curves_for(engine, one(swaps.domestic_floating_index), one(swaps.foreign_floating_index),

@@ -302,7 +302,7 @@ int adr_price_dev(adr_ctx* ctx, const adr_curve* curve, const adr_trades* trades
  * XCCY curve held fixed (:1702-1712); delta_basis [n * P_x] = d pv / d (basis spreads); per bp.  agg_foreign / agg_basis: the
  * book sums in adr_price's layout ([pv, delta[P], zeros]; the PV total sits in agg_foreign[0]).  VALUE / DELTA only
  * (ADR_ERR_UNSUPPORTED with GAMMA: use three batches - adr_trades_upload_weighted - and adr_price); both curves up to 32
- * pillars on FLAT_FWD_RATES or LINEAR_ZERO_RATES; every leg at most 390 coupons with some accrual end != payment time.
+ * pillars, both on LINEAR_FWD_RATES or both on a log-linear scheme; every leg at most 390 coupons with some accrual end != payment time.
  * The _dev form enqueues on `stream` and neither allocates nor synchronises.
  */
 int adr_price_xccy_foreign(adr_ctx* ctx, const adr_curve* foreign_curve, const adr_curve* xccy_curve, const adr_trades* legs,

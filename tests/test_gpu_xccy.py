@@ -215,8 +215,10 @@ def test_foreign_leg_in_one_launch_on_two_curves(monkeypatch):
 
 def test_two_curve_entry_refuses_what_it_does_not_take(monkeypatch):
     """adr_price_xccy_foreign answers ADR_ERR_UNSUPPORTED (-2) for books outside its scope - legs without a coupon whose
-    accrual end differs from its payment time, LINEAR_FWD_RATES curves - and the engine then prices the three batches
-    (`_price_fused` returns None); a curve of another context is ADR_ERR_INVALID."""
+    accrual end differs from its payment time, a foreign curve on LINEAR_FWD_RATES with an XCCY curve on a log-linear scheme (or
+    the other way round) - and the engine then prices the three batches (`_price_fused` returns None); with both curves on
+    LINEAR_FWD_RATES the launch takes the book (a factor's effective log weights, kernels_lite.hip `factor`); a curve of another
+    context is ADR_ERR_INVALID."""
     from adrates_amd import _native
     from adrates_amd.market.position import xccy_engine as XE
     from adrates_amd.market.position.engine import Engine
@@ -230,24 +232,25 @@ def test_two_curve_entry_refuses_what_it_does_not_take(monkeypatch):
     with pytest.raises(LibError, match=r"\(-2\)"):
         _native.price_xccy_foreign(ctx, for_cur["dev"], x_dev, plain)
     plain.close()
-    # LINEAR_FWD_RATES on all three curves: the launch refuses, price_xccy_batch falls back and agrees with the oracle
-    m2, _, _ = _ois_curves()
-    for name in ("GBP_OIS_SONIA", "USD_OIS_SOFR"):
-        getattr(m2.curves, name)._interp_type = InterpTypes.LINEAR_FWD_RATES
-    m2.build_xccy_curve(name="USD_GBP_BASIS", domestic_curve_name="GBP_OIS_SONIA", foreign_curve_name="USD_OIS_SOFR",
-                        basis_spreads=[b * 1e4 for b in BASIS], tenor_list=TENORS, spot_fx=SPOT,
-                        domestic_dc_type=DayCountTypes.ACT_365F, foreign_dc_type=DayCountTypes.ACT_360,
-                        interp_type=InterpTypes.LINEAR_FWD_RATES)
     swap = _swap("6Y", 0.0041, freq=FrequencyTypes.SEMI_ANNUAL)
-    assert XE._price_fused(Engine(m2), [swap], True, True, True, False) is None
-    res = swap.position(m2).compute([RequestTypes.VALUE, RequestTypes.DELTA])
-    gbp, usd, x = m2.curves.GBP_OIS_SONIA, m2.curves.USD_OIS_SOFR, m2.curves.USD_GBP_BASIS
-    want = XO.xccy_analytics(swap, VALUE_DT, _cache(gbp), gbp._interp_type.value, _cache(usd), usd._interp_type.value,
-                             x, times_from_dates)
-    scale = _close.notional = abs(swap._domestic_leg._notional)
-    _close(res.value.amount, want["value"], scale)
-    _close(res.risk(CurveTypes.USD_OIS_SOFR).risk_ladder, want["delta_for"], scale * 1e-4)
-    _close(res.risk(CurveTypes.USD_GBP_BASIS).risk_ladder, want["delta_basis"], scale * 1e-4)
+    for x_interp, fused in ((InterpTypes.LINEAR_FWD_RATES, True), (InterpTypes.FLAT_FWD_RATES, False)):
+        m2, _, _ = _ois_curves()
+        for name in ("GBP_OIS_SONIA", "USD_OIS_SOFR"):
+            getattr(m2.curves, name)._interp_type = InterpTypes.LINEAR_FWD_RATES
+        m2.build_xccy_curve(name="USD_GBP_BASIS", domestic_curve_name="GBP_OIS_SONIA", foreign_curve_name="USD_OIS_SOFR",
+                            basis_spreads=[b * 1e4 for b in BASIS], tenor_list=TENORS, spot_fx=SPOT,
+                            domestic_dc_type=DayCountTypes.ACT_365F, foreign_dc_type=DayCountTypes.ACT_360,
+                            interp_type=x_interp)
+        assert (XE._price_fused(Engine(m2), [swap], True, True, True, False) is not None) == fused
+        res = swap.position(m2).compute([RequestTypes.VALUE, RequestTypes.DELTA])
+        gbp, usd, x = m2.curves.GBP_OIS_SONIA, m2.curves.USD_OIS_SOFR, m2.curves.USD_GBP_BASIS
+        want = XO.xccy_analytics(swap, VALUE_DT, _cache(gbp), gbp._interp_type.value, _cache(usd), usd._interp_type.value,
+                                 x, times_from_dates)
+        scale = _close.notional = abs(swap._domestic_leg._notional)
+        _close(res.value.amount, want["value"], scale)
+        _close(res.risk(CurveTypes.GBP_OIS_SONIA).risk_ladder, want["delta_dom"], scale * 1e-4)
+        _close(res.risk(CurveTypes.USD_OIS_SOFR).risk_ladder, want["delta_for"], scale * 1e-4)
+        _close(res.risk(CurveTypes.USD_GBP_BASIS).risk_ladder, want["delta_basis"], scale * 1e-4)
     other = _native.Context(0)
     with pytest.raises(LibError):
         _native.price_xccy_foreign(other, for_cur["dev"], x_dev, _native.DeviceTrades(other, synthetic.synthesize(VALUE_DT, 8, seed=3)))
