@@ -1,6 +1,6 @@
 #!/bin/bash
-# alternate two builds on tools/ab_lite.py: usage tools/ab_lite.sh N libA.so libB.so ("default" = the in-tree build)
-N=${1:-3}; A=${2:-default}; B=${3:-variants_order0.so}
+# alternate two builds on tools/ab_lite.py: usage tools/ab_lite.sh N libA.so libB.so ("default" = the in-tree build; a variant: make -C adrates_amd/csrc OUT=../../variant.so OBJDIR=build_variant EXTRA=-D...)
+N=${1:-3}; A=${2:-default}; B=${3:-default}
 cd /root/repo
 for i in $(seq $N); do
   for L in $A $B; do
