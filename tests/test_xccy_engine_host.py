@@ -57,6 +57,49 @@ def _host_no_two_curve_launch(ctx, *a, **k):
     raise LibError("adr_price_xccy_foreign failed (-2): no two-curve launch on the host stand-in")
 
 
+def _host_two_curve_launch(ctx, for_curve, x_curve, legs, want_value=True, want_delta=True, per_trade=True, aggregate=False):
+    """Stand-in for adr_price_xccy_foreign: the formula of the two-curve kernel (kernels_lite.hip, XC; engine.py:1640-1733) on
+    torch tensors - per coupon  s N ((D_f(ts) / D_f(te) - 1) + spread alpha) D_x(tp), the exchanges as flows on the XCCY curve -
+    differentiated w.r.t. the two curves' knot DFs and chained with their Jacobians.  Foreign currency, per bp."""
+    import torch
+    from oracle import cavour_oracle as O
+    b = legs.batch
+    n = b.n_trades
+    (mf, tf, dfs_f, jac_f), (mx, tx, dfs_x, jac_x) = for_curve.args[:4], x_curve.args[:4]
+    if (mf == 2) != (mx == 2):
+        return _host_no_two_curve_launch(ctx)
+    d_f = torch.tensor(dfs_f, dtype=torch.float64, requires_grad=True)
+    d_x = torch.tensor(dfs_x, dtype=torch.float64, requires_grad=True)
+    T = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64))
+    owner = torch.as_tensor(np.repeat(np.arange(n), np.diff(b.flt_off)))
+    fown = torch.as_tensor(np.repeat(np.arange(n), np.diff(b.fix_off)))
+    live, acc = torch.as_tensor(b.flt_tp >= 0.0), torch.as_tensor(b.flt_alpha > 0.0)
+    Dx = O.simple_interpolate(b.flt_tp, tx, d_x, mx)
+    R = torch.where(acc, O.simple_interpolate(b.flt_ts, tf, d_f, mf) / O.simple_interpolate(b.flt_te, tf, d_f, mf), torch.ones_like(Dx))
+    w = T(np.ones_like(b.flt_tp) if b.flt_weight is None else b.flt_weight)
+    amount = (T(b.flt_sign) * T(b.notional))[owner] * w * ((R - 1.0) + T(b.spread)[owner] * T(b.flt_alpha))
+    pv = torch.zeros(n, dtype=torch.float64).index_add(0, owner, torch.where(live, amount * Dx, torch.zeros_like(Dx)))
+    if b.fix_tp.size:
+        Df = O.simple_interpolate(b.fix_tp, tx, d_x, mx)
+        flows = T(b.fix_sign)[fown] * T(b.fix_pay) * Df
+        pv = pv.index_add(0, fown, torch.where(torch.as_tensor(b.fix_tp > 0.0), flows, torch.zeros_like(flows)))
+    Pf, Px = np.asarray(jac_f).shape[1], np.asarray(jac_x).shape[1]
+    de_f, de_x = np.zeros((n, Pf)), np.zeros((n, Px))
+    for i in range(n if want_delta else 0):
+        g_f, g_x = torch.autograd.grad(pv[i], (d_f, d_x), retain_graph=True, allow_unused=True)
+        de_f[i] = 1e-4 * np.asarray(jac_f).T @ (np.zeros(len(dfs_f)) if g_f is None else g_f.numpy())
+        de_x[i] = 1e-4 * np.asarray(jac_x).T @ (np.zeros(len(dfs_x)) if g_x is None else g_x.numpy())
+    pv = pv.detach().numpy()
+    out = {}
+    if per_trade and want_value:
+        out["pv"] = pv
+    if per_trade and want_delta:
+        out["delta_foreign"], out["delta_basis"] = de_f, de_x
+    if aggregate:
+        out.update(agg_pv=float(pv.sum()), agg_delta_foreign=de_f.sum(0), agg_delta_basis=de_x.sum(0))
+    return out
+
+
 @pytest.fixture()
 def host_engine(monkeypatch):
     monkeypatch.setattr(_native, "price_xccy_foreign", _host_no_two_curve_launch)
@@ -427,3 +470,32 @@ def test_cross_gamma_is_labelled_and_can_be_switched_off(host_engine, monkeypatc
     x = m.curves.USD_GBP_BASIS
     monkeypatch.setattr(x, "_mixed_hess_foreign_basis", None)
     assert not swap.position(m).compute(reqs).gamma.has_cross_gamma(CurveTypes.USD_OIS_SOFR, CurveTypes.USD_GBP_BASIS)
+
+
+def test_value_and_delta_requests_through_the_two_curve_launch(host_engine, monkeypatch):
+    """VALUE / DELTA requests: `compile_xccy_legs` + ONE foreign launch (`_price_fused`) - here with the kernel's formula restated
+    on torch tensors standing in for adr_price_xccy_foreign - against the autodiff restatement of Engine._compute_xccy per swap,
+    and against the three-batch assembly as book sums."""
+    from adrates_amd.market.position.engine import Engine
+    m = host_engine
+    book = _book()
+    calls = []
+    monkeypatch.setattr(_native, "price_xccy_foreign", lambda *a, **k: (calls.append(1), _host_two_curve_launch(*a, **k))[1])
+    reqs = {RequestTypes.VALUE, RequestTypes.DELTA}
+    out = xccy_engine.price_xccy_batch(Engine(m), book, reqs, per_trade=True, aggregate=True)
+    assert calls and "gamma_dom" not in out
+    for i, s in enumerate(book):
+        w = _oracle(m, s)
+        scale = abs(s._domestic_leg._notional)
+        assert abs(out["pv"][i] - w["value"]) <= 1e-10 * scale
+        for k in ("delta_dom", "delta_for", "delta_basis"):
+            assert np.max(np.abs(out[k][i] - w[k])) <= 1e-10 * scale * 1e-4, (i, k)
+    monkeypatch.setattr(xccy_engine, "FUSED_FOREIGN_LEG", False)
+    three = xccy_engine.price_xccy_batch(Engine(m), book, reqs, per_trade=True, aggregate=True)
+    assert len(calls) == 1
+    total = sum(abs(s._domestic_leg._notional) for s in book)
+    assert abs(out["agg_pv"] - three["agg_pv"]) <= 1e-10 * total
+    for k in ("delta_dom", "delta_for", "delta_basis"):
+        assert np.max(np.abs(out["agg_" + k] - three["agg_" + k])) <= 1e-10 * total * 1e-4
+    res = book[2].position(m).compute([RequestTypes.VALUE, RequestTypes.DELTA])          # the public API takes the same path
+    assert abs(res.value.amount - _oracle(m, book[2])["value"]) <= 1e-10 * abs(book[2]._domestic_leg._notional)
